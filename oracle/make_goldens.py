@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""oracle/make_goldens.py -- TEST INFRASTRUCTURE ONLY.
+
+Generates tests/golden/*.npz from the UNMODIFIED reference, compiled from /root/reference by
+`make -C oracle ref` into oracle/_ref/ref_driver (see oracle/ref_driver.cc).  Runs only in the build
+container (it needs /root/reference for the scene files); the GPU box and the test-suite consume the
+committed .npz files.  Nothing here is imported by the product.
+
+Every vector below is an OUTPUT of the reference binary (or an input fed to it):
+  camera.npz        Camera::BuildCameraFrame frames + Camera::GenerateRay probes        (camera.cc:40-240)
+  cornell_obj.npz   Mesh arrays after Scene::Init(obj) + BVH nodes/indices               (scene.cc:66, bvh_accel.cc:445)
+  cornell_eson.npz  same through the ESON loader (no facevarying normals)                (mesh_loader.cc:212)
+  teapot_obj.npz    same for teapot.obj
+  trace_*.npz       (Ray -> Intersection) batches through Scene::Trace                   (scene.cc:253)
+  render_*.npz      Render() images, 1..2 consecutive passes, OMP_NUM_THREADS=1           (render.cc:593)
+
+Rules: CWD=/root/reference so tinyobj finds the .mtl; one process per render config
+(Render() keeps `static bool initial_pass`); OMP_NUM_THREADS=1.
+"""
+import hashlib
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("MALLIE_REF", "/root/reference")
+DRIVER = os.path.join(HERE, "_ref", "ref_driver")
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+NODE_DT = np.dtype([("bmin", "<f8", 3), ("bmax", "<f8", 3), ("flag", "<i4"), ("axis", "<i4"), ("data", "<u4", 2)])
+HIT_DT = np.dtype([("hit", "<u4"), ("faceID", "<u4"), ("materialID", "<u4"), ("f0", "<u4"), ("f1", "<u4"),
+                   ("f2", "<u4"), ("t", "<f8"), ("u", "<f8"), ("v", "<f8"), ("position", "<f8", 3),
+                   ("geometricNormal", "<f8", 3), ("normal", "<f8", 3), ("texcoord", "<f8", 2)])
+assert NODE_DT.itemsize == 64 and HIT_DT.itemsize == 136
+
+
+def run(args, stdin=None):
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run([DRIVER] + [str(a) for a in args], cwd=REF, env=env, input=stdin, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout[-2000:] + r.stderr[-2000:])
+        raise SystemExit("ref_driver failed: %r" % (args,))
+    return r
+
+
+def read_mesh(prefix):
+    with open(prefix + ".mesh", "rb") as f:
+        nv, nf, hn, hu = struct.unpack("<QQBB", f.read(18))
+        verts = np.frombuffer(f.read(24 * nv), "<f8").reshape(nv, 3)
+        faces = np.frombuffer(f.read(12 * nf), "<u4").reshape(nf, 3)
+        mats = np.frombuffer(f.read(4 * nf), "<u4")
+        normals = np.frombuffer(f.read(72 * nf), "<f8").reshape(nf, 9) if hn else np.zeros((0, 9))
+        uvs = np.frombuffer(f.read(48 * nf), "<f8").reshape(nf, 6) if hu else np.zeros((0, 6))
+    with open(prefix + ".bvh", "rb") as f:
+        (nn,) = struct.unpack("<Q", f.read(8))
+        nodes = np.frombuffer(f.read(64 * nn), NODE_DT).copy()
+        (ni,) = struct.unpack("<Q", f.read(8))
+        idx = np.frombuffer(f.read(4 * ni), "<u4")
+    # the reference never initialises BVHNode::axis of a leaf (bvh_accel.cc:343-360): the dumped value is stack
+    # garbage, so it is masked here and ignored by every comparison.
+    nodes["axis"][nodes["flag"] == 1] = 0
+    return dict(verts=verts, faces=faces, matIDs=mats, normals=normals, uvs=uvs, has_normals=np.uint8(hn),
+                has_uvs=np.uint8(hu), nodes=nodes, indices=idx)
+
+
+def gen_mesh(tmp, kind, fname, name):
+    prefix = os.path.join(tmp, name)
+    run(["mesh", kind, fname, 1.0, prefix])
+    m = read_mesh(prefix)
+    # uvs of these scenes are all-zero placeholders (mesh_loader.cc:64-65); store only the flag when so.
+    if m["uvs"].size and not m["uvs"].any():
+        m["uvs"] = np.zeros((0, 6))
+        m["uvs_all_zero"] = np.uint8(1)
+    else:
+        m["uvs_all_zero"] = np.uint8(0)
+    # vertex coordinates came through float32 (tinyobj / ESON store float): keep them compact when lossless
+    if np.array_equal(m["verts"], m["verts"].astype(np.float32).astype(np.float64)):
+        m["verts"] = m["verts"].astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **m)
+    print(name, "verts", m["verts"].shape, "faces", m["faces"].shape, "nodes", m["nodes"].shape,
+          "normals", m["normals"].shape)
+    return m
+
+
+def make_rays(rng, m, n_cam, n_rand, n_vertex, n_axis, eye):
+    """A ray set that exercises primary-like rays, incoherent interior rays, exact-vertex / edge hits (t ties
+    between neighbouring triangles), axis-parallel directions (1/0 -> inf) and misses."""
+    v = m["verts"].astype(np.float64)
+    lo, hi = v.min(0), v.max(0)
+    rays = []
+    # camera-like
+    tgt = lo + (hi - lo) * rng.random((n_cam, 3))
+    d = tgt - eye
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays.append(np.hstack([np.tile(eye, (n_cam, 1)), d]))
+    # interior random
+    o = lo + (hi - lo) * (0.1 + 0.8 * rng.random((n_rand, 3)))
+    d = rng.normal(size=(n_rand, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays.append(np.hstack([o, d]))
+    # aimed exactly at mesh vertices and edge midpoints
+    f = m["faces"][rng.integers(0, len(m["faces"]), n_vertex)]
+    pick = rng.integers(0, 3, n_vertex)
+    tv = v[f[np.arange(n_vertex), pick]]
+    mid = 0.5 * (v[f[:, 0]] + v[f[:, 1]])
+    tv[::2] = mid[::2]
+    o = np.tile(eye, (n_vertex, 1)) + rng.normal(scale=0.5, size=(n_vertex, 3))
+    d = tv - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays.append(np.hstack([o, d]))
+    # axis-parallel (zero direction components -> +-inf inverse direction), unnormalised lengths too
+    o = lo + (hi - lo) * rng.random((n_axis, 3))
+    d = np.zeros((n_axis, 3))
+    ax = rng.integers(0, 3, n_axis)
+    d[np.arange(n_axis), ax] = rng.choice([-1.0, 1.0, 2.5, -0.25], n_axis)
+    second = rng.random(n_axis) < 0.3
+    d[second, (ax[second] + 1) % 3] = rng.normal(size=second.sum())
+    rays.append(np.hstack([o, d]))
+    return np.ascontiguousarray(np.vstack(rays), dtype="<f8")
+
+
+def gen_trace(tmp, kind, fname, name, rays):
+    rp = os.path.join(tmp, name + ".rays")
+    op = os.path.join(tmp, name + ".hits")
+    rays.tofile(rp)
+    run(["trace", kind, fname, 1.0, rp, op])
+    hits = np.fromfile(op, HIT_DT)
+    assert len(hits) == len(rays)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), rays=rays, hits=hits)
+    print(name, len(rays), "rays", int(hits["hit"].sum()), "hits")
+
+
+def gen_render(tmp, kind, fname, name, W, H, plane, passes, eye, lookat, up=(0, 1, 0), quat=(0, 0, 0, 0), store=True):
+    prefix = os.path.join(tmp, name)
+    run(["render", kind, fname, 1.0, W, H, int(plane), passes, *eye, *lookat, *up, *quat, prefix])
+    imgs = [np.fromfile("%s.pass%d.f32" % (prefix, p), "<f4").reshape(H, W, 3) for p in range(passes)]
+    count = np.fromfile(prefix + ".count.i32", "<i4").reshape(H, W)
+    meta = dict(W=W, H=H, plane=int(plane), passes=passes, eye=np.array(eye, "f8"), lookat=np.array(lookat, "f8"),
+                up=np.array(up, "f8"), quat=np.array(quat, "f8"), maxPathLength=16, scene=name.split("_")[1])
+    if store:
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), images=np.stack(imgs), count=count, **meta)
+    else:
+        # large frame: keep scalars + a digest only
+        im = imgs[0]
+        np.savez_compressed(os.path.join(OUT, name + ".npz"),
+                            sha256=np.frombuffer(hashlib.sha256(im.tobytes()).digest(), "u1"),
+                            mean_r=np.float64(im[..., 0].astype(np.float64).mean()),
+                            nonzero=np.int64((im[..., 0] != 0).sum()), rows=im[::64].copy(),
+                            row_ids=np.arange(0, H, 64), count_min=count.min(), count_max=count.max(), **meta)
+    print(name, [float(i[..., 0].mean()) for i in imgs])
+
+
+def gen_camera(tmp):
+    rng = np.random.default_rng(7)
+    cfgs = [
+        (512, 512, 45.0, (0, 0, 20), (0, 0, 0), (0, 1, 0), (0, 0, 0, 0)),
+        (1920, 1080, 45.0, (0, 0, 20), (0, 0, 0), (0, 1, 0), (0, 0, 0, 0)),
+        (1920, 1080, 45.0, (0, 40, 250), (0, 40, 0), (0, 1, 0), (0, 0, 0, 0)),
+        (1920, 1080, 45.0, (0, 40, 80), (0, 0, 0), (0, 1, 0), (0, 0, 0, 0)),
+        (640, 480, 60.0, (3.5, 2.25, -7.75), (0.5, 1.0, 0.25), (0, 1, 0), (0, 0, 0, 0)),
+        (512, 512, 45.0, (0, 0, 20), (0, 0, 0), (0, 1, 0), (6.123233995736766e-17, 0, 0, 1)),  # main_sdl.cc:593
+        (333, 777, 30.0, (1, 2, 3), (-4, 0.5, -6), (0.1, 0.9, 0.2), (0.1, -0.2, 0.3, 0.9)),
+        (800, 600, 75.0, (-12, 6, 9), (0, 1, 0), (0, 1, 0), (0.0, 0.38268343236508978, 0.0, 0.92387953251128674)),
+    ]
+    frames, probes, rays = [], [], []
+    for i, (W, H, fov, eye, la, up, q) in enumerate(cfgs):
+        uv = np.column_stack([rng.random(16) * W, rng.random(16) * H])
+        uv[0] = (0.0, 0.0)
+        uv[1] = (W - 0.5, H - 0.5)
+        # px + float jitter is a float32 value in the reference (render.cc:387-391): probe such values too
+        uv[2:8] = uv[2:8].astype(np.float32)
+        out = os.path.join(tmp, "cam%d.bin" % i)
+        run(["camera", W, H, repr(fov), *map(repr, map(float, eye)), *map(repr, map(float, la)),
+             *map(repr, map(float, up)), *map(repr, map(float, q)), out],
+            stdin="".join("%r %r\n" % (float(a), float(b)) for a, b in uv))
+        d = np.fromfile(out, "<f8")
+        frames.append(d[:12])
+        rays.append(d[12:].reshape(-1, 6))
+        probes.append(uv)
+    cfg_arr = np.array([[W, H, fov, *eye, *la, *up, *q] for (W, H, fov, eye, la, up, q) in cfgs], "f8")
+    np.savez_compressed(os.path.join(OUT, "camera.npz"), cfg=cfg_arr, frames=np.array(frames), probes=np.array(probes),
+                        rays=np.array(rays))
+    print("camera", len(cfgs), "frames; corner[0] =", frames[0][3:6], " corner[1] =", frames[1][3:6])
+
+
+def main():
+    if not os.path.exists(DRIVER):
+        raise SystemExit("build the reference driver first: make -C oracle ref")
+    os.makedirs(OUT, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        gen_camera(tmp)
+        mc = gen_mesh(tmp, "obj", "cornellbox_suzanne.obj", "cornell_obj")
+        gen_mesh(tmp, "eson", "cornellbox_suzanne.eson", "cornell_eson")
+        mt = gen_mesh(tmp, "obj", "teapot.obj", "teapot_obj")
+        rng = np.random.default_rng(20260929)
+        gen_trace(tmp, "obj", "cornellbox_suzanne.obj", "trace_cornell_obj",
+                  make_rays(rng, mc, 1500, 1500, 700, 300, np.array([0.0, 0.0, 20.0])))
+        gen_trace(tmp, "eson", "cornellbox_suzanne.eson", "trace_cornell_eson",
+                  make_rays(rng, mc, 300, 300, 100, 50, np.array([0.0, 5.0, 20.0])))
+        gen_trace(tmp, "obj", "teapot.obj", "trace_teapot_obj",
+                  make_rays(rng, mt, 1200, 800, 400, 100, np.array([0.0, 40.0, 250.0])))
+        eye, la = (0, 0, 20), (0, 0, 0)
+        gen_render(tmp, "obj", "cornellbox_suzanne.obj", "render_cornell_obj_64_plane_2pass", 64, 64, True, 2, eye, la)
+        gen_render(tmp, "obj", "cornellbox_suzanne.obj", "render_cornell_obj_64_noplane", 64, 64, False, 1, eye, la)
+        gen_render(tmp, "obj", "cornellbox_suzanne.obj", "render_cornell_obj_128x96_plane", 128, 96, True, 1, eye, la)
+        gen_render(tmp, "eson", "cornellbox_suzanne.eson", "render_cornell_eson_48_plane", 48, 48, True, 1, eye, la)
+        gen_render(tmp, "obj", "cornellbox_suzanne.obj", "render_cornell_obj_40x56_view2", 40, 56, True, 1,
+                   (6.5, 7.0, 14.0), (0.0, 3.0, 0.0), quat=(0.05, -0.1, 0.02, 0.99))
+        gen_render(tmp, "obj", "teapot.obj", "render_teapot_obj_64x48_plane", 64, 48, True, 1, (0, 40, 250), (0, 40, 0))
+        gen_render(tmp, "obj", "cornellbox_suzanne.obj", "render_cornell_obj_512_plane_digest", 512, 512, True, 1, eye, la,
+                   store=False)
+
+
+if __name__ == "__main__":
+    main()
