@@ -1,0 +1,160 @@
+/*
+ * include/mgpu.h -- C ABI of the MI355X render hot path (libmallie_mgpu.so).
+ *
+ * This is the drop-in boundary underneath the Mallie-compatible C++ facade (the headers under include/mallie/): plain pointers and
+ * sizes, no C++ or torch types.  Every entry point names the reference interface it replaces (paths relative to the
+ * lighttransport/mallie tree).  All functions return MGPU_OK (0) on success and a negative code on failure; nothing
+ * throws.  The caller owns every buffer it passes.  One host thread per scene handle at a time.
+ *
+ * The library contains NO CPU fallback: if no HIP device is usable every call fails with MGPU_ERR_NO_DEVICE.
+ */
+#ifndef MGPU_H_
+#define MGPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGPU_ABI_VERSION 1
+
+enum {
+  MGPU_OK = 0,
+  MGPU_ERR_INVALID = -1,     /* bad argument                                                        */
+  MGPU_ERR_NO_DEVICE = -2,   /* no usable HIP device / device index out of range                     */
+  MGPU_ERR_OOM = -3,         /* host or device allocation failed                                     */
+  MGPU_ERR_HIP = -4,         /* a HIP runtime call failed (see mgpu_last_error)                      */
+  MGPU_ERR_STACK = -5,       /* traversal needed more stack than the reference's 512 entries         */
+  MGPU_ERR_UNSUPPORTED = -6  /* e.g. MGPU_RNG_STREAM requested from the device renderer              */
+};
+
+/* RNG start-state source for mgpu_render* (SURVEY.md H1). The generator itself is the reference's xorshift128
+ * (render.cc:137-168); only where a path's 128-bit start state comes from differs. */
+enum {
+  MGPU_RNG_STREAM = 0, /* the reference's serial thread stream: NOT reproducible in parallel -> MGPU_ERR_UNSUPPORTED */
+  MGPU_RNG_TABLE = 1,  /* rng_states[((pass*H + y)*W + x)*4 .. +4]: start state of every (pass, pixel)              */
+  MGPU_RNG_HASH = 2    /* start state = hash(seed, pass_base + pass, y*W + x)  (mgpu_hash_state)                    */
+};
+
+/* 64-byte BVH node, byte-identical to the reference's BVHNode (bvh_accel.h:10-30). */
+typedef struct {
+  double bmin[3];
+  double bmax[3];
+  int32_t flag;     /* 1 = leaf, 0 = branch */
+  int32_t axis;     /* split axis of a branch */
+  uint32_t data[2]; /* leaf: {count, first index into indices}; branch: {child0, child1} */
+} MgpuNode;
+
+/* 88-byte ray, byte-identical to the reference's Ray (common.h:78-83); only org and dir are read. */
+typedef struct {
+  double org[3];
+  double dir[3];
+  double invDir[3];
+  int32_t dirSign[3];
+  int32_t pad_;
+} MgpuRay;
+
+/* 184-byte hit record, byte-identical to the reference's Intersection (intersection.h:6-24). */
+typedef struct {
+  double t, u, v;
+  uint32_t faceID, materialID;
+  uint32_t f0, f1, f2;
+  uint32_t pad_;
+  double position[3];
+  double geometricNormal[3];
+  double normal[3];
+  double tangent[3];
+  double binormal[3];
+  double texcoord[2];
+} MgpuIntersection;
+
+/* Work counters of one call (events, not bytes). "Real" rays are Scene::Trace calls made up to and including a path's
+ * first miss; the reference's post-miss continuation rays are finished analytically on the device and
+ * are reported only through trace_calls. */
+typedef struct {
+  uint64_t trace_calls;  /* reference-equivalent Scene::Trace() calls                */
+  uint64_t real_rays;    /* BVH traversals actually performed                         */
+  uint64_t nodes;        /* BVH nodes popped and box-tested                           */
+  uint64_t tris;         /* ray-triangle tests                                        */
+  uint64_t paths;        /* eye paths (= pixels * passes)                             */
+  uint64_t stack_overflow; /* != 0: some ray exceeded 512 stack entries (result invalid) */
+  double kernel_ms;      /* device time of the dominant kernel, HIP events on its stream */
+  double total_ms;       /* whole call incl. copies, host wall clock                   */
+} MgpuStats;
+
+typedef struct MgpuScene MgpuScene;
+
+/* -- library ------------------------------------------------------------------------------------------------------ */
+int mgpu_abi_version(void);
+int mgpu_device_count(void);                 /* number of usable HIP devices, 0 if none */
+const char *mgpu_last_error(void);           /* thread-local text of the last failure   */
+const char *mgpu_status_string(int status);
+
+/* -- scene: replaces the data Scene::Init leaves behind (scene.cc:66-251: Mesh arrays + BVHAccel nodes_/indices_) --- */
+/* verts 3*nv doubles; faces 3*nf; matIDs nf or NULL (then hits report 0xFFFFFFFF, bvh_accel.cc:687-691);
+ * fv_normals 9*nf or NULL (mesh.h:13); fv_uvs 6*nf or NULL; nodes/indices as BVHAccel::GetNodes()/GetIndices()
+ * (bvh_accel.h:74-75); mat_diffuse 3*nm doubles = Scene::materials_[i].diffuse (nm may be 0: default 0.5 grey,
+ * scene.h:58-65).  Everything is copied to `device` and re-laid-out there; the host arrays may be freed afterwards. */
+int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, size_t nf, const uint32_t *matIDs,
+                      const double *fv_normals, const double *fv_uvs, const MgpuNode *nodes, size_t nn,
+                      const uint32_t *indices, const double *mat_diffuse, size_t nm, int device, MgpuScene **out);
+int mgpu_scene_destroy(MgpuScene *scene);
+/* Scene::BoundingBox (scene.cc:317-333). */
+int mgpu_scene_bbox(const MgpuScene *scene, double bmin[3], double bmax[3]);
+/* Bytes resident on the device for this scene. */
+size_t mgpu_scene_device_bytes(const MgpuScene *scene);
+
+/* -- batched Scene::Trace (scene.cc:253-315 -> BVHAccel::Traverse, bvh_accel.cc:773-844) ------------------------------ */
+/* For each of n rays: out[i] = the Intersection Traverse would fill, hit[i] = its bool result. On a miss out[i] has
+ * t = DBL_MAX, u = v = 0, faceID = 0xFFFFFFFF and all other fields zero. stats may be NULL. */
+int mgpu_trace(MgpuScene *scene, const MgpuRay *rays, size_t n, MgpuIntersection *out, uint8_t *hit, MgpuStats *stats);
+
+/* -- Render (render.cc:593-708: per-pixel PathTrace, render.cc:381-456) ---------------------------------------------- */
+/* Renders `passes` passes of the window [x0,x1) x [y0,y1) of a W x H frame and returns, per window pixel, the float32
+ * sum over the passes of the per-pass radiance, added in pass order (== Render() followed by AccumImage,
+ * main_sdl.cc:138-143; with passes == 1 exactly what Render() stores).
+ *   origin/corner/du/dv : the camera frame of Camera::BuildCameraFrame (camera.cc:40-220)
+ *   maxPathLength       : the reference's kMaxPathLength (render.cc:52); bounces = maxPathLength - 1
+ *   plane               : {a,b,c,d} of the debug ground plane (prim-plane.h:15-24) or NULL when config.plane is false
+ *   image_out           : HOST buffer, full-frame indexing 3*(y*W+x)+c; only window pixels are written
+ *   count_out           : HOST buffer W*H or NULL; count[y*W+x] += passes for window pixels (render.cc:677-679)
+ */
+int mgpu_render(MgpuScene *scene, const double origin[3], const double corner[3], const double du[3],
+                const double dv[3], int W, int H, int x0, int y0, int x1, int y1, int maxPathLength, int passes,
+                const float plane[4], int rng_mode, const uint32_t *rng_states, uint64_t seed, uint32_t pass_base,
+                float *image_out, int32_t *count_out, MgpuStats *stats);
+
+/* Device-resident variant used by the multi-GPU strip renderer and the benchmark: nothing crosses PCIe.
+ * The pixel set is a list of row strips: local row j (0 <= j < n_rows) is frame row
+ *     y = y_first + (j / strip_h) * y_period + (j % strip_h)
+ * and columns [x0,x1).  d_image (DEVICE pointer, 3*n_rows*(x1-x0) floats, row-major over local rows) receives the
+ * pass-ordered float32 sum; d_count (DEVICE pointer or NULL, n_rows*(x1-x0) int32) is incremented by `passes`.
+ * d_rng_states is a DEVICE pointer in the MGPU_RNG_TABLE layout (full-frame indexing) or NULL.
+ * `stream` is a hipStream_t (NULL = the default stream); the call is asynchronous unless stats != NULL. */
+int mgpu_render_strips_device(MgpuScene *scene, const double frame[12], int W, int H, int x0, int x1, int y_first,
+                              int strip_h, int y_period, int n_rows, int maxPathLength, int passes,
+                              const float plane[4], int rng_mode, const uint32_t *d_rng_states, uint64_t seed,
+                              uint32_t pass_base, float *d_image, int32_t *d_count, void *stream, MgpuStats *stats);
+
+/* The per-(pixel,pass) start state of MGPU_RNG_HASH (host helper; the device uses the same function). */
+void mgpu_hash_state(uint64_t seed, uint32_t pass, uint32_t pixel, uint32_t state[4]);
+
+/* -- host-side pieces of the path (plain C++ on the CPU, as in the reference; no device work) -------------------------- */
+/* Camera::BuildCameraFrame (camera.cc:40-220): frame = origin[3], corner[3], du[3], dv[3]. */
+int mgpu_camera_frame(const double eye[3], const double lookat[3], const double up[3], const double quat[4], double fov,
+                      int width, int height, double frame[12]);
+/* BVHAccel::Build (bvh_accel.cc:445-482) with explicit BVHBuildOptions; *nodes_out / *indices_out are malloc'ed, release
+ * with mgpu_free. stats = {maxTreeDepth, numLeafNodes, numBranchNodes}. */
+int mgpu_bvh_build(const double *verts, size_t nv, const uint32_t *faces, size_t nf, double costTaabb,
+                   int minLeafPrimitives, int maxTreeDepth, int binSize, MgpuNode **nodes_out, size_t *nn_out,
+                   uint32_t **indices_out, int stats[3]);
+void mgpu_free(void *p);
+/* The debug ground plane Render() derives from the scene box on its first call (render.cc:620-627). */
+void mgpu_plane_from_bbox(const double bmin[3], const double bmax[3], float plane[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGPU_H_ */

@@ -1,0 +1,52 @@
+"""Builds libmallie_mgpu.so (the HIP kernels + C ABI) in-tree with hipcc for gfx950.
+
+Usage: python -m mallie_amd.build [--force]
+The .so is git-ignored but travels to the GPU box with the repo snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmallie_mgpu.so")
+SOURCES = ["mgpu_kernels.hip", "mgpu_api.hip", "host/bvh_build.cc", "host/camera.cc", "host/scene_render.cc",
+           "host/mesh_io.cc"]
+HEADERS = ["mgpu_device.hpp", "mgpu_kernels.hpp", "host/mesh_io.hpp", os.path.join("..", "..", "include", "mgpu.h"),
+           os.path.join("..", "..", "include", "mallie", "mallie_api.hpp")]
+# -ffp-contract=off: the parity contract (no FMA contraction on device or host), see csrc/mgpu_device.hpp
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
+         "-Wno-unused-function"]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm; this package has no CPU build)")
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not is_stale():
+        return LIB
+    cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed building %s" % LIB)
+    if verbose:
+        sys.stderr.write(r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,249 @@
+// host/scene_render.cc -- mallie::Scene and mallie::Render of the facade (host glue around the C ABI).
+//
+//   Scene::Init / InitFromArrays   scene.cc:66-251   (mesh load, scale / fit-to-[-1,1]^3, BVH build)
+//   Scene::Trace / BoundingBox     scene.cc:253-333
+//   Render                         render.cc:593-708 (camera frame, first-call plane setup, one pass, count++)
+#include <algorithm>
+#include <cfloat>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+
+#include "../../../include/mallie/mallie_api.hpp"
+#include "../../../include/mgpu.h"
+#include "mesh_io.hpp"
+
+namespace mallie {
+
+// ---- Scene ------------------------------------------------------------------------------------------------------------
+Scene::Scene() { memset(&mesh_, 0, sizeof(mesh_)); }
+Scene::~Scene() { FreeMesh(); }
+
+void Scene::FreeMesh() {
+  accel_.ReleaseDevice();
+  delete[] mesh_.vertices;
+  delete[] mesh_.faces;
+  delete[] mesh_.materialIDs;
+  delete[] mesh_.facevarying_normals;
+  delete[] mesh_.facevarying_uvs;
+  memset(&mesh_, 0, sizeof(mesh_));
+}
+
+bool Scene::Init(const std::string &objFilename, const std::string &esonFilename,
+                 const std::string &magicaVoxelFilename, const std::string &materialFilename, double sceneScale,
+                 bool sceneFit) {
+  (void)materialFilename; // accepted and ignored, as in the reference
+  FreeMesh();
+  materials_.clear();
+  bool ok = false;
+  if (!objFilename.empty()) {
+    ok = mesh_io::LoadObj(mesh_, objFilename.c_str());
+    printf(ok ? "Mallie:info\tmsg:Success to load .obj file [ %s ]\n" : "Mallie:err\tmsg:Failed to load .obj file [ %s ]\n",
+           objFilename.c_str());
+  } else if (!esonFilename.empty()) {
+    ok = mesh_io::LoadESON(mesh_, esonFilename.c_str());
+    printf(ok ? "Mallie:info\tmsg:Success to load .eson file [ %s ]\n" : "Mallie:err\tmsg:Failed to load .eson file [ %s ]\n",
+           esonFilename.c_str());
+  } else if (!magicaVoxelFilename.empty()) {
+    printf("Mallie:err\tmsg:Failed to load .vox file [ %s ] (MagicaVoxel input is not supported by the MI355X path)\n",
+           magicaVoxelFilename.c_str());
+  }
+  if (!ok) {
+    printf("Mallie:err\tmsg:Failed to load mesh\n");
+    return false;
+  }
+  return Finish(sceneScale, sceneFit);
+}
+
+bool Scene::InitFromArrays(const real *vertices, size_t numVertices, const unsigned int *faces, size_t numFaces,
+                           const unsigned int *materialIDs, const real *facevarying_normals,
+                           const real *facevarying_uvs, const std::vector<Material> &materials, double sceneScale,
+                           bool sceneFit) {
+  if (!vertices || !faces || !numVertices || !numFaces) return false;
+  FreeMesh();
+  mesh_.numVertices = numVertices;
+  mesh_.numFaces = numFaces;
+  mesh_.vertices = new real[3 * numVertices];
+  memcpy(mesh_.vertices, vertices, sizeof(real) * 3 * numVertices);
+  mesh_.faces = new unsigned int[3 * numFaces];
+  memcpy(mesh_.faces, faces, sizeof(unsigned int) * 3 * numFaces);
+  mesh_.materialIDs = new unsigned int[numFaces];
+  if (materialIDs) memcpy(mesh_.materialIDs, materialIDs, sizeof(unsigned int) * numFaces);
+  else memset(mesh_.materialIDs, 0, sizeof(unsigned int) * numFaces); // 0 = default material (mesh_loader.cc:295-297)
+  if (facevarying_normals) {
+    mesh_.facevarying_normals = new real[9 * numFaces];
+    memcpy(mesh_.facevarying_normals, facevarying_normals, sizeof(real) * 9 * numFaces);
+  }
+  if (facevarying_uvs) {
+    mesh_.facevarying_uvs = new real[6 * numFaces];
+    memcpy(mesh_.facevarying_uvs, facevarying_uvs, sizeof(real) * 6 * numFaces);
+  }
+  materials_ = materials;
+  return Finish(sceneScale, sceneFit);
+}
+
+bool Scene::Finish(double sceneScale, bool sceneFit) {
+  real *v = mesh_.vertices;
+  const size_t nv = mesh_.numVertices;
+  if (sceneFit) { // scene.cc:112-160: fit to [-1,1]^3, each step applied as its own rounding
+    real lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for (size_t i = 0; i < nv; i++)
+      for (int k = 0; k < 3; k++) {
+        lo[k] = std::min(lo[k], v[3 * i + k]);
+        hi[k] = std::max(hi[k], v[3 * i + k]);
+      }
+    real inv[3];
+    for (int k = 0; k < 3; k++) {
+      const real ext = hi[k] - lo[k];
+      inv[k] = (ext > 0.000001) ? (1.0 / ext) : ext;
+    }
+    printf("bmin = %f, %f, %f\n", lo[0], lo[1], lo[2]);
+    printf("bmax = %f, %f, %f\n", hi[0], hi[1], hi[2]);
+    printf("binv = %f, %f, %f\n", inv[0], inv[1], inv[2]);
+    for (size_t i = 0; i < nv; i++)
+      for (int k = 0; k < 3; k++) {
+        real &c = v[3 * i + k];
+        c -= lo[k];
+        c *= inv[k];
+        c -= 0.5;
+        c *= 2.0;
+      }
+  } else {
+    for (size_t i = 0; i < 3 * nv; i++) v[i] *= sceneScale; // scene.cc:164-168
+  }
+  BVHBuildOptions options;
+  printf("  BVH build option:\n    # of leaf primitives: %d\n    SAH binsize         : %d\n", options.minLeafPrimitives,
+         options.binSize);
+  if (!accel_.Build(&mesh_, options)) return false;
+  const BVHBuildStatistics st = accel_.GetStatistics();
+  printf("  BVH statistics:\n    # of leaf   nodes: %d\n    # of branch nodes: %d\n  Max tree depth   : %d\n",
+         st.numLeafNodes, st.numBranchNodes, st.maxTreeDepth);
+  real3 bmin, bmax;
+  BoundingBox(bmin, bmax);
+  printf("  BVH bounding box:\n    bmin = (%f, %f, %f)\n    bmax = (%f, %f, %f)\n", bmin[0], bmin[1], bmin[2], bmax[0],
+         bmax[1], bmax[2]);
+  return true;
+}
+
+bool Scene::Trace(Intersection &isect, Ray &ray) { return accel_.Traverse(isect, &mesh_, ray); }
+
+void Scene::BoundingBox(real3 &bmin, real3 &bmax) {
+  const std::vector<BVHNode> &nodes = accel_.GetNodes();
+  if (nodes.empty()) {
+    bmin = real3(0, 0, 0);
+    bmax = real3(0, 0, 0);
+    return;
+  }
+  for (int k = 0; k < 3; k++) {
+    bmin[k] = nodes[0].bmin[k];
+    bmax[k] = nodes[0].bmax[k];
+  }
+}
+
+real3 Scene::GetBackgroundRadiance(real3 &dir) {
+  (void)dir;
+  return real3(0.75, 0.75, 0.75); // scene.cc:335-338
+}
+
+// ---- RenderConfig (render.h:33-48) ----------------------------------------------------------------------------------------
+RenderConfig::RenderConfig()
+    : fov(45.0), width(512), height(512), scene_scale(1.0), scene_fit(false), plane(false), num_passes(10),
+      num_photons(10000) {
+  eye[0] = 0.0; eye[1] = 0.0; eye[2] = -5.0;
+  lookat[0] = lookat[1] = lookat[2] = 0.0;
+  up[0] = 0.0; up[1] = 1.0; up[2] = 0.0;
+  quat[0] = quat[1] = quat[2] = quat[3] = 0.0;
+}
+
+// ---- Render ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+// process-wide render state, mirroring the reference's file-scope globals (render.cc:113-116,615)
+bool gInitialPass = true;
+bool gPlane = false;
+Plane gPlaneObject;
+int gMaxPathLength = 16;
+unsigned long long gSeed = 1;
+unsigned int gPassCounter = 0;
+const unsigned int *gRngTable = NULL;
+
+void plane_from_bbox(const double bmin[3], const double bmax[3], float pl[4]) {
+  // render.cc:622-626: float zmin, float zsize, d = -(zmin - zsize * 0.0001f)
+  const float zmin = (float)bmin[1];
+  const float zsize = (float)(bmax[1] - bmin[1]);
+  pl[0] = 0;
+  pl[1] = 1;
+  pl[2] = 0;
+  pl[3] = -(zmin - zsize * 0.0001f);
+}
+
+} // namespace
+
+void SetMaxPathLength(int n) { gMaxPathLength = n < 1 ? 1 : n; }
+void SetRenderSeed(unsigned long long seed) {
+  gSeed = seed;
+  gPassCounter = 0;
+}
+void SetRenderRngTable(const unsigned int *states) { gRngTable = states; }
+
+bool RenderPasses(Scene &scene, const RenderConfig &config, std::vector<float> &image, std::vector<int> &count,
+                  const double eye[3], const double lookat[3], const double up[3], const double quat[4], int passes) {
+  const int width = config.width, height = config.height;
+  if (width <= 0 || height <= 0 || passes < 1) return false;
+  if (image.size() < (size_t)3 * width * height || count.size() < (size_t)width * height) {
+    printf("Mallie:err\tmsg:Render: image/count buffers are smaller than %dx%d\n", width, height);
+    return false;
+  }
+  double origin[3], corner[3], du[3], dv[3];
+  Camera camera(eye, lookat, up);
+  camera.BuildCameraFrame(origin, corner, du, dv, config.fov, quat, width, height);
+
+  if (gInitialPass) { // plane fixed by the FIRST scene rendered in this process (render.cc:615-628)
+    gInitialPass = false;
+    gPlane = config.plane;
+    if (gPlane) {
+      real3 bmin, bmax;
+      scene.BoundingBox(bmin, bmax);
+      float pl[4];
+      plane_from_bbox(&bmin.x, &bmax.x, pl);
+      gPlaneObject.set(pl[0], pl[1], pl[2], pl[3]);
+    }
+  }
+  MgpuScene *dev = scene.DeviceScene();
+  if (!dev) {
+    printf("Mallie:err\tmsg:Render: no device scene (%s)\n", mgpu_last_error());
+    return false;
+  }
+  const float pl[4] = {gPlaneObject.m_a, gPlaneObject.m_b, gPlaneObject.m_c, gPlaneObject.m_d};
+  const bool table = gRngTable != NULL;
+  MgpuStats st;
+  const int rc = mgpu_render(dev, origin, corner, du, dv, width, height, 0, 0, width, height, gMaxPathLength, passes,
+                             gPlane ? pl : NULL, table ? MGPU_RNG_TABLE : MGPU_RNG_HASH, gRngTable, gSeed, gPassCounter,
+                             &image[0], &count[0], &st);
+  gRngTable = NULL;
+  if (rc != MGPU_OK) {
+    printf("Mallie:err\tmsg:Render failed: %s\n", mgpu_last_error());
+    return false;
+  }
+  gPassCounter += (unsigned int)passes;
+  const double sec = st.total_ms / 1000.0;
+  printf("\r[Mallie] Render time: %f sec(s) | %f fps", sec, sec > 0 ? 1.0 / sec : 0.0);
+  fflush(stdout);
+  return true;
+}
+
+void Render(Scene &scene, const RenderConfig &config, std::vector<float> &image, std::vector<int> &count,
+            const double eye[3], const double lookat[3], const double up[3], const double quat[4], int step) {
+  if (step != 1) {
+    printf("Mallie:err\tmsg:Render: step = %d is not supported by the MI355X path (only step 1)\n", step);
+    return;
+  }
+  RenderPasses(scene, config, image, count, eye, lookat, up, quat, 1);
+}
+
+} // namespace mallie
+
+extern "C" void mgpu_plane_from_bbox(const double bmin[3], const double bmax[3], float plane[4]) {
+  mallie::plane_from_bbox(bmin, bmax, plane);
+}

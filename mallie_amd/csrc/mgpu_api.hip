@@ -1,0 +1,517 @@
+// mgpu_api.hip -- host side of the C ABI declared in include/mgpu.h.
+//
+// Scene upload re-lays the reference's Mesh + BVHAccel arrays out for the device (see mgpu_device.hpp: nodes verbatim,
+// triangles pre-gathered per leaf slot with edges precomputed, shading normals per slot) and the entry points launch
+// the gfx950 kernels of mgpu_kernels.hip.  There is no CPU execution path here: without a HIP device every call fails.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "mgpu_kernels.hpp"
+
+using namespace mgpu;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                             \
+  do {                                                                                                            \
+    hipError_t e_ = (expr);                                                                                       \
+    if (e_ != hipSuccess) return fail(MGPU_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                                      __LINE__);                                                                  \
+  } while (0)
+
+double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+constexpr int kCounterRing = 64;
+
+} // namespace
+
+struct MgpuScene {
+  int device = 0;
+  size_t nv = 0, nf = 0, nn = 0, nm = 0;
+  int tree_depth = 0;  // deepest node level (root = 0)
+  int stack_need = 1;  // entries a traversal can ever hold = tree_depth + 1
+  int cap = 16;        // LDS stack entries per lane of the instantiated kernels
+  double bmin[3], bmax[3];
+  DScene d{};
+  // owned device allocations
+  void *p_nodes = nullptr, *p_tris = nullptr, *p_slotn = nullptr, *p_mat = nullptr, *p_verts = nullptr,
+       *p_faces = nullptr, *p_fvn = nullptr, *p_fvuv = nullptr, *p_overflow = nullptr;
+  size_t overflow_lanes = 0;
+  uint32_t *p_counters = nullptr;         // kCounterRing work counters
+  unsigned long long *p_stats = nullptr;  // kStatWords
+  unsigned launch_seq = 0;
+  size_t device_bytes = 0;
+  int num_cu = 0;
+  int render_blocks_per_cu = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int dev_alloc(MgpuScene *s, void **p, size_t bytes) {
+  *p = nullptr;
+  if (!bytes) return MGPU_OK;
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) return fail(MGPU_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  s->device_bytes += bytes;
+  return MGPU_OK;
+}
+
+int upload(MgpuScene *s, void **p, const void *src, size_t bytes) {
+  int rc = dev_alloc(s, p, bytes);
+  if (rc) return rc;
+  if (bytes) HIP_TRY(hipMemcpy(*p, src, bytes, hipMemcpyHostToDevice));
+  return MGPU_OK;
+}
+
+// Validates the tree (child / leaf ranges in bounds, no cycles through an explicit visit budget) and returns its depth.
+int tree_depth(const MgpuNode *nodes, size_t nn, size_t nf, int *depth_out) {
+  struct Item { uint32_t node; int depth; };
+  std::vector<Item> stack;
+  stack.push_back({0u, 0});
+  size_t visited = 0;
+  int depth = 0;
+  while (!stack.empty()) {
+    Item it = stack.back();
+    stack.pop_back();
+    if (++visited > nn) return fail(MGPU_ERR_INVALID, "BVH is not a tree (more than %zu node visits)", nn);
+    const MgpuNode &n = nodes[it.node];
+    if (it.depth > depth) depth = it.depth;
+    if (n.flag == 0) {
+      if (n.axis < 0 || n.axis > 2) return fail(MGPU_ERR_INVALID, "node %u: bad axis %d", it.node, n.axis);
+      for (int k = 0; k < 2; k++) {
+        if (n.data[k] >= nn) return fail(MGPU_ERR_INVALID, "node %u: child %u out of range", it.node, n.data[k]);
+        stack.push_back({n.data[k], it.depth + 1});
+      }
+    } else {
+      if ((size_t)n.data[1] + n.data[0] > nf)
+        return fail(MGPU_ERR_INVALID, "leaf %u: range [%u,+%u) exceeds %zu faces", it.node, n.data[1], n.data[0], nf);
+    }
+  }
+  *depth_out = depth;
+  return MGPU_OK;
+}
+
+int set_device(const MgpuScene *s) {
+  HIP_TRY(hipSetDevice(s->device));
+  return MGPU_OK;
+}
+
+// Makes sure the HBM overflow columns cover `lanes` hardware lanes.
+int ensure_overflow(MgpuScene *s, size_t lanes) {
+  const int extra = s->stack_need - s->cap;
+  if (extra <= 0) {
+    s->d.stack_overflow = nullptr;
+    s->d.overflow_cap = 0;
+    return MGPU_OK;
+  }
+  if (lanes > s->overflow_lanes) {
+    if (s->p_overflow) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(s->p_overflow));
+      s->p_overflow = nullptr;
+    }
+    int rc = dev_alloc(s, &s->p_overflow, lanes * (size_t)extra * sizeof(uint32_t));
+    if (rc) return rc;
+    s->overflow_lanes = lanes;
+  }
+  s->d.stack_overflow = (uint32_t *)s->p_overflow;
+  s->d.overflow_cap = (uint32_t)extra;
+  return MGPU_OK;
+}
+
+void read_stats(const unsigned long long *w, MgpuStats *st) {
+  st->trace_calls = w[kStatTraceCalls];
+  st->real_rays = w[kStatRays];
+  st->nodes = w[kStatNodes];
+  st->tris = w[kStatTris];
+  st->paths = w[kStatPaths];
+  st->stack_overflow = 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int mgpu_abi_version(void) { return MGPU_ABI_VERSION; }
+
+int mgpu_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *mgpu_last_error(void) { return g_err; }
+
+const char *mgpu_status_string(int status) {
+  switch (status) {
+  case MGPU_OK: return "ok";
+  case MGPU_ERR_INVALID: return "invalid argument";
+  case MGPU_ERR_NO_DEVICE: return "no usable HIP device";
+  case MGPU_ERR_OOM: return "out of memory";
+  case MGPU_ERR_HIP: return "HIP runtime error";
+  case MGPU_ERR_STACK: return "traversal stack deeper than the reference's 512 entries";
+  case MGPU_ERR_UNSUPPORTED: return "unsupported mode";
+  default: return "unknown status";
+  }
+}
+
+void mgpu_hash_state(uint64_t seed, uint32_t pass, uint32_t pixel, uint32_t state[4]) {
+  hash_state(seed, pass, pixel, state);
+}
+
+int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, size_t nf, const uint32_t *matIDs,
+                      const double *fv_normals, const double *fv_uvs, const MgpuNode *nodes, size_t nn,
+                      const uint32_t *indices, const double *mat_diffuse, size_t nm, int device, MgpuScene **out) {
+  if (!out) return fail(MGPU_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (!verts || !faces || !nodes || !indices || nv == 0 || nf == 0 || nn == 0)
+    return fail(MGPU_ERR_INVALID, "verts/faces/nodes/indices must be non-empty");
+  if (nm && !mat_diffuse) return fail(MGPU_ERR_INVALID, "mat_diffuse is NULL with nm = %zu", nm);
+  if (nf > 0xFFFFFFF0ull || nn > 0xFFFFFFF0ull) return fail(MGPU_ERR_INVALID, "scene too large for 32-bit indices");
+  const int ndev = mgpu_device_count();
+  if (ndev <= 0) return fail(MGPU_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(MGPU_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, ndev - 1);
+  for (size_t i = 0; i < 3 * nf; i++)
+    if (faces[i] >= nv) return fail(MGPU_ERR_INVALID, "faces[%zu] = %u >= %zu vertices", i, faces[i], nv);
+  for (size_t i = 0; i < nf; i++)
+    if (indices[i] >= nf) return fail(MGPU_ERR_INVALID, "indices[%zu] = %u >= %zu faces", i, indices[i], nf);
+  int depth = 0;
+  int rc = tree_depth(nodes, nn, nf, &depth);
+  if (rc) return rc;
+  if (depth + 1 > 512) return fail(MGPU_ERR_STACK, "tree depth %d needs more than the reference's 512 stack entries", depth);
+
+  MgpuScene *s = new (std::nothrow) MgpuScene();
+  if (!s) return fail(MGPU_ERR_OOM, "host allocation failed");
+  s->device = device;
+  s->nv = nv; s->nf = nf; s->nn = nn; s->nm = nm;
+  s->tree_depth = depth;
+  s->stack_need = depth + 1;
+  s->cap = pick_stack_cap(s->stack_need);
+  for (int k = 0; k < 3; k++) { s->bmin[k] = nodes[0].bmin[k]; s->bmax[k] = nodes[0].bmax[k]; }
+
+#define TRY_OR_FREE(expr)        \
+  do {                           \
+    int rc_ = (expr);            \
+    if (rc_) {                   \
+      mgpu_scene_destroy(s);     \
+      return rc_;                \
+    }                            \
+  } while (0)
+
+  {
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) {
+      delete s;
+      return fail(MGPU_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    }
+  }
+  // slot-ordered triangle records: p0, e1 = p1-p0, e2 = p2-p0 (bvh_accel.cc:606-607), face id, material id
+  std::vector<DTri> tris(nf);
+  const size_t nstride = fv_normals ? 9 : 3;
+  std::vector<double> slotn(nstride * nf);
+  for (size_t slot = 0; slot < nf; slot++) {
+    const uint32_t face = indices[slot];
+    const double *p0 = verts + 3 * (size_t)faces[3 * (size_t)face + 0];
+    const double *p1 = verts + 3 * (size_t)faces[3 * (size_t)face + 1];
+    const double *p2 = verts + 3 * (size_t)faces[3 * (size_t)face + 2];
+    DTri &t = tris[slot];
+    for (int k = 0; k < 3; k++) {
+      t.p0[k] = p0[k];
+      t.e1[k] = p1[k] - p0[k];
+      t.e2[k] = p2[k] - p0[k];
+    }
+    t.face = face;
+    t.mat = matIDs ? matIDs[face] : kNoMaterial;
+    if (fv_normals) {
+      memcpy(&slotn[9 * slot], fv_normals + 9 * (size_t)face, 9 * sizeof(double));
+    } else {
+      // geometric normal of BuildIntersection (bvh_accel.cc:723-729): normalize(cross(p1-p0, p2-p0)), len guard 1e-6
+      const double *a = t.e1, *b = t.e2;
+      double n[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+      const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+      if (std::fabs(len) > 1.0e-6) {
+        const double inv = 1.0 / len;
+        n[0] *= inv; n[1] *= inv; n[2] *= inv;
+      }
+      memcpy(&slotn[3 * slot], n, sizeof(n));
+    }
+  }
+  TRY_OR_FREE(upload(s, &s->p_nodes, nodes, sizeof(MgpuNode) * nn));
+  TRY_OR_FREE(upload(s, &s->p_tris, tris.data(), sizeof(DTri) * nf));
+  TRY_OR_FREE(upload(s, &s->p_slotn, slotn.data(), sizeof(double) * slotn.size()));
+  TRY_OR_FREE(upload(s, &s->p_mat, mat_diffuse, sizeof(double) * 3 * nm));
+  TRY_OR_FREE(upload(s, &s->p_verts, verts, sizeof(double) * 3 * nv));
+  TRY_OR_FREE(upload(s, &s->p_faces, faces, sizeof(uint32_t) * 3 * nf));
+  TRY_OR_FREE(upload(s, &s->p_fvn, fv_normals, fv_normals ? sizeof(double) * 9 * nf : 0));
+  TRY_OR_FREE(upload(s, &s->p_fvuv, fv_uvs, fv_uvs ? sizeof(double) * 6 * nf : 0));
+  TRY_OR_FREE(dev_alloc(s, (void **)&s->p_counters, sizeof(uint32_t) * kCounterRing));
+  TRY_OR_FREE(dev_alloc(s, (void **)&s->p_stats, sizeof(unsigned long long) * kStatWords));
+  {
+    hipError_t e = hipMemset(s->p_stats, 0, sizeof(unsigned long long) * kStatWords);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev1);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+      mgpu_scene_destroy(s);
+      return fail(MGPU_ERR_HIP, "scene setup: %s", hipGetErrorString(e));
+    }
+    s->num_cu = prop.multiProcessorCount;
+  }
+  s->d.nodes = (const MgpuNode *)s->p_nodes;
+  s->d.tris = (const DTri *)s->p_tris;
+  s->d.slot_normal = (const double *)s->p_slotn;
+  s->d.mat_diffuse = (const double *)s->p_mat;
+  s->d.nm = (uint32_t)nm;
+  s->d.has_fv_normals = fv_normals ? 1 : 0;
+  s->d.verts = (const double *)s->p_verts;
+  s->d.faces = (const uint32_t *)s->p_faces;
+  s->d.fv_normals = (const double *)s->p_fvn;
+  s->d.fv_uvs = (const double *)s->p_fvuv;
+  s->d.stack_overflow = nullptr;
+  s->d.overflow_cap = 0;
+  *out = s;
+  return MGPU_OK;
+#undef TRY_OR_FREE
+}
+
+int mgpu_scene_destroy(MgpuScene *s) {
+  if (!s) return MGPU_OK;
+  (void)hipSetDevice(s->device);
+  (void)hipDeviceSynchronize();
+  void *ptrs[] = {s->p_nodes, s->p_tris, s->p_slotn, s->p_mat, s->p_verts, s->p_faces, s->p_fvn, s->p_fvuv,
+                  s->p_overflow, s->p_counters, s->p_stats};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  delete s;
+  return MGPU_OK;
+}
+
+int mgpu_scene_bbox(const MgpuScene *s, double bmin[3], double bmax[3]) {
+  if (!s || !bmin || !bmax) return fail(MGPU_ERR_INVALID, "NULL argument");
+  for (int k = 0; k < 3; k++) { bmin[k] = s->bmin[k]; bmax[k] = s->bmax[k]; }
+  return MGPU_OK;
+}
+
+size_t mgpu_scene_device_bytes(const MgpuScene *s) { return s ? s->device_bytes : 0; }
+
+int mgpu_trace(MgpuScene *s, const MgpuRay *rays, size_t n, MgpuIntersection *out, uint8_t *hit, MgpuStats *stats) {
+  if (!s) return fail(MGPU_ERR_INVALID, "scene is NULL");
+  if (n && (!rays || !out || !hit)) return fail(MGPU_ERR_INVALID, "rays/out/hit must be non-NULL");
+  const double t0 = now_ms();
+  int rc = set_device(s);
+  if (rc) return rc;
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (n == 0) return MGPU_OK;
+  const size_t blocks = (n + kBlock - 1) / kBlock;
+  if (blocks > 0x7FFFFFFFull) return fail(MGPU_ERR_INVALID, "too many rays in one call");
+  rc = ensure_overflow(s, blocks * kBlock);
+  if (rc) return rc;
+  MgpuRay *d_rays = nullptr;
+  MgpuIntersection *d_out = nullptr;
+  uint8_t *d_hit = nullptr;
+  auto cleanup = [&]() {
+    if (d_rays) (void)hipFree(d_rays);
+    if (d_out) (void)hipFree(d_out);
+    if (d_hit) (void)hipFree(d_hit);
+  };
+#define TRY_T(expr)                                                                                   \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess) {                                                                           \
+      cleanup();                                                                                      \
+      return fail(MGPU_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));                       \
+    }                                                                                                 \
+  } while (0)
+  TRY_T(hipMalloc((void **)&d_rays, sizeof(MgpuRay) * n));
+  TRY_T(hipMalloc((void **)&d_out, sizeof(MgpuIntersection) * n));
+  TRY_T(hipMalloc((void **)&d_hit, n));
+  TRY_T(hipMemcpy(d_rays, rays, sizeof(MgpuRay) * n, hipMemcpyHostToDevice));
+  TRY_T(hipMemsetAsync(s->p_stats, 0, sizeof(unsigned long long) * kStatWords, 0));
+  TRY_T(hipEventRecord(s->ev0, 0));
+  launch_trace(s->cap, dim3((unsigned)blocks), 0, s->d, d_rays, n, d_out, d_hit, s->p_stats);
+  TRY_T(hipGetLastError());
+  TRY_T(hipEventRecord(s->ev1, 0));
+  TRY_T(hipMemcpy(out, d_out, sizeof(MgpuIntersection) * n, hipMemcpyDeviceToHost));
+  TRY_T(hipMemcpy(hit, d_hit, n, hipMemcpyDeviceToHost));
+  if (stats) {
+    unsigned long long w[kStatWords];
+    TRY_T(hipMemcpy(w, s->p_stats, sizeof(w), hipMemcpyDeviceToHost));
+    read_stats(w, stats);
+    float ms = 0.f;
+    TRY_T(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    stats->kernel_ms = ms;
+    stats->total_ms = now_ms() - t0;
+  }
+  cleanup();
+  return MGPU_OK;
+#undef TRY_T
+}
+
+int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H, int x0, int x1, int y_first,
+                              int strip_h, int y_period, int n_rows, int maxPathLength, int passes,
+                              const float plane[4], int rng_mode, const uint32_t *d_rng_states, uint64_t seed,
+                              uint32_t pass_base, float *d_image, int32_t *d_count, void *stream, MgpuStats *stats) {
+  if (!s || !frame || !d_image) return fail(MGPU_ERR_INVALID, "scene/frame/d_image must be non-NULL");
+  if (W <= 0 || H <= 0 || x0 < 0 || x1 > W || x0 > x1) return fail(MGPU_ERR_INVALID, "bad window columns");
+  if (strip_h <= 0 || y_period < strip_h || n_rows < 0 || y_first < 0) return fail(MGPU_ERR_INVALID, "bad strip layout");
+  if (maxPathLength < 1 || passes < 1) return fail(MGPU_ERR_INVALID, "maxPathLength and passes must be >= 1");
+  if ((uint64_t)W * (uint64_t)H > 0xFFFFFFFFull) return fail(MGPU_ERR_INVALID, "frame too large");
+  if (rng_mode == MGPU_RNG_STREAM)
+    return fail(MGPU_ERR_UNSUPPORTED,
+                "the reference's serial RNG stream cannot be reproduced in parallel; capture per-pixel start states "
+                "and use MGPU_RNG_TABLE");
+  if (rng_mode != MGPU_RNG_TABLE && rng_mode != MGPU_RNG_HASH) return fail(MGPU_ERR_INVALID, "bad rng_mode %d", rng_mode);
+  if (rng_mode == MGPU_RNG_TABLE && !d_rng_states) return fail(MGPU_ERR_INVALID, "MGPU_RNG_TABLE needs rng_states");
+  if (n_rows > 0) {
+    const int j = n_rows - 1;
+    const long long ylast = (long long)y_first + (long long)(j / strip_h) * y_period + (j % strip_h);
+    if (ylast >= H) return fail(MGPU_ERR_INVALID, "strip layout reaches row %lld of a %d-row frame", ylast, H);
+  }
+  const double t0 = now_ms();
+  int rc = set_device(s);
+  if (rc) return rc;
+  if (stats) memset(stats, 0, sizeof(*stats));
+  const int win_w = x1 - x0;
+  if (win_w == 0 || n_rows == 0) return MGPU_OK;
+  hipStream_t st = (hipStream_t)stream;
+
+  // persistent grid: as many workgroups as stay resident, capped by the work available
+  if (!s->render_blocks_per_cu) {
+    s->render_blocks_per_cu = 2;
+    // 169-ish VGPRs -> 2 waves/SIMD -> 2 workgroups of 4 waves per CU; the query is advisory
+  }
+  const uint64_t tiles = (uint64_t)((win_w + 7) / 8) * (uint64_t)((n_rows + 7) / 8);
+  uint64_t blocks = (uint64_t)s->num_cu * (uint64_t)s->render_blocks_per_cu;
+  const uint64_t max_useful = (tiles * 64 + kBlock - 1) / kBlock;
+  if (blocks > max_useful) blocks = max_useful;
+  if (blocks < 1) blocks = 1;
+  rc = ensure_overflow(s, blocks * kBlock);
+  if (rc) return rc;
+
+  RenderParams P;
+  memcpy(P.frame, frame, sizeof(P.frame));
+  if (plane) memcpy(P.plane, plane, sizeof(P.plane));
+  else memset(P.plane, 0, sizeof(P.plane));
+  P.has_plane = plane ? 1 : 0;
+  P.W = W; P.H = H; P.x0 = x0; P.x1 = x1;
+  P.y_first = y_first; P.strip_h = strip_h; P.y_period = y_period; P.n_rows = n_rows;
+  P.maxPathLength = maxPathLength; P.passes = passes;
+  P.rng_mode = rng_mode;
+  P.rng_states = d_rng_states;
+  P.seed = seed;
+  P.pass_base = pass_base;
+  P.image = d_image;
+  P.count = d_count;
+  P.work_counter = s->p_counters + (s->launch_seq++ % kCounterRing);
+  P.stats = s->p_stats;
+
+  HIP_TRY(hipMemsetAsync(P.work_counter, 0, sizeof(uint32_t), st));
+  if (stats) {
+    HIP_TRY(hipMemsetAsync(s->p_stats, 0, sizeof(unsigned long long) * kStatWords, st));
+    HIP_TRY(hipEventRecord(s->ev0, st));
+  }
+  launch_render(s->cap, dim3((unsigned)blocks), st, s->d, P);
+  HIP_TRY(hipGetLastError());
+  if (stats) {
+    HIP_TRY(hipEventRecord(s->ev1, st));
+    unsigned long long w[kStatWords];
+    HIP_TRY(hipMemcpyAsync(w, s->p_stats, sizeof(w), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    read_stats(w, stats);
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    stats->kernel_ms = ms;
+    stats->total_ms = now_ms() - t0;
+  }
+  return MGPU_OK;
+}
+
+int mgpu_render(MgpuScene *s, const double origin[3], const double corner[3], const double du[3], const double dv[3],
+                int W, int H, int x0, int y0, int x1, int y1, int maxPathLength, int passes, const float plane[4],
+                int rng_mode, const uint32_t *rng_states, uint64_t seed, uint32_t pass_base, float *image_out,
+                int32_t *count_out, MgpuStats *stats) {
+  if (!s || !origin || !corner || !du || !dv || !image_out) return fail(MGPU_ERR_INVALID, "NULL argument");
+  if (W <= 0 || H <= 0 || x0 < 0 || y0 < 0 || x1 > W || y1 > H || x0 > x1 || y0 > y1)
+    return fail(MGPU_ERR_INVALID, "bad window");
+  if (passes < 1) return fail(MGPU_ERR_INVALID, "passes must be >= 1");
+  const double t0 = now_ms();
+  int rc = set_device(s);
+  if (rc) return rc;
+  if (stats) memset(stats, 0, sizeof(*stats));
+  const int ww = x1 - x0, wh = y1 - y0;
+  if (ww == 0 || wh == 0) return MGPU_OK;
+  double frame[12];
+  memcpy(frame + 0, origin, 24);
+  memcpy(frame + 3, corner, 24);
+  memcpy(frame + 6, du, 24);
+  memcpy(frame + 9, dv, 24);
+  float *d_img = nullptr;
+  uint32_t *d_states = nullptr;
+  auto cleanup = [&]() {
+    if (d_img) (void)hipFree(d_img);
+    if (d_states) (void)hipFree(d_states);
+  };
+#define TRY_R(expr)                                                                                   \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess) {                                                                           \
+      cleanup();                                                                                      \
+      return fail(MGPU_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));                       \
+    }                                                                                                 \
+  } while (0)
+  TRY_R(hipMalloc((void **)&d_img, sizeof(float) * 3 * (size_t)ww * wh));
+  if (rng_mode == MGPU_RNG_TABLE) {
+    if (!rng_states) {
+      cleanup();
+      return fail(MGPU_ERR_INVALID, "MGPU_RNG_TABLE needs rng_states");
+    }
+    const size_t bytes = (size_t)passes * W * H * 16;
+    TRY_R(hipMalloc((void **)&d_states, bytes));
+    TRY_R(hipMemcpy(d_states, rng_states, bytes, hipMemcpyHostToDevice));
+  }
+  MgpuStats local;
+  rc = mgpu_render_strips_device(s, frame, W, H, x0, x1, y0, wh, wh, wh, maxPathLength, passes, plane, rng_mode,
+                                 d_states, seed, pass_base, d_img, nullptr, nullptr, &local);
+  if (rc) {
+    cleanup();
+    return rc;
+  }
+  TRY_R(hipMemcpy2D(image_out + 3 * ((size_t)y0 * W + x0), sizeof(float) * 3 * (size_t)W, d_img,
+                    sizeof(float) * 3 * (size_t)ww, sizeof(float) * 3 * (size_t)ww, (size_t)wh, hipMemcpyDeviceToHost));
+  cleanup();
+  if (count_out)
+    for (int y = y0; y < y1; y++)
+      for (int x = x0; x < x1; x++) count_out[(size_t)y * W + x] += passes;
+  if (stats) {
+    *stats = local;
+    stats->total_ms = now_ms() - t0;
+  }
+  return MGPU_OK;
+#undef TRY_R
+}
+
+} // extern "C"

@@ -1,0 +1,266 @@
+// mgpu_device.hpp -- device-side data layout and the per-ray building blocks of the gfx950 path tracer.
+//
+// Arithmetic contract: every fp64 expression below keeps the operation ORDER of the reference function it names
+// (lighttransport/mallie, paths relative to that tree) and this file is compiled with -ffp-contract=off, so IEEE
+// add/sub/mul/div/sqrt give bit-identical results to the x86-64 reference build.  Only acos/sin/cos come from the
+// device math library and may differ from glibc in the last ulp (see DESIGN.md "Numerics").
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mgpu.h"
+
+namespace mgpu {
+
+constexpr uint32_t kNoMaterial = 0xFFFFFFFFu;
+constexpr uint32_t kNoHit = 0xFFFFFFFFu;
+constexpr double kDblMax = 1.7976931348623157e+308;
+constexpr double kDblEps1024 = 2.220446049250313e-16 * 1024; // std::numeric_limits<double>::epsilon() * 1024
+
+// One triangle per BVH leaf SLOT (position in BVHAccel::indices_), pre-gathered so a leaf is a contiguous run and
+// the two index indirections of TestLeafNode (bvh_accel.cc:660-678) disappear.  e1/e2 are the reference's
+// p1-p0 / p2-p0 (bvh_accel.cc:606-607) evaluated once on the host: the same IEEE subtraction, the same bits.
+struct alignas(16) DTri {
+  double p0[3];
+  double e1[3];
+  double e2[3];
+  uint32_t face; // original face index (Intersection::faceID)
+  uint32_t mat;  // Mesh::materialIDs[face] or kNoMaterial
+};
+static_assert(sizeof(DTri) == 80, "DTri must be 80 bytes (5 x 16B loads)");
+
+struct DScene {
+  const MgpuNode *nodes;     // reference 64-byte layout, uploaded verbatim
+  const DTri *tris;          // nf entries, slot order
+  const double *slot_normal; // slot order: 9 doubles (facevarying n0,n1,n2) or 3 doubles (geometric normal)
+  const double *mat_diffuse; // 3*nm
+  uint32_t nm;
+  int has_fv_normals;
+  // original arrays, used by the batched Scene::Trace entry point to fill the full Intersection record
+  const double *verts;
+  const uint32_t *faces;
+  const double *fv_normals; // may be null
+  const double *fv_uvs;     // may be null
+  // traversal stack overflow area (entries beyond the LDS part), per hardware lane slot
+  uint32_t *stack_overflow;
+  uint32_t overflow_cap; // entries per lane
+};
+
+struct Hit {
+  double t, u, v;
+  uint32_t slot; // kNoHit when nothing was hit
+};
+
+struct Counters {
+  uint32_t rays, nodes, tris;
+};
+
+struct V3 {
+  double x, y, z;
+};
+
+__device__ __forceinline__ V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 scale(V3 a, double f) { return v3(a.x * f, a.y * f, a.z * f); }
+__device__ __forceinline__ V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
+// common.h:66-76
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// real3::normalize, common.h:46-56
+__device__ __forceinline__ V3 normalized(V3 a) {
+  double len = sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+  if (fabs(len) > 1.0e-6) {
+    double inv = 1.0 / len;
+    a.x *= inv;
+    a.y *= inv;
+    a.z *= inv;
+  }
+  return a;
+}
+
+// ---- RNG ----------------------------------------------------------------------------------------------------------
+struct Rng {
+  uint32_t x, y, z, w;
+};
+// randomreal(), render.cc:137-168
+__device__ __forceinline__ double rng_next(Rng &r) {
+  uint32_t t = r.x ^ (r.x << 11);
+  r.x = r.y;
+  r.y = r.z;
+  r.z = r.w;
+  r.w = (r.w ^ (r.w >> 19)) ^ (t ^ (t >> 8));
+  return r.w * (1.0 / 4294967296.0);
+}
+
+__host__ __device__ __forceinline__ uint64_t splitmix64_mix(uint64_t x) {
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+  return x ^ (x >> 31);
+}
+// MGPU_RNG_HASH start state; the oracle's mo_hash_state is the same function written independently.
+__host__ __device__ __forceinline__ void hash_state(uint64_t seed, uint32_t pass, uint32_t pixel, uint32_t st[4]) {
+  const uint64_t golden = 0x9E3779B97F4A7C15ULL;
+  uint64_t ctr = seed * golden + (((uint64_t)pass << 32) | (uint64_t)pixel);
+  uint64_t a = splitmix64_mix(ctr + golden);
+  uint64_t b = splitmix64_mix(ctr + 2 * golden);
+  st[0] = (uint32_t)a;
+  st[1] = (uint32_t)(a >> 32);
+  st[2] = (uint32_t)b;
+  st[3] = (uint32_t)(b >> 32);
+  if ((st[0] | st[1] | st[2] | st[3]) == 0) st[0] = 1;
+}
+
+// ---- traversal stack: first CAP entries in LDS (entry-major, lane-minor: conflict-free), rest in HBM ---------------
+template <int CAP> struct Stack {
+  uint32_t *lds;      // &s_stack[wave][0][lane]
+  uint32_t *overflow; // this lane's overflow column (may be null when overflow_cap == 0)
+  __device__ __forceinline__ void put(int i, uint32_t v) const {
+    if (i < CAP) lds[i * 64] = v;
+    else overflow[i - CAP] = v;
+  }
+  __device__ __forceinline__ uint32_t get(int i) const { return (i < CAP) ? lds[i * 64] : overflow[i - CAP]; }
+};
+
+// ---- BVHAccel::Traverse (bvh_accel.cc:773-844) without the final BuildIntersection ----------------------------------
+// while-while form: every lane pops and box-tests nodes until it holds a leaf (or runs dry), then the wave tests leaf
+// triangles together.  Pop order, the near/far push order and the in-leaf triangle order are the reference's, so
+// exact-t ties resolve identically and node/triangle counts equal the CPU's.
+template <int CAP>
+__device__ __forceinline__ void traverse(const DScene &sc, const Stack<CAP> &stk, V3 org, V3 dir, Hit &h, Counters &c) {
+  const bool sx = dir.x < 0.0, sy = dir.y < 0.0, sz = dir.z < 0.0;
+  const double ix = 1.0 / dir.x, iy = 1.0 / dir.y, iz = 1.0 / dir.z; // no zero guard, as the reference
+  h.t = kDblMax;
+  h.u = 0.0;
+  h.v = 0.0;
+  h.slot = kNoHit;
+  int sp = 0;
+  stk.put(0, 0u);
+  uint32_t leaf_first = 0, leaf_cnt = 0;
+  uint32_t nnodes = 0, ntris = 0;
+  for (;;) {
+    while (sp >= 0 && leaf_cnt == 0) {
+      const uint32_t ni = stk.get(sp);
+      --sp;
+      ++nnodes;
+      const MgpuNode *nd = sc.nodes + ni;
+      const double2 b0 = *reinterpret_cast<const double2 *>(&nd->bmin[0]); // bmin.x bmin.y
+      const double2 b1 = *reinterpret_cast<const double2 *>(&nd->bmin[2]); // bmin.z bmax.x
+      const double2 b2 = *reinterpret_cast<const double2 *>(&nd->bmax[1]); // bmax.y bmax.z
+      const int4 meta = *reinterpret_cast<const int4 *>(&nd->flag);        // flag axis data0 data1
+      // IntersectRayAABB, bvh_accel.cc:550-593
+      const double nx = sx ? b1.y : b0.x, fx = sx ? b0.x : b1.y;
+      const double ny = sy ? b2.x : b0.y, fy = sy ? b0.y : b2.x;
+      const double nz = sz ? b2.y : b1.x, fz = sz ? b1.x : b2.y;
+      const double tmin_x = (nx - org.x) * ix, tmax_x = (fx - org.x) * ix;
+      const double tmin_y = (ny - org.y) * iy, tmax_y = (fy - org.y) * iy;
+      double tmin = (tmin_x > tmin_y) ? tmin_x : tmin_y;
+      double tmax = (tmax_x < tmax_y) ? tmax_x : tmax_y;
+      const double tmin_z = (nz - org.z) * iz, tmax_z = (fz - org.z) * iz;
+      tmin = (tmin > tmin_z) ? tmin : tmin_z;
+      tmax = (tmax < tmax_z) ? tmax : tmax_z;
+      const bool hit = (tmax > 0.0) && (tmin <= tmax) && (tmin <= h.t);
+      if (hit) {
+        if (meta.x == 0) {
+          const bool nearIsSecond = (meta.y == 0) ? sx : ((meta.y == 1) ? sy : sz); // dirSign[node.axis]
+          const uint32_t c0 = (uint32_t)meta.z, c1 = (uint32_t)meta.w;
+          stk.put(sp + 1, nearIsSecond ? c0 : c1); // far
+          stk.put(sp + 2, nearIsSecond ? c1 : c0); // near: popped first
+          sp += 2;
+        } else {
+          leaf_cnt = (uint32_t)meta.z;
+          leaf_first = (uint32_t)meta.w;
+        }
+      }
+    }
+    if (leaf_cnt == 0) break;
+    // TestLeafNode + TriangleIsect, bvh_accel.cc:595-697
+    for (uint32_t i = 0; i < leaf_cnt; ++i) {
+      const DTri *tp = sc.tris + (leaf_first + i);
+      const double2 a0 = reinterpret_cast<const double2 *>(tp)[0]; // p0.x p0.y
+      const double2 a1 = reinterpret_cast<const double2 *>(tp)[1]; // p0.z e1.x
+      const double2 a2 = reinterpret_cast<const double2 *>(tp)[2]; // e1.y e1.z
+      const double2 a3 = reinterpret_cast<const double2 *>(tp)[3]; // e2.x e2.y
+      const double e2z = tp->e2[2];
+      ++ntris;
+      const V3 p0 = v3(a0.x, a0.y, a1.x), e1 = v3(a1.y, a2.x, a2.y), e2 = v3(a3.x, a3.y, e2z);
+      const V3 p = cross(dir, e2);
+      const double det = dot(e1, p);
+      if (fabs(det) < kDblEps1024) continue;
+      const double invDet = 1.0 / det;
+      const V3 s = org - p0;
+      const V3 q = cross(s, e1);
+      const double u = dot(s, p) * invDet;
+      const double v = dot(q, dir) * invDet;
+      const double t = dot(e2, q) * invDet;
+      if (u < 0.0 || u > 1.0) continue;
+      if (v < 0.0 || u + v > 1.0) continue;
+      if (t < 0.0 || t > h.t) continue;
+      h.t = t;
+      h.u = u;
+      h.v = v;
+      h.slot = leaf_first + i;
+    }
+    leaf_cnt = 0;
+  }
+  c.nodes += nnodes;
+  c.tris += ntris;
+  c.rays += 1;
+}
+
+// ---- Plane::intersect (prim-plane.cc:8-44): float core, double outputs ------------------------------------------------
+// Returns true and overwrites t / normal when the plane is hit closer than `t`.
+__device__ __forceinline__ bool plane_hit(const float pl[4], V3 org, V3 dir, double &t_io, V3 &normal) {
+  V3 n = v3((double)pl[0], (double)pl[1], (double)pl[2]);
+  const V3 v = normalized(dir);
+  const float vn = (float)dot(v, n);
+  if (fabsf(vn) > 1.1920929e-07f * 1024.0f) {
+    const float on_d = (float)(dot(org, n) + (double)pl[3]);
+    const float t = -on_d / vn;
+    if ((t > 0) && ((double)t < t_io)) {
+      t_io = (double)t;
+      normal = normalized(n);
+      return true;
+    }
+  }
+  return false;
+}
+
+// ---- GenerateBasis + SampleDiffuseIS (render.cc:271-339) ------------------------------------------------------------------
+__device__ __forceinline__ V3 sample_diffuse(V3 n, Rng &rng) {
+  // minor axis by |n[i]| compared after rounding to float (fabsf), first minimum wins
+  const double ax = (double)fabsf((float)n.x), ay = (double)fabsf((float)n.y), az = (double)fabsf((float)n.z);
+  int index = 0;
+  double minval = ax; // ax < 1e6 always holds for a (near-)unit normal; keep the reference's guard anyway
+  if (!(ax < 1.0e+6)) { index = -1; minval = 1.0e+6; }
+  if (ay < minval) { minval = ay; index = 1; }
+  if (az < minval) { minval = az; index = 2; }
+  V3 t;
+  if (index == 0) t = v3(0.0, -n.z, n.y);
+  else if (index == 1) t = v3(-n.z, 0.0, n.x);
+  else t = v3(-n.y, n.x, 0.0);
+  t = normalized(t);
+  const V3 b = normalized(cross(t, n));
+  const double theta = acos(sqrt(1.0 - rng_next(rng)));
+  const double phi = 6.283185307179586 * rng_next(rng); // 2.0 * M_PI, folded exactly
+  const double cos_theta = cos(theta);
+  const double sin_theta = sin(theta);
+  const V3 T = scale(scale(t, cos(phi)), sin_theta);
+  const V3 B = scale(scale(b, sin(phi)), sin_theta);
+  const V3 N = scale(n, cos_theta);
+  return (T + B) + N;
+}
+
+// Camera::GenerateRay direction (camera.cc:222-240)
+__device__ __forceinline__ V3 camera_dir(const double *frame, double u, double v) {
+  V3 d;
+  d.x = (frame[3] + u * frame[6] + v * frame[9]) - frame[0];
+  d.y = (frame[4] + u * frame[7] + v * frame[10]) - frame[1];
+  d.z = (frame[5] + u * frame[8] + v * frame[11]) - frame[2];
+  return normalized(d);
+}
+
+} // namespace mgpu

@@ -1,0 +1,339 @@
+// mgpu_kernels.hip -- gfx950 kernels of the render hot path (wave64, fp64, no MFMA: branchy scalar traversal).
+//
+//   k_trace  : batched Scene::Trace  (scene.cc:253 -> BVHAccel::Traverse bvh_accel.cc:773 + BuildIntersection :699)
+//   k_render : persistent-threads path tracer = Render()'s pixel loop (render.cc:657-681) + PathTrace (render.cc:381-456)
+//
+// Compiled with -ffp-contract=off (see mgpu_device.hpp for the arithmetic contract).
+#include "mgpu_device.hpp"
+#include "mgpu_kernels.hpp"
+
+namespace mgpu {
+
+// =====================================================================================================================
+// k_trace: one lane per ray
+// =====================================================================================================================
+template <int CAP>
+__global__ __launch_bounds__(kBlock) void k_trace(DScene sc, const MgpuRay *__restrict__ rays, size_t n,
+                                                 MgpuIntersection *__restrict__ out, uint8_t *__restrict__ hit_out,
+                                                 unsigned long long *__restrict__ stats) {
+  __shared__ uint32_t s_stack[kBlock / 64][CAP][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t gid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  Stack<CAP> stk;
+  stk.lds = &s_stack[wave][0][lane];
+  stk.overflow = sc.stack_overflow ? sc.stack_overflow + gid * sc.overflow_cap : nullptr;
+  Counters c{0, 0, 0};
+  if (gid < n) {
+    const MgpuRay *r = rays + gid;
+    const V3 org = v3(r->org[0], r->org[1], r->org[2]);
+    const V3 dir = v3(r->dir[0], r->dir[1], r->dir[2]);
+    Hit h;
+    traverse<CAP>(sc, stk, org, dir, h, c);
+    MgpuIntersection is;
+    // a miss leaves t = DBL_MAX, u = v = 0, faceID = -1 (bvh_accel.cc:782-786); every other field is zeroed here
+    is.t = h.t; is.u = h.u; is.v = h.v;
+    is.faceID = 0xFFFFFFFFu; is.materialID = 0; is.f0 = is.f1 = is.f2 = 0; is.pad_ = 0;
+    for (int k = 0; k < 3; ++k) {
+      is.position[k] = 0.0; is.geometricNormal[k] = 0.0; is.normal[k] = 0.0; is.tangent[k] = 0.0; is.binormal[k] = 0.0;
+    }
+    is.texcoord[0] = is.texcoord[1] = 0.0;
+    const bool hit = h.slot != kNoHit;
+    if (hit) {
+      // BuildIntersection, bvh_accel.cc:699-769
+      const DTri *tp = sc.tris + h.slot;
+      const uint32_t face = tp->face;
+      is.faceID = face;
+      is.materialID = tp->mat;
+      is.f0 = sc.faces[3 * (size_t)face + 0];
+      is.f1 = sc.faces[3 * (size_t)face + 1];
+      is.f2 = sc.faces[3 * (size_t)face + 2];
+      is.position[0] = org.x + h.t * dir.x;
+      is.position[1] = org.y + h.t * dir.y;
+      is.position[2] = org.z + h.t * dir.z;
+      const V3 e1 = v3(tp->e1[0], tp->e1[1], tp->e1[2]), e2 = v3(tp->e2[0], tp->e2[1], tp->e2[2]);
+      const V3 gn = normalized(cross(e1, e2));
+      is.geometricNormal[0] = gn.x; is.geometricNormal[1] = gn.y; is.geometricNormal[2] = gn.z;
+      if (sc.fv_normals) {
+        const double *nn = sc.fv_normals + 9 * (size_t)face;
+        const double w = 1.0 - h.u - h.v;
+        is.normal[0] = w * nn[0] + h.u * nn[3] + h.v * nn[6];
+        is.normal[1] = w * nn[1] + h.u * nn[4] + h.v * nn[7];
+        is.normal[2] = w * nn[2] + h.u * nn[5] + h.v * nn[8];
+      } else {
+        is.normal[0] = gn.x; is.normal[1] = gn.y; is.normal[2] = gn.z;
+      }
+      if (sc.fv_uvs) {
+        const double *uv = sc.fv_uvs + 6 * (size_t)face;
+        const double w = 1.0 - h.u - h.v;
+        is.texcoord[0] = w * uv[0] + h.u * uv[2] + h.v * uv[4];
+        is.texcoord[1] = w * uv[1] + h.u * uv[3] + h.v * uv[5];
+      }
+    }
+    out[gid] = is;
+    hit_out[gid] = hit ? 1 : 0;
+  }
+  // counters: one atomic per wave and counter
+  unsigned long long rn = c.rays, nn = c.nodes, tn = c.tris;
+  for (int off = 32; off; off >>= 1) {
+    rn += __shfl_down(rn, off);
+    nn += __shfl_down(nn, off);
+    tn += __shfl_down(tn, off);
+  }
+  if (lane == 0 && stats) {
+    atomicAdd(&stats[kStatRays], rn);
+    atomicAdd(&stats[kStatNodes], nn);
+    atomicAdd(&stats[kStatTris], tn);
+    atomicAdd(&stats[kStatTraceCalls], rn);
+  }
+}
+
+// =====================================================================================================================
+// k_render: persistent waves; every lane owns one pixel at a time for all its passes, then takes the next pixel.
+// =====================================================================================================================
+//
+// Work distribution: the pixel set is cut into 8x8 tiles (one wave-fetch = one tile = 64 pixels, so the lanes of a
+// freshly fed wave shoot coherent primary rays); tiles are handed out in chunks of kChunkTiles by one global counter
+// per launch (a few thousand atomics per frame).  A lane that finishes its pixel (all passes) early pulls the next
+// pixel of the wave's chunk right away, so path-length divergence does not idle lanes ("path regeneration").
+//
+// Float accumulation order: a pixel's passes are summed in pass order in float32 by the lane that owns it, which is
+// exactly Render() + AccumImage (main_sdl.cc:138-143); no atomics touch the image.
+enum : int { S_NEED_PIXEL = 0, S_NEED_PATH = 1, S_TRACE = 2 };
+
+template <int CAP>
+__global__ __launch_bounds__(kBlock) void k_render(DScene sc, RenderParams P) {
+  __shared__ uint32_t s_stack[kBlock / 64][CAP][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t gid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  Stack<CAP> stk;
+  stk.lds = &s_stack[wave][0][lane];
+  stk.overflow = sc.stack_overflow ? sc.stack_overflow + gid * sc.overflow_cap : nullptr;
+
+  const int win_w = P.x1 - P.x0;
+  const uint32_t tiles_x = (uint32_t)(win_w + 7) >> 3;
+  const uint32_t tiles_y = (uint32_t)(P.n_rows + 7) >> 3;
+  const uint32_t total_tiles = tiles_x * tiles_y;
+
+  // wave-uniform chunk of tiles [tile_next, tile_end); pixel cursor inside the current tile
+  uint32_t tile_next = 0, tile_end = 0, in_tile = 64;
+  bool exhausted = false;
+
+  int state = S_NEED_PIXEL;
+  uint32_t lx = 0, ly = 0; // local pixel (window column, local row)
+  int pass = 0;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+  Rng rng{1, 0, 0, 0};
+  V3 org = v3(0, 0, 0), dir = v3(0, 0, 1);
+  double thr0 = 1, thr1 = 1, thr2 = 1, rad0 = 0, rad1 = 0, rad2 = 0;
+  int pathLength = 1;
+  uint32_t last_mat = kNoMaterial; // Intersection::materialID as the reference would still hold it (stale on a miss)
+  Counters c{0, 0, 0};
+  uint32_t trace_calls = 0, paths = 0;
+
+  for (;;) {
+    // ---- 1. hand pixels to idle lanes ---------------------------------------------------------------------------
+    {
+      const unsigned long long need = __ballot(state == S_NEED_PIXEL);
+      if (need) {
+        if (in_tile >= 64 && !exhausted) { // current tile used up: advance (refill the chunk when empty)
+          if (tile_next >= tile_end) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(P.work_counter, (uint32_t)kChunkTiles);
+            base = __shfl(base, 0);
+            tile_next = base;
+            tile_end = min(base + (uint32_t)kChunkTiles, total_tiles);
+            if (base >= total_tiles) { exhausted = true; tile_end = tile_next = total_tiles; }
+          }
+          if (!exhausted) { in_tile = 0; }
+        }
+        if (!exhausted && in_tile < 64) {
+          const uint32_t rank = __popcll(need & ((1ull << lane) - 1ull));
+          const uint32_t slot = in_tile + rank;
+          if (state == S_NEED_PIXEL && slot < 64) {
+            const uint32_t tx = tile_next % tiles_x, ty = tile_next / tiles_x;
+            const uint32_t x = tx * 8 + (slot & 7), y = ty * 8 + (slot >> 3);
+            if (x < (uint32_t)win_w && y < (uint32_t)P.n_rows) {
+              lx = x; ly = y; pass = 0;
+              acc0 = acc1 = acc2 = 0.f;
+              state = S_NEED_PATH;
+            } // pixels of a partial edge tile that fall outside the window are simply skipped
+          }
+          in_tile += (uint32_t)__popcll(need);
+          if (in_tile >= 64) { in_tile = 64; ++tile_next; }
+        }
+      }
+      if (__all(state == S_NEED_PIXEL)) {
+        if (exhausted) break;
+        continue;
+      }
+    }
+
+    // ---- 2. start a new eye path (PathTrace prologue, render.cc:387-400) ----------------------------------------
+    if (state == S_NEED_PATH) {
+      const uint32_t j = ly;
+      const int gy = P.y_first + (int)(j / (uint32_t)P.strip_h) * P.y_period + (int)(j % (uint32_t)P.strip_h);
+      const int gx = P.x0 + (int)lx;
+      const uint32_t gpix = (uint32_t)gy * (uint32_t)P.W + (uint32_t)gx;
+      uint32_t st[4];
+      if (P.rng_mode == MGPU_RNG_TABLE) {
+        const uint4 s4 = reinterpret_cast<const uint4 *>(P.rng_states)[(size_t)pass * P.W * P.H + gpix];
+        st[0] = s4.x; st[1] = s4.y; st[2] = s4.z; st[3] = s4.w;
+      } else {
+        hash_state(P.seed, P.pass_base + (uint32_t)pass, gpix, st);
+      }
+      rng = Rng{st[0], st[1], st[2], st[3]};
+      const float ju = (float)(rng_next(rng) - 0.5);
+      const float jv = (float)(rng_next(rng) - 0.5);
+      org = v3(P.frame[0], P.frame[1], P.frame[2]);
+      dir = camera_dir(P.frame, (double)((float)gx + ju), (double)((float)gy + jv));
+      thr0 = thr1 = thr2 = 1.0;
+      rad0 = rad1 = rad2 = 0.0;
+      pathLength = 1;
+      ++paths;
+      state = S_TRACE;
+    }
+
+    // ---- 3. Scene::Trace for every lane that holds a ray --------------------------------------------------------
+    Hit h;
+    h.slot = kNoHit;
+    h.t = kDblMax;
+    h.u = h.v = 0.0;
+    if (state == S_TRACE) traverse<CAP>(sc, stk, org, dir, h, c);
+
+    // ---- 4. the rest of one PathTrace loop iteration (render.cc:403-452) ----------------------------------------
+    if (state == S_TRACE) {
+      bool hit = h.slot != kNoHit;
+      double t = h.t;
+      V3 n = v3(0, 0, 0);
+      if (hit) {
+        const DTri *tp = sc.tris + h.slot;
+        last_mat = tp->mat;
+        if (sc.has_fv_normals) { // barycentric lerp, not renormalised (bvh_accel.cc:745-748)
+          const double *nn = sc.slot_normal + 9 * (size_t)h.slot;
+          const double w = 1.0 - h.u - h.v;
+          n.x = w * nn[0] + h.u * nn[3] + h.v * nn[6];
+          n.y = w * nn[1] + h.u * nn[4] + h.v * nn[7];
+          n.z = w * nn[2] + h.u * nn[5] + h.v * nn[8];
+        } else {
+          const double *gn = sc.slot_normal + 3 * (size_t)h.slot;
+          n = v3(gn[0], gn[1], gn[2]);
+        }
+      }
+      if (P.has_plane && plane_hit(P.plane, org, dir, t, n)) {
+        hit = true;
+        last_mat = kNoMaterial; // prim-plane.cc:34
+      }
+      bool path_done = false;
+      if (!hit) {
+        path_done = true;
+        if (pathLength < 2) {
+          trace_calls += 1; // eye ray -> background: radiance stays 0 (render.cc:409-412)
+        } else {
+          // First miss of a path that has bounced.  The reference does NOT stop: it iterates on to kMaxPathLength
+          // with the stale intersection record; every one of those rays starts ~1e308 away and misses, adds
+          // throughput*0.5/length and re-applies the stale material.  Their RNG draws cannot reach
+          // this pixel's value, so the tail is evaluated in closed loop: same adds, same multiplies, same order.
+          trace_calls += (uint32_t)P.maxPathLength;
+          double d0 = 0.5, d1 = 0.5, d2 = 0.5; // Material().diffuse default (material.h:12-15)
+          const bool mul = last_mat != kNoMaterial;
+          if (mul && (size_t)(int)last_mat < (size_t)sc.nm) {
+            d0 = sc.mat_diffuse[3 * (size_t)last_mat + 0];
+            d1 = sc.mat_diffuse[3 * (size_t)last_mat + 1];
+            d2 = sc.mat_diffuse[3 * (size_t)last_mat + 2];
+          }
+          for (int L = pathLength;; ++L) {
+            const double dl = (double)(unsigned)L;
+            rad0 += thr0 * 0.5 / dl;
+            rad1 += thr1 * 0.5 / dl;
+            rad2 += thr2 * 0.5 / dl;
+            if (L >= P.maxPathLength) break;
+            if (mul) { thr0 *= d0; thr1 *= d1; thr2 *= d2; }
+          }
+        }
+      } else if (pathLength >= P.maxPathLength) {
+        path_done = true;
+        trace_calls += (uint32_t)P.maxPathLength;
+      } else {
+        const V3 hitP = org + scale(dir, t);
+        (void)rng_next(rng); // `double r = randomreal();` drawn and never used (render.cc:430)
+        const double ndoti = dot(n, neg(dir));
+        if (ndoti < 0.0) n = neg(n);
+        const V3 sd = sample_diffuse(n, rng);
+        if (last_mat != kNoMaterial) { // Scene::GetMaterial, scene.h:58-65
+          if ((size_t)(int)last_mat < (size_t)sc.nm) {
+            thr0 *= sc.mat_diffuse[3 * (size_t)last_mat + 0];
+            thr1 *= sc.mat_diffuse[3 * (size_t)last_mat + 1];
+            thr2 *= sc.mat_diffuse[3 * (size_t)last_mat + 2];
+          } else {
+            thr0 *= 0.5; thr1 *= 0.5; thr2 *= 0.5;
+          }
+        }
+        org = hitP + scale(sd, 1.0e-3);
+        dir = sd;
+        ++pathLength;
+      }
+      if (path_done) {
+        // image[...] = radiance (double -> float, render.cc:673-675), then AccumImage over passes
+        acc0 += (float)rad0;
+        acc1 += (float)rad1;
+        acc2 += (float)rad2;
+        ++pass;
+        if (pass >= P.passes) {
+          const size_t o = (size_t)ly * (size_t)win_w + lx;
+          P.image[3 * o + 0] = acc0;
+          P.image[3 * o + 1] = acc1;
+          P.image[3 * o + 2] = acc2;
+          if (P.count) P.count[o] += P.passes;
+          state = S_NEED_PIXEL;
+        } else {
+          state = S_NEED_PATH;
+        }
+      }
+    }
+  }
+
+  // ---- counters: one atomic per wave and word ---------------------------------------------------------------------
+  unsigned long long v0 = trace_calls, v1 = c.rays, v2 = c.nodes, v3_ = c.tris, v4 = paths;
+  for (int off = 32; off; off >>= 1) {
+    v0 += __shfl_down(v0, off);
+    v1 += __shfl_down(v1, off);
+    v2 += __shfl_down(v2, off);
+    v3_ += __shfl_down(v3_, off);
+    v4 += __shfl_down(v4, off);
+  }
+  if (lane == 0 && P.stats) {
+    atomicAdd(&P.stats[kStatTraceCalls], v0);
+    atomicAdd(&P.stats[kStatRays], v1);
+    atomicAdd(&P.stats[kStatNodes], v2);
+    atomicAdd(&P.stats[kStatTris], v3_);
+    atomicAdd(&P.stats[kStatPaths], v4);
+  }
+}
+
+// =====================================================================================================================
+// launchers
+// =====================================================================================================================
+int pick_stack_cap(int needed_entries) {
+  if (needed_entries <= 16) return 16;
+  if (needed_entries <= 24) return 24;
+  return 32; // deeper trees spill the remainder to the per-lane HBM overflow column
+}
+
+void launch_trace(int cap, dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, size_t n,
+                  MgpuIntersection *out, uint8_t *hit, unsigned long long *stats) {
+  switch (cap) {
+  case 16: hipLaunchKernelGGL(k_trace<16>, grid, dim3(kBlock), 0, s, sc, rays, n, out, hit, stats); break;
+  case 24: hipLaunchKernelGGL(k_trace<24>, grid, dim3(kBlock), 0, s, sc, rays, n, out, hit, stats); break;
+  default: hipLaunchKernelGGL(k_trace<32>, grid, dim3(kBlock), 0, s, sc, rays, n, out, hit, stats); break;
+  }
+}
+
+void launch_render(int cap, dim3 grid, hipStream_t s, const DScene &sc, const RenderParams &p) {
+  switch (cap) {
+  case 16: hipLaunchKernelGGL(k_render<16>, grid, dim3(kBlock), 0, s, sc, p); break;
+  case 24: hipLaunchKernelGGL(k_render<24>, grid, dim3(kBlock), 0, s, sc, p); break;
+  default: hipLaunchKernelGGL(k_render<32>, grid, dim3(kBlock), 0, s, sc, p); break;
+  }
+}
+
+} // namespace mgpu

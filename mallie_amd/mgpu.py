@@ -1,0 +1,234 @@
+"""ctypes binding of the C ABI in include/mgpu.h (libmallie_mgpu.so)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmallie_mgpu.so")
+
+RNG_STREAM, RNG_TABLE, RNG_HASH = 0, 1, 2
+
+# byte-identical to the reference's BVHNode / Ray / Intersection (bvh_accel.h:10-30, common.h:78-83, intersection.h:6-24)
+NODE_DT = np.dtype([("bmin", "<f8", 3), ("bmax", "<f8", 3), ("flag", "<i4"), ("axis", "<i4"), ("data", "<u4", 2)])
+RAY_DT = np.dtype([("org", "<f8", 3), ("dir", "<f8", 3), ("invDir", "<f8", 3), ("dirSign", "<i4", 3), ("pad_", "<i4")])
+ISECT_DT = np.dtype([("t", "<f8"), ("u", "<f8"), ("v", "<f8"), ("faceID", "<u4"), ("materialID", "<u4"), ("f0", "<u4"),
+                     ("f1", "<u4"), ("f2", "<u4"), ("pad_", "<u4"), ("position", "<f8", 3),
+                     ("geometricNormal", "<f8", 3), ("normal", "<f8", 3), ("tangent", "<f8", 3),
+                     ("binormal", "<f8", 3), ("texcoord", "<f8", 2)])
+assert NODE_DT.itemsize == 64 and RAY_DT.itemsize == 88 and ISECT_DT.itemsize == 184
+
+
+class MgpuError(RuntimeError):
+    def __init__(self, status, where, detail):
+        super().__init__("%s failed with status %d: %s" % (where, status, detail))
+        self.status = status
+
+
+class Stats(C.Structure):
+    _fields_ = [("trace_calls", C.c_uint64), ("real_rays", C.c_uint64), ("nodes", C.c_uint64), ("tris", C.c_uint64),
+                ("paths", C.c_uint64), ("stack_overflow", C.c_uint64), ("kernel_ms", C.c_double),
+                ("total_ms", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Loads libmallie_mgpu.so. Fails loudly when it has not been built: there is no fallback implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError("%s is missing: build it with `python -m mallie_amd.build` (needs hipcc). mallie_amd has no "
+                          "CPU fallback." % _LIB_PATH)
+    L = C.CDLL(_LIB_PATH)
+    vp, sz, u64, u32, i32, dbl = C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_int, C.c_double
+    L.mgpu_abi_version.restype = i32
+    L.mgpu_device_count.restype = i32
+    L.mgpu_last_error.restype = C.c_char_p
+    L.mgpu_status_string.restype = C.c_char_p
+    L.mgpu_status_string.argtypes = [i32]
+    L.mgpu_scene_create.argtypes = [vp, sz, vp, sz, vp, vp, vp, vp, sz, vp, vp, sz, i32, C.POINTER(vp)]
+    L.mgpu_scene_create.restype = i32
+    L.mgpu_scene_destroy.argtypes = [vp]
+    L.mgpu_scene_destroy.restype = i32
+    L.mgpu_scene_bbox.argtypes = [vp, vp, vp]
+    L.mgpu_scene_bbox.restype = i32
+    L.mgpu_scene_device_bytes.argtypes = [vp]
+    L.mgpu_scene_device_bytes.restype = sz
+    L.mgpu_trace.argtypes = [vp, vp, sz, vp, vp, vp]
+    L.mgpu_trace.restype = i32
+    L.mgpu_render.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, u64, u32, vp, vp,
+                              vp]
+    L.mgpu_render.restype = i32
+    L.mgpu_render_strips_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, u64,
+                                            u32, vp, vp, vp, vp]
+    L.mgpu_render_strips_device.restype = i32
+    L.mgpu_hash_state.argtypes = [u64, u32, u32, vp]
+    L.mgpu_camera_frame.argtypes = [vp, vp, vp, vp, dbl, i32, i32, vp]
+    L.mgpu_camera_frame.restype = i32
+    L.mgpu_bvh_build.argtypes = [vp, sz, vp, sz, dbl, i32, i32, i32, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), vp]
+    L.mgpu_bvh_build.restype = i32
+    L.mgpu_free.argtypes = [vp]
+    L.mgpu_plane_from_bbox.argtypes = [vp, vp, vp]
+    _lib = L
+    return L
+
+
+def _check(rc, where):
+    if rc != 0:
+        L = load_library()
+        raise MgpuError(rc, where, (L.mgpu_last_error() or b"").decode() or L.mgpu_status_string(rc).decode())
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return None if a is None else np.ascontiguousarray(a, dtype=dt)
+
+
+def abi_version():
+    return load_library().mgpu_abi_version()
+
+
+def device_count():
+    return load_library().mgpu_device_count()
+
+
+def hash_state(seed, pass_, pixel):
+    st = np.zeros(4, "<u4")
+    load_library().mgpu_hash_state(seed, pass_, pixel, _p(st))
+    return st
+
+
+def camera_frame(eye, lookat, up=(0, 1, 0), quat=(0, 0, 0, 0), fov=45.0, width=512, height=512):
+    """Camera::BuildCameraFrame (camera.cc:40-220): returns origin, corner, du, dv as 12 doubles (host code)."""
+    f = np.zeros(12)
+    _check(load_library().mgpu_camera_frame(_p(_c(eye, "<f8")), _p(_c(lookat, "<f8")), _p(_c(up, "<f8")),
+                                            _p(_c(quat, "<f8")), float(fov), int(width), int(height), _p(f)),
+           "mgpu_camera_frame")
+    return f
+
+
+def bvh_build(verts, faces, costTaabb=0.2, minLeaf=16, maxDepth=256, binSize=64):
+    """BVHAccel::Build (bvh_accel.cc:445-482) with BVHBuildOptions defaults; host code. -> (nodes, indices, stats)"""
+    L = load_library()
+    verts = _c(verts, "<f8").reshape(-1, 3)
+    faces = _c(faces, "<u4").reshape(-1, 3)
+    pn, pi, nn = C.c_void_p(), C.c_void_p(), C.c_size_t()
+    st = (C.c_int * 3)()
+    _check(L.mgpu_bvh_build(_p(verts), len(verts), _p(faces), len(faces), costTaabb, minLeaf, maxDepth, binSize,
+                            C.byref(pn), C.byref(nn), C.byref(pi), st), "mgpu_bvh_build")
+    nodes = np.frombuffer(C.string_at(pn, 64 * nn.value), NODE_DT).copy()
+    idx = np.frombuffer(C.string_at(pi, 4 * len(faces)), "<u4").copy()
+    L.mgpu_free(pn)
+    L.mgpu_free(pi)
+    return nodes, idx, dict(maxTreeDepth=st[0], numLeafNodes=st[1], numBranchNodes=st[2])
+
+
+def plane_from_bbox(bmin, bmax):
+    """Ground-plane coefficients as Render() derives them on its first call (render.cc:620-627)."""
+    pl = np.zeros(4, "<f4")
+    load_library().mgpu_plane_from_bbox(_p(_c(bmin, "<f8")), _p(_c(bmax, "<f8")), _p(pl))
+    return pl
+
+
+class Scene:
+    """Device-resident scene: what Scene::Init leaves behind (Mesh arrays + BVH), uploaded and re-laid-out once."""
+
+    def __init__(self, verts, faces, matIDs=None, normals=None, uvs=None, nodes=None, indices=None, mat_diffuse=None,
+                 device=0):
+        L = load_library()
+        verts = _c(verts, "<f8").reshape(-1, 3)
+        faces = _c(faces, "<u4").reshape(-1, 3)
+        matIDs = _c(matIDs, "<u4")
+        normals = _c(normals, "<f8") if normals is not None and np.size(normals) else None
+        uvs = _c(uvs, "<f8") if uvs is not None and np.size(uvs) else None
+        if nodes is None:
+            nodes, indices, _ = bvh_build(verts, faces)
+        nodes = _c(nodes, NODE_DT)
+        indices = _c(indices, "<u4")
+        mat_diffuse = _c(mat_diffuse, "<f8") if mat_diffuse is not None and np.size(mat_diffuse) else None
+        nm = 0 if mat_diffuse is None else mat_diffuse.size // 3
+        self.n_faces, self.n_nodes, self.device = len(faces), len(nodes), device
+        h = C.c_void_p()
+        _check(L.mgpu_scene_create(_p(verts), len(verts), _p(faces), len(faces), _p(matIDs), _p(normals), _p(uvs),
+                                   _p(nodes), len(nodes), _p(indices), _p(mat_diffuse), nm, device, C.byref(h)),
+               "mgpu_scene_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            load_library().mgpu_scene_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def bbox(self):
+        lo, hi = np.zeros(3), np.zeros(3)
+        _check(load_library().mgpu_scene_bbox(self.h, _p(lo), _p(hi)), "mgpu_scene_bbox")
+        return lo, hi
+
+    def plane(self):
+        return plane_from_bbox(*self.bbox())
+
+    def device_bytes(self):
+        return load_library().mgpu_scene_device_bytes(self.h)
+
+    def trace(self, rays, want_stats=False):
+        """Batched Scene::Trace. rays: (n,6) [org,dir] or a RAY_DT array. -> (ISECT_DT array, hit uint8 array[, stats])"""
+        rays = np.asarray(rays)
+        if rays.dtype != RAY_DT:
+            r6 = _c(rays, "<f8").reshape(-1, 6)
+            rays = np.zeros(len(r6), RAY_DT)
+            rays["org"], rays["dir"] = r6[:, :3], r6[:, 3:]
+        rays = np.ascontiguousarray(rays)
+        out = np.zeros(len(rays), ISECT_DT)
+        hit = np.zeros(len(rays), "u1")
+        st = Stats()
+        _check(load_library().mgpu_trace(self.h, _p(rays), len(rays), _p(out), _p(hit), C.byref(st)), "mgpu_trace")
+        return (out, hit, st.as_dict()) if want_stats else (out, hit)
+
+    def render(self, frame, W, H, maxPathLength=16, passes=1, plane=None, rng_mode=RNG_HASH, rng_states=None, seed=1,
+               pass_base=0, window=None, image=None, count=None):
+        """mgpu_render into host buffers. -> (image HxWx3 float32, count HxW int32, stats dict)"""
+        frame = _c(frame, "<f8")
+        x0, y0, x1, y1 = window if window is not None else (0, 0, W, H)
+        if image is None:
+            image = np.zeros((H, W, 3), "<f4")
+        if count is None:
+            count = np.zeros((H, W), "<i4")
+        plane = _c(plane, "<f4")
+        rng_states = _c(rng_states, "<u4")
+        st = Stats()
+        _check(load_library().mgpu_render(self.h, _p(frame[0:3]), _p(frame[3:6]), _p(frame[6:9]), _p(frame[9:12]), W, H,
+                                          x0, y0, x1, y1, maxPathLength, passes, _p(plane), rng_mode, _p(rng_states),
+                                          seed, pass_base, _p(image), _p(count), C.byref(st)), "mgpu_render")
+        return image, count, st.as_dict()
+
+    def render_strips_device(self, frame, W, H, d_image_ptr, n_rows, x0=0, x1=None, y_first=0, strip_h=None,
+                             y_period=None, maxPathLength=16, passes=1, plane=None, rng_mode=RNG_HASH,
+                             d_rng_states_ptr=None, seed=1, pass_base=0, d_count_ptr=None, stream=None,
+                             want_stats=False):
+        """mgpu_render_strips_device: device pointers in, nothing crosses PCIe. Asynchronous unless want_stats."""
+        frame = _c(frame, "<f8")
+        x1 = W if x1 is None else x1
+        strip_h = n_rows if strip_h is None else strip_h
+        y_period = strip_h if y_period is None else y_period
+        plane = _c(plane, "<f4")
+        st = Stats() if want_stats else None
+        _check(load_library().mgpu_render_strips_device(
+            self.h, _p(frame), W, H, x0, x1, y_first, strip_h, y_period, n_rows, maxPathLength, passes, _p(plane),
+            rng_mode, d_rng_states_ptr, seed, pass_base, d_image_ptr, d_count_ptr, stream,
+            C.byref(st) if st is not None else None), "mgpu_render_strips_device")
+        return st.as_dict() if st is not None else None

@@ -1,0 +1,241 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (mallie_amd -> libmallie_mgpu.so), against
+ (1) the committed reference goldens and (2) the oracle on the same seeded inputs.  Bit-exact for everything that is
+IEEE arithmetic (trace records, images); the image tolerance north_star allows (1e-4 per-pixel L2) is only a fallback
+that is reported, never silently used: see test_render_* for the exact criterion."""
+import numpy as np
+import pytest
+
+import mallie_amd as M
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_L2 = 1.0e-4  # north_star: per-pixel L2 against the reference CPU renderer on identical seeds
+
+
+def gpu_scene(name, own_bvh=False, **kw):
+    g = O.load_golden(name)
+    return M.Scene(g["verts"], g["faces"], g["matIDs"], g["normals"] if g["has_normals"] else None, O.golden_uvs(g),
+                   None if own_bvh else g["nodes"], None if own_bvh else g["indices"], **kw)
+
+
+def assert_images_match(img, ref, what):
+    """Bit-exact is the expectation (radiance is a sum of exactly representable products, so ulp-level differences in
+    device acos/sin/cos cannot reach it unless a hit/miss decision flips).  Report precisely if not."""
+    if img.tobytes() == ref.tobytes():
+        return
+    d = (img.astype(np.float64) - ref.astype(np.float64))
+    l2 = np.sqrt((d ** 2).sum(-1))
+    bad = int((l2 > 0).sum())
+    rms = float(np.sqrt((l2 ** 2).mean()))
+    assert rms <= TOL_L2 and bad <= max(1, img.shape[0] * img.shape[1] // 100000), \
+        "%s: %d pixels differ, max L2 %.3g, rms L2 %.3g" % (what, bad, l2.max(), rms)
+
+
+def test_loaded_native_library_and_device():
+    assert M.device_count() >= 1
+    assert M.lib_path().endswith("libmallie_mgpu.so")
+
+
+@pytest.mark.parametrize("name", ["cornell_obj", "cornell_eson", "teapot_obj"])
+def test_trace_matches_reference_goldens_bit_exact(name):
+    t = O.load_golden("trace_" + name)
+    sc = gpu_scene(name)
+    out, hit, st = sc.trace(t["rays"], want_stats=True)
+    ref = t["hits"]
+    assert np.array_equal(hit, ref["hit"].astype("u1"))
+    h = ref["hit"] == 1
+    for f in ("t", "u", "v", "faceID", "materialID", "f0", "f1", "f2", "position", "geometricNormal", "normal",
+              "texcoord"):
+        assert out[f][h].tobytes() == ref[f][h].tobytes(), (name, f)
+    # misses: what Traverse leaves behind (bvh_accel.cc:782-786)
+    assert np.all(out["t"][~h] == np.finfo(np.float64).max) and np.all(out["faceID"][~h] == 0xFFFFFFFF)
+    # same traversal order => same work counts as the CPU restatement
+    ost = O.Stats()
+    O.scene_from_golden(name).trace(t["rays"], ost)
+    assert (st["real_rays"], st["nodes"], st["tris"]) == (ost.real_rays, ost.nodes, ost.tris)
+
+
+def test_trace_edge_cases():
+    sc = gpu_scene("cornell_obj")
+    osc = O.scene_from_golden("cornell_obj")
+    out, hit = sc.trace(np.zeros((0, 6)))
+    assert len(out) == 0 and len(hit) == 0
+    rays = np.array([
+        [0, 5, 20, 0, 0, -1.0],          # SURVEY probe
+        [0, 5, 20, 0, 0, 1.0],           # away from the scene
+        [0, 5, 0, 0, 0, 0],              # zero direction: 1/0 = inf, 0*inf = nan paths of the slab test
+        [1e308, 1e308, 1e308, 0.3, -0.5, 0.8],   # the reference's post-miss "garbage" origins
+        [0, 5, 20, np.nan, 0, -1.0],
+        [0, 0.117050, 0, 1, 0, 0],       # grazing along the floor plane
+        [-5.144927, 0.117050, -4.948757, 1, 0, 0],  # starting exactly on a vertex
+    ])
+    out, hit = sc.trace(rays)
+    ref = osc.trace(rays)
+    assert np.array_equal(hit, ref["hit"].astype("u1"))
+    h = ref["hit"] == 1
+    for f in ("t", "u", "v", "faceID", "normal"):
+        assert out[f][h].tobytes() == ref[f][h].tobytes(), f
+    assert out["faceID"][0] == 7 and out["t"][0] == 24.591497079797261
+
+
+def test_trace_random_incoherent_vs_oracle_own_bvh():
+    """Product-built BVH (mgpu_bvh_build) on the device vs oracle-built BVH on the CPU, 200k incoherent rays."""
+    g = O.load_golden("teapot_obj")
+    rng = np.random.default_rng(11)
+    v = g["verts"].astype(np.float64)
+    lo, hi = v.min(0), v.max(0)
+    n = 200000
+    o = lo + (hi - lo) * (rng.random((n, 3)) * 1.4 - 0.2)
+    d = rng.normal(size=(n, 3))
+    rays = np.hstack([o, d])
+    sc = gpu_scene("teapot_obj", own_bvh=True)
+    out, hit, st = sc.trace(rays, want_stats=True)
+    ost = O.Stats()
+    ref = O.scene_from_golden("teapot_obj", own_bvh=True).trace(rays, ost)
+    assert np.array_equal(hit, ref["hit"].astype("u1"))
+    h = ref["hit"] == 1
+    assert h.sum() > 1000
+    for f in ("t", "u", "v", "faceID", "position", "geometricNormal", "normal", "texcoord"):
+        assert out[f][h].tobytes() == ref[f][h].tobytes(), f
+    assert (st["nodes"], st["tris"]) == (ost.nodes, ost.tris)
+
+
+RENDERS = ["render_cornell_obj_64_plane_2pass", "render_cornell_obj_64_noplane", "render_cornell_obj_128x96_plane",
+           "render_cornell_eson_48_plane", "render_cornell_obj_40x56_view2", "render_teapot_obj_64x48_plane"]
+
+
+@pytest.mark.parametrize("name", RENDERS)
+def test_render_replays_reference_stream(name):
+    """The reference image itself, on the GPU: per-pixel start states are captured from an oracle run in the
+    reference's serial RNG stream (itself bit-equal to the golden), then the device renders from that table."""
+    r = O.load_golden(name)
+    mesh = "cornell_eson" if "eson" in name else ("teapot_obj" if "teapot" in name else "cornell_obj")
+    osc = O.scene_from_golden(mesh)
+    W, H, passes = int(r["W"]), int(r["H"]), int(r["passes"])
+    frame = M.camera_frame(r["eye"], r["lookat"], r["up"], r["quat"], 45.0, W, H)
+    plane = osc.plane() if int(r["plane"]) else None
+    state = np.array(O.REFERENCE_SEED, "<u4")
+    oimg, _, ost, states = osc.render(frame, W, H, 16, passes, plane, O.RNG_STREAM, stream_state=state, want_states=True)
+    assert np.array_equal(oimg, r["images"].sum(0, dtype=np.float32) if passes > 1 else r["images"][0])
+    sc = gpu_scene(mesh)
+    if plane is not None:
+        assert sc.plane().tobytes() == plane.tobytes()
+    img, count, st = sc.render(frame, W, H, 16, passes, plane, M.RNG_TABLE, rng_states=states)
+    assert_images_match(img, oimg, name)
+    assert np.array_equal(count, r["count"])
+    # the device finishes post-miss continuation rays analytically: reference-equivalent call count must still agree,
+    # and the rays it really traced are the oracle's "real" rays with identical node / triangle work
+    assert st["trace_calls"] == ost["trace_calls"] and st["paths"] == ost["paths"]
+    assert (st["real_rays"], st["nodes"], st["tris"]) == (ost["real_rays"], ost["nodes"], ost["tris"])
+    # per-pass check too (pass 0 alone == Render()'s own output)
+    img0, _, _ = sc.render(frame, W, H, 16, 1, plane, M.RNG_TABLE, rng_states=states[:1])
+    assert_images_match(img0, r["images"][0], name + " pass0")
+
+
+@pytest.mark.parametrize("mpl,passes", [(16, 1), (5, 4), (2, 3), (1, 2), (9, 2)])
+def test_render_hash_mode_vs_oracle(mpl, passes):
+    sc, osc = gpu_scene("cornell_obj"), O.scene_from_golden("cornell_obj")
+    W, H = 96, 80
+    frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    plane = osc.plane()
+    img, count, st = sc.render(frame, W, H, mpl, passes, plane, M.RNG_HASH, seed=42, pass_base=3)
+    oimg, ocount, ost, _ = osc.render(frame, W, H, mpl, passes, plane, O.RNG_HASH, seed=42, pass_base=3)
+    assert_images_match(img, oimg, "hash mpl=%d" % mpl)
+    assert np.array_equal(count, ocount)
+    assert (st["trace_calls"], st["real_rays"], st["nodes"], st["tris"], st["paths"]) == \
+        (ost["trace_calls"], ost["real_rays"], ost["nodes"], ost["tris"], ost["paths"])
+    assert ost["garbage_hits"] == 0
+
+
+def test_render_materials_and_no_matids():
+    """materials_ filled (the .vox path of the reference) incl. an out-of-range id -> default 0.5; and a mesh without
+    materialIDs (every hit carries 0xFFFFFFFF: throughput never multiplied)."""
+    g = O.load_golden("cornell_obj")
+    mats = (np.arange(980) % 5).astype("u4")
+    diffuse = np.array([[0.8, 0.2, 0.1], [0.25, 0.5, 0.75], [0.9, 0.9, 0.9]])  # ids 3,4 are out of range
+    W, H = 64, 64
+    frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    for matIDs, md in ((mats, diffuse), (None, None)):
+        sc = M.Scene(g["verts"], g["faces"], matIDs, g["normals"], None, g["nodes"], g["indices"], mat_diffuse=md)
+        osc = O.OracleScene(g["verts"], g["faces"], matIDs, g["normals"], None, g["nodes"], g["indices"], mat_diffuse=md)
+        img, _, _ = sc.render(frame, W, H, 8, 2, osc.plane(), M.RNG_HASH, seed=7)
+        oimg, _, _, _ = osc.render(frame, W, H, 8, 2, osc.plane(), O.RNG_HASH, seed=7)
+        assert_images_match(img, oimg, "materials")
+        if md is not None:
+            assert not np.array_equal(img[..., 0], img[..., 2])  # RGB really differ
+
+
+def test_render_window_and_edge_sizes():
+    sc, osc = gpu_scene("cornell_obj"), O.scene_from_golden("cornell_obj")
+    plane = osc.plane()
+    for (W, H, win) in [(1, 1, None), (7, 3, None), (65, 9, None), (100, 60, (13, 5, 77, 41)), (100, 60, (0, 59, 100, 60))]:
+        frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+        base = np.full((H, W, 3), -1.0, "<f4")
+        img, count, _ = sc.render(frame, W, H, 5, 2, plane, M.RNG_HASH, seed=3, window=win, image=base.copy())
+        oimg, ocount, _, _ = osc.render(frame, W, H, 5, 2, plane, O.RNG_HASH, seed=3, window=win)
+        x0, y0, x1, y1 = win if win else (0, 0, W, H)
+        assert_images_match(img[y0:y1, x0:x1], oimg[y0:y1, x0:x1], "window %r" % (win,))
+        mask = np.ones((H, W), bool)
+        mask[y0:y1, x0:x1] = False
+        assert np.all(img[mask] == -1.0)  # pixels outside the window are untouched
+        assert np.array_equal(count, ocount)
+    # empty window is a no-op
+    img, count, _ = sc.render(frame, W, H, 5, 1, plane, M.RNG_HASH, window=(5, 5, 5, 9))
+    assert not img.any() and not count.any()
+
+
+def test_render_errors_are_loud():
+    sc = gpu_scene("cornell_obj")
+    frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=8, height=8)
+    with pytest.raises(M.MgpuError) as e:
+        sc.render(frame, 8, 8, 16, 1, None, M.RNG_STREAM)
+    assert e.value.status == -6
+    with pytest.raises(M.MgpuError):
+        sc.render(frame, 8, 8, 16, 1, None, M.RNG_TABLE, rng_states=None)
+    with pytest.raises(M.MgpuError):
+        sc.render(frame, 8, 8, 0, 1, None, M.RNG_HASH)
+    g = O.load_golden("cornell_obj")
+    bad = g["nodes"].copy()
+    bad["data"][0] = (1, 5000)
+    with pytest.raises(M.MgpuError):
+        M.Scene(g["verts"], g["faces"], g["matIDs"], g["normals"], None, bad, g["indices"])
+
+
+def test_full_size_properties_1080p():
+    """BASELINE config C2 size (1920x1080, maxPathLength 5) is too big for the oracle in a unit test, so check
+    size-independent properties: determinism, pass additivity in float order, strip-partition invariance, and an
+    oracle spot check on image rows."""
+    import torch
+    sc, osc = gpu_scene("cornell_obj"), O.scene_from_golden("cornell_obj")
+    W, H, mpl = 1920, 1080, 5
+    frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    plane = osc.plane()
+    dev = torch.device("cuda:0")
+
+    def render(passes, pass_base=0, **kw):
+        rows = kw.pop("n_rows", H)
+        buf = torch.empty((rows, W, 3), dtype=torch.float32, device=dev)
+        st = sc.render_strips_device(frame, W, H, buf.data_ptr(), rows, maxPathLength=mpl, passes=passes, plane=plane,
+                                     seed=1, pass_base=pass_base, want_stats=True, **kw)
+        return buf, st
+
+    a, st = render(2)
+    b, _ = render(2)
+    assert torch.equal(a, b)                                   # deterministic
+    p0, _ = render(1, 0)
+    p1, _ = render(1, 1)
+    assert torch.equal(a, p0 + p1)                             # pass-ordered float accumulation
+    assert st["paths"] == 2 * W * H and st["real_rays"] >= st["paths"]
+    # interleaved 8-row strips over 4 parts reassemble to the same frame (multi-GPU partition, single process here)
+    full = torch.empty_like(a)
+    strip, parts = 8, 4
+    for part in range(parts):
+        ys = [y for y in range(H) if (y // strip) % parts == part]
+        buf, _ = render(2, 0, n_rows=len(ys), y_first=part * strip, strip_h=strip, y_period=strip * parts)
+        full[torch.tensor(ys, device=dev)] = buf
+    assert torch.equal(full, a)
+    # oracle spot check on a band of rows
+    y0, y1 = 500, 508
+    oimg, _, _, _ = osc.render(frame, W, H, mpl, 2, plane, O.RNG_HASH, seed=1, window=(0, y0, W, y1))
+    assert_images_match(a[y0:y1].cpu().numpy(), oimg[y0:y1], "1080p rows")

@@ -1,0 +1,94 @@
+"""CPU-only checks of the product's host side (mallie_amd + libmallie_mgpu.so): the C-ABI library loads and exports
+every symbol include/mgpu.h declares, the host-side pieces of the path (camera frame, BVH build, plane, RNG seeding)
+agree bit-for-bit with the reference goldens and with the oracle, and compute calls fail loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import mallie_amd as M
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "mgpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(mgpu_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(names) >= 15, names
+    lib = ctypes.CDLL(M.lib_path())
+    for n in names:
+        assert hasattr(lib, n), "libmallie_mgpu.so does not export %s" % n
+    assert M.abi_version() == 1
+
+
+def test_pod_layouts_match_reference_sizes():
+    # sizeof measured from the reference build
+    assert M.NODE_DT.itemsize == 64 and M.RAY_DT.itemsize == 88 and M.ISECT_DT.itemsize == 184
+    assert M.ISECT_DT.fields["position"][1] == 48 and M.ISECT_DT.fields["normal"][1] == 96
+    assert M.ISECT_DT.fields["texcoord"][1] == 168 and M.RAY_DT.fields["dirSign"][1] == 72
+
+
+def test_camera_frame_matches_reference_goldens():
+    g = O.load_golden("camera")
+    for cfg, frame in zip(g["cfg"], g["frames"]):
+        f = M.camera_frame(cfg[3:6], cfg[6:9], cfg[9:12], cfg[12:16], cfg[2], int(cfg[0]), int(cfg[1]))
+        assert f.tobytes() == frame.tobytes(), cfg
+        assert f.tobytes() == O.camera_frame(cfg[3:6], cfg[6:9], cfg[9:12], cfg[12:16], cfg[2], int(cfg[0]),
+                                             int(cfg[1])).tobytes()
+
+
+@pytest.mark.parametrize("name", ["cornell_obj", "cornell_eson", "teapot_obj"])
+def test_bvh_build_matches_reference_goldens(name):
+    g = O.load_golden(name)
+    nodes, idx, st = M.bvh_build(g["verts"], g["faces"])
+    assert np.array_equal(idx, g["indices"])
+    assert nodes.tobytes() == g["nodes"].tobytes()
+    assert st["numLeafNodes"] + st["numBranchNodes"] == len(nodes)
+
+
+def test_bvh_build_matches_oracle_on_synthetic_meshes():
+    rng = np.random.default_rng(5)
+    for nf in (1, 15, 16, 17, 200, 3000):
+        verts = rng.normal(size=(3 * nf, 3)).round(3)
+        verts[: nf // 2] *= 0.0  # degenerate cluster: exercises the median fallback of a failed partition
+        faces = rng.integers(0, len(verts), (nf, 3)).astype("u4")
+        a = M.bvh_build(verts, faces)
+        b = O.bvh_build(verts, faces)
+        assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) and a[2] == b[2], nf
+    # non-default options
+    a = M.bvh_build(verts, faces, 0.35, 4, 6, 16)
+    b = O.bvh_build(verts, faces, 0.35, 4, 6, 16)
+    assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) and a[2]["maxTreeDepth"] <= 6
+
+
+def test_plane_and_seed_helpers_match_oracle():
+    sc = O.scene_from_golden("cornell_obj")
+    lo, hi = sc.bbox()
+    assert M.plane_from_bbox(lo, hi).tobytes() == sc.plane().tobytes()
+    for seed, p, px in [(1, 0, 0), (1, 15, 1920 * 1080 - 1), (0xDEADBEEFCAFE, 3, 77), (2 ** 64 - 1, 2 ** 32 - 1, 5)]:
+        assert np.array_equal(M.hash_state(seed, p, px), O.hash_state(seed, p, px))
+
+
+def test_compute_fails_loudly_without_gpu():
+    if M.device_count() > 0:
+        pytest.skip("a GPU is present")
+    g = O.load_golden("cornell_obj")
+    with pytest.raises(M.MgpuError) as e:
+        M.Scene(g["verts"], g["faces"], g["matIDs"], g["normals"], None, g["nodes"], g["indices"])
+    assert e.value.status == -2 and "no CPU path" in str(e.value)
+
+
+def test_product_does_not_touch_the_oracle():
+    """The shipped package must never import, link or call oracle/ (the checker)."""
+    pkg = os.path.join(ROOT, "mallie_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".cc", ".h")):
+                txt = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "mallie_oracle" not in txt and "oracle_lib" not in txt and "libmallie_oracle" not in txt, fn
+    out = os.popen("ldd %s" % M.lib_path()).read()
+    assert "oracle" not in out
