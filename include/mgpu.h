@@ -138,6 +138,13 @@ int mgpu_render_strips_device(MgpuScene *scene, const double frame[12], int W, i
                               const float plane[4], int rng_mode, const uint32_t *d_rng_states, uint64_t seed,
                               uint32_t pass_base, float *d_image, int32_t *d_count, void *stream, MgpuStats *stats);
 
+/* Diagnostic: traces ONE eye path (pixel px,py, given 128-bit start state) on the device and returns one record of 16
+ * doubles per PathTrace loop iteration actually executed (render.cc:402-453): org[3], dir[3], t, hit (0/1), BVH slot
+ * of the mesh hit or -1 (plane / miss), shading normal[3], Intersection::materialID, pathLength, throughput.x and
+ * radiance.x BEFORE the iteration's update. records must hold 16*maxPathLength doubles. */
+int mgpu_probe_path(MgpuScene *scene, const double frame[12], int W, int H, int px, int py, int maxPathLength,
+                    const float plane[4], const uint32_t start_state[4], double *records, int *n_records);
+
 /* The per-(pixel,pass) start state of MGPU_RNG_HASH (host helper; the device uses the same function). */
 void mgpu_hash_state(uint64_t seed, uint32_t pass, uint32_t pixel, uint32_t state[4]);
 

@@ -64,6 +64,8 @@ struct MgpuScene {
   int num_cu = 0;
   int render_blocks_per_cu = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double *probe_buf = nullptr; // set only for the duration of mgpu_probe_path
+  uint32_t probe_pixel = 0, probe_pass = 0;
 };
 
 namespace {
@@ -428,6 +430,9 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   P.count = d_count;
   P.work_counter = s->p_counters + (s->launch_seq++ % kCounterRing);
   P.stats = s->p_stats;
+  P.probe = s->probe_buf;
+  P.probe_pixel = s->probe_pixel;
+  P.probe_pass = s->probe_pass;
 
   HIP_TRY(hipMemsetAsync(P.work_counter, 0, sizeof(uint32_t), st));
   if (stats) {
@@ -512,6 +517,59 @@ int mgpu_render(MgpuScene *s, const double origin[3], const double corner[3], co
   }
   return MGPU_OK;
 #undef TRY_R
+}
+
+int mgpu_probe_path(MgpuScene *s, const double frame[12], int W, int H, int px, int py, int maxPathLength,
+                    const float plane[4], const uint32_t start_state[4], double *records, int *n_records) {
+  if (!s || !frame || !start_state || !records || !n_records) return fail(MGPU_ERR_INVALID, "NULL argument");
+  if (px < 0 || py < 0 || px >= W || py >= H || maxPathLength < 1) return fail(MGPU_ERR_INVALID, "bad pixel");
+  int rc = set_device(s);
+  if (rc) return rc;
+  const size_t nrec = (size_t)maxPathLength * kProbeStride;
+  double *d_probe = nullptr;
+  float *d_img = nullptr;
+  uint32_t *d_states = nullptr;
+  auto cleanup = [&]() {
+    s->probe_buf = nullptr;
+    if (d_probe) (void)hipFree(d_probe);
+    if (d_img) (void)hipFree(d_img);
+    if (d_states) (void)hipFree(d_states);
+  };
+#define TRY_P(expr)                                                             \
+  do {                                                                          \
+    hipError_t e_ = (expr);                                                     \
+    if (e_ != hipSuccess) {                                                     \
+      cleanup();                                                                \
+      return fail(MGPU_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    }                                                                           \
+  } while (0)
+  TRY_P(hipMalloc((void **)&d_probe, sizeof(double) * nrec));
+  TRY_P(hipMalloc((void **)&d_img, sizeof(float) * 3));
+  // a one-pixel window reads its start state at table index (pass 0, pixel): place it there
+  const size_t pix = (size_t)py * W + px;
+  TRY_P(hipMalloc((void **)&d_states, 16 * (pix + 1)));
+  TRY_P(hipMemcpy(d_states + 4 * pix, start_state, 16, hipMemcpyHostToDevice));
+  std::vector<double> nanfill(nrec, std::nan(""));
+  TRY_P(hipMemcpy(d_probe, nanfill.data(), sizeof(double) * nrec, hipMemcpyHostToDevice));
+  s->probe_buf = d_probe;
+  s->probe_pixel = (uint32_t)pix;
+  s->probe_pass = 0;
+  MgpuStats st;
+  rc = mgpu_render_strips_device(s, frame, W, H, px, px + 1, py, 1, 1, 1, maxPathLength, 1, plane, MGPU_RNG_TABLE,
+                                 d_states, 0, 0, d_img, nullptr, nullptr, &st);
+  if (rc) {
+    cleanup();
+    return rc;
+  }
+  std::vector<double> host(nrec);
+  TRY_P(hipMemcpy(host.data(), d_probe, sizeof(double) * nrec, hipMemcpyDeviceToHost));
+  int n = 0;
+  while (n < maxPathLength && !std::isnan(host[(size_t)n * kProbeStride])) ++n;
+  memcpy(records, host.data(), sizeof(double) * (size_t)n * kProbeStride);
+  *n_records = n;
+  cleanup();
+  return MGPU_OK;
+#undef TRY_P
 }
 
 } // extern "C"

@@ -231,17 +231,23 @@ __device__ __forceinline__ bool plane_hit(const float pl[4], V3 org, V3 dir, dou
 
 // ---- GenerateBasis + SampleDiffuseIS (render.cc:271-339) ------------------------------------------------------------------
 __device__ __forceinline__ V3 sample_diffuse(V3 n, Rng &rng) {
-  // minor axis by |n[i]| compared after rounding to float (fabsf), first minimum wins
+  // Minor axis by |n[i]| compared after rounding to float (fabsf); the loop of render.cc:279-285 keeps the FIRST
+  // strict minimum below 1e6, and an index that stays -1 (NaN / huge normal) takes the final else branch.
+  // Written as boolean selects, not as an int index + if/else-if chain: hipcc (ROCm 7.2, clang 22) lowers that
+  // chain to a switch whose gfx950 code leaves the third case's tangent.x undefined (caught by the path probe
+  // parity test; see DESIGN.md "Compiler hazards").
   const double ax = (double)fabsf((float)n.x), ay = (double)fabsf((float)n.y), az = (double)fabsf((float)n.z);
-  int index = 0;
-  double minval = ax; // ax < 1e6 always holds for a (near-)unit normal; keep the reference's guard anyway
-  if (!(ax < 1.0e+6)) { index = -1; minval = 1.0e+6; }
-  if (ay < minval) { minval = ay; index = 1; }
-  if (az < minval) { minval = az; index = 2; }
-  V3 t;
-  if (index == 0) t = v3(0.0, -n.z, n.y);
-  else if (index == 1) t = v3(-n.z, 0.0, n.x);
-  else t = v3(-n.y, n.x, 0.0);
+  const bool x_ok = ax < 1.0e+6;
+  const double m0 = x_ok ? ax : 1.0e+6;
+  const bool y_less = ay < m0;
+  const double m1 = y_less ? ay : m0;
+  const bool z_less = az < m1;
+  const bool use_z = z_less || (!y_less && !x_ok); // index == 2 or index == -1: tangent = (-n.y, n.x, 0)
+  const bool use_y = !z_less && y_less;            // index == 1:               tangent = (-n.z, 0, n.x)
+  V3 t;                                            // index == 0:               tangent = (0, -n.z, n.y)
+  t.x = use_z ? -n.y : (use_y ? -n.z : 0.0);
+  t.y = use_z ? n.x : (use_y ? 0.0 : -n.z);
+  t.z = use_z ? 0.0 : (use_y ? n.x : n.y);
   t = normalized(t);
   const V3 b = normalized(cross(t, n));
   const double theta = acos(sqrt(1.0 - rng_next(rng)));

@@ -37,7 +37,13 @@ __global__ __launch_bounds__(kBlock) void k_trace(DScene sc, const MgpuRay *__re
       is.position[k] = 0.0; is.geometricNormal[k] = 0.0; is.normal[k] = 0.0; is.tangent[k] = 0.0; is.binormal[k] = 0.0;
     }
     is.texcoord[0] = is.texcoord[1] = 0.0;
-    const bool hit = h.slot != kNoHit;
+    // Traverse reports a hit iff isect.t < DBL_MAX (bvh_accel.cc:838): a NaN t (NaN ray) fails that test even though
+    // TestLeafNode accepted a triangle and already wrote faceID / materialID.
+    const bool hit = h.t < kDblMax;
+    if (!hit && h.slot != kNoHit) {
+      is.faceID = sc.tris[h.slot].face;
+      is.materialID = sc.tris[h.slot].mat;
+    }
     if (hit) {
       // BuildIntersection, bvh_accel.cc:699-769
       const DTri *tp = sc.tris + h.slot;
@@ -129,6 +135,7 @@ __global__ __launch_bounds__(kBlock) void k_render(DScene sc, RenderParams P) {
   uint32_t last_mat = kNoMaterial; // Intersection::materialID as the reference would still hold it (stale on a miss)
   Counters c{0, 0, 0};
   uint32_t trace_calls = 0, paths = 0;
+  bool probe_on = false;
 
   for (;;) {
     // ---- 1. hand pixels to idle lanes ---------------------------------------------------------------------------
@@ -182,6 +189,7 @@ __global__ __launch_bounds__(kBlock) void k_render(DScene sc, RenderParams P) {
         hash_state(P.seed, P.pass_base + (uint32_t)pass, gpix, st);
       }
       rng = Rng{st[0], st[1], st[2], st[3]};
+      probe_on = P.probe && gpix == P.probe_pixel && (uint32_t)pass == P.probe_pass;
       const float ju = (float)(rng_next(rng) - 0.5);
       const float jv = (float)(rng_next(rng) - 0.5);
       org = v3(P.frame[0], P.frame[1], P.frame[2]);
@@ -202,12 +210,11 @@ __global__ __launch_bounds__(kBlock) void k_render(DScene sc, RenderParams P) {
 
     // ---- 4. the rest of one PathTrace loop iteration (render.cc:403-452) ----------------------------------------
     if (state == S_TRACE) {
-      bool hit = h.slot != kNoHit;
+      bool hit = h.t < kDblMax; // bvh_accel.cc:838
       double t = h.t;
       V3 n = v3(0, 0, 0);
+      if (h.slot != kNoHit) last_mat = sc.tris[h.slot].mat; // written by TestLeafNode on every accepted triangle
       if (hit) {
-        const DTri *tp = sc.tris + h.slot;
-        last_mat = tp->mat;
         if (sc.has_fv_normals) { // barycentric lerp, not renormalised (bvh_accel.cc:745-748)
           const double *nn = sc.slot_normal + 9 * (size_t)h.slot;
           const double w = 1.0 - h.u - h.v;
@@ -222,6 +229,13 @@ __global__ __launch_bounds__(kBlock) void k_render(DScene sc, RenderParams P) {
       if (P.has_plane && plane_hit(P.plane, org, dir, t, n)) {
         hit = true;
         last_mat = kNoMaterial; // prim-plane.cc:34
+      }
+      if (P.probe && probe_on) {
+        double *rec = P.probe + (size_t)(pathLength - 1) * kProbeStride;
+        rec[0] = org.x; rec[1] = org.y; rec[2] = org.z; rec[3] = dir.x; rec[4] = dir.y; rec[5] = dir.z;
+        rec[6] = t; rec[7] = hit ? 1.0 : 0.0; rec[8] = (h.t < kDblMax && t == h.t) ? (double)h.slot : -1.0;
+        rec[9] = n.x; rec[10] = n.y; rec[11] = n.z; rec[12] = (double)last_mat; rec[13] = (double)pathLength;
+        rec[14] = thr0; rec[15] = rad0;
       }
       bool path_done = false;
       if (!hit) {

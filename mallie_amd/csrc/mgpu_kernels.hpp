@@ -30,7 +30,10 @@ struct RenderParams {
   int32_t *count;   // device or null
   uint32_t *work_counter;        // device, zeroed before the launch
   unsigned long long *stats;     // device, kStatWords, accumulated
+  double *probe;                 // device or null: kProbeStride doubles per PathTrace iteration of ONE path
+  uint32_t probe_pixel, probe_pass; // full-frame pixel index and pass of the probed path
 };
+constexpr int kProbeStride = 16; // org[3] dir[3] t hit slot normal[3] materialID pathLength throughput.x radiance.x
 
 // stack capacities (LDS entries per lane) the kernels are instantiated for
 void launch_trace(int cap, dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, size_t n,

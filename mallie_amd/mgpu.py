@@ -46,6 +46,14 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch's ROCm wheels bundle their own libamdhip64/libhsa-runtime (same SONAME as
+    # /opt/rocm's).  Importing torch FIRST makes this library bind to that copy; loading ours first would pull in the
+    # system runtime as well and the second HSA instance then sees no GPU.  MALLIE_NO_TORCH=1 skips it (pure HIP use).
+    if os.environ.get("MALLIE_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(_LIB_PATH):
         raise ImportError("%s is missing: build it with `python -m mallie_amd.build` (needs hipcc). mallie_amd has no "
                           "CPU fallback." % _LIB_PATH)
@@ -73,6 +81,8 @@ def load_library():
                                             u32, vp, vp, vp, vp]
     L.mgpu_render_strips_device.restype = i32
     L.mgpu_hash_state.argtypes = [u64, u32, u32, vp]
+    L.mgpu_probe_path.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, C.POINTER(i32)]
+    L.mgpu_probe_path.restype = i32
     L.mgpu_camera_frame.argtypes = [vp, vp, vp, vp, dbl, i32, i32, vp]
     L.mgpu_camera_frame.restype = i32
     L.mgpu_bvh_build.argtypes = [vp, sz, vp, sz, dbl, i32, i32, i32, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), vp]
@@ -215,6 +225,15 @@ class Scene:
                                           x0, y0, x1, y1, maxPathLength, passes, _p(plane), rng_mode, _p(rng_states),
                                           seed, pass_base, _p(image), _p(count), C.byref(st)), "mgpu_render")
         return image, count, st.as_dict()
+
+    def probe_path(self, frame, W, H, px, py, start_state, maxPathLength=16, plane=None):
+        """mgpu_probe_path: per-iteration records (n,16) of one eye path traced on the device."""
+        rec = np.zeros((maxPathLength, 16))
+        n = C.c_int(0)
+        _check(load_library().mgpu_probe_path(self.h, _p(_c(frame, "<f8")), W, H, px, py, maxPathLength,
+                                              _p(_c(plane, "<f4")), _p(_c(start_state, "<u4")), _p(rec), C.byref(n)),
+               "mgpu_probe_path")
+        return rec[: n.value]
 
     def render_strips_device(self, frame, W, H, d_image_ptr, n_rows, x0=0, x1=None, y_first=0, strip_h=None,
                              y_period=None, maxPathLength=16, passes=1, plane=None, rng_mode=RNG_HASH,

@@ -784,7 +784,7 @@ typedef struct {
 /* PathTrace, render.cc:381-456.  Nothing is short-circuited: after the first miss the path keeps iterating with the
  * stale intersection record exactly as the reference does; those Trace() calls are only COUNTED apart. */
 static int path_trace(const mo_scene *s, const double frame[12], const float *plane, int maxPathLength, int px, int py,
-                      uint32_t rng[4], double radiance_out[3], path_counters *pc) {
+                      uint32_t rng[4], double radiance_out[3], path_counters *pc, double *probe, int *probe_n) {
   float ju = (float)(mo_xorshift128(rng) - 0.5);
   float jv = (float)(mo_xorshift128(rng) - 0.5);
   double ray[6];
@@ -810,10 +810,21 @@ static int path_trace(const mo_scene *s, const double frame[12], const float *pl
       pc->nodes += nv;
       pc->tris += nt;
     }
+    int mesh_final = hit; /* the mesh hit survives unless the plane is closer */
     if (plane) {
       int ph = plane_hit(plane, &is, org, dir);
       if (ph && escaped) pc->garbage_hits++;
+      if (ph) mesh_final = 0;
       hit |= ph;
+    }
+    if (probe && !escaped) { /* same record as mgpu_probe_path (include/mgpu.h) */
+      double *rec = probe + (size_t)(pathLength - 1) * 16;
+      rec[0] = org.x; rec[1] = org.y; rec[2] = org.z; rec[3] = dir.x; rec[4] = dir.y; rec[5] = dir.z;
+      rec[6] = is.t; rec[7] = hit ? 1.0 : 0.0;
+      rec[8] = mesh_final ? (double)is.faceID : -1.0;
+      rec[9] = is.normal.x; rec[10] = is.normal.y; rec[11] = is.normal.z; rec[12] = (double)is.materialID;
+      rec[13] = (double)pathLength; rec[14] = thr[0]; rec[15] = rad[0];
+      *probe_n = (int)pathLength;
     }
     if (!hit) {
       if (pathLength < 2) break; /* kMinPathLength */
@@ -881,7 +892,7 @@ int mo_render(const mo_scene *s, const double frame[12], int W, int H, int x0, i
           size_t px = (size_t)y * W + x;
           if (states_out) memcpy(&states_out[((size_t)p * W * H + px) * 4], stream_state, 16);
           double rad[3];
-          if (path_trace(s, frame, plane, maxPathLength, x, y, stream_state, rad, &total)) return -3;
+          if (path_trace(s, frame, plane, maxPathLength, x, y, stream_state, rad, &total, NULL, NULL)) return -3;
           for (int c = 0; c < 3; c++) {
             float f = (float)rad[c];
             image[3 * px + c] = (p == 0) ? f : image[3 * px + c] + f;
@@ -910,7 +921,7 @@ int mo_render(const mo_scene *s, const double frame[12], int W, int H, int x0, i
             else mo_hash_state(seed, pass_base + (uint32_t)p, (uint32_t)px, st);
             if (states_out) memcpy(&states_out[((size_t)p * W * H + px) * 4], st, 16);
             double rad[3];
-            if (path_trace(s, frame, plane, maxPathLength, x, y, st, rad, &local)) {
+            if (path_trace(s, frame, plane, maxPathLength, x, y, st, rad, &local, NULL, NULL)) {
 #pragma omp atomic write
               err = -3;
             }
@@ -940,4 +951,21 @@ int mo_render(const mo_scene *s, const double frame[12], int W, int H, int x0, i
   }
   if (stats) merge_stats(stats, &total);
   return err;
+}
+
+/* One eye path with per-iteration records (16 doubles each, layout of mgpu_probe_path in include/mgpu.h, except that
+ * field 8 holds the FACE id of a mesh hit rather than the BVH slot).  Only iterations up to and including the first
+ * miss are recorded, which is what the device executes. */
+int mo_probe_path(const mo_scene *s, const double frame[12], int px, int py, int maxPathLength, const float *plane,
+                  const uint32_t start_state[4], double *records, int *n_records, double radiance[3]) {
+  if (!s || !frame || !start_state || !records || !n_records) return -1;
+  uint32_t st[4];
+  memcpy(st, start_state, 16);
+  path_counters pc;
+  memset(&pc, 0, sizeof(pc));
+  double rad[3];
+  *n_records = 0;
+  int rc = path_trace(s, frame, plane, maxPathLength, px, py, st, rad, &pc, records, n_records);
+  if (radiance) { radiance[0] = rad[0]; radiance[1] = rad[1]; radiance[2] = rad[2]; }
+  return rc;
 }

@@ -128,6 +128,10 @@ int mo_render(const mo_scene *s, const double frame[12], int W, int H, int x0, i
               const uint32_t *rng_states, uint64_t seed, uint32_t pass_base, float *image, int32_t *count,
               uint32_t *states_out, mo_stats *stats, int nthreads);
 
+/* One eye path with per-iteration records: see mallie_oracle.c. records: 16*maxPathLength doubles. */
+int mo_probe_path(const mo_scene *s, const double frame[12], int px, int py, int maxPathLength, const float *plane,
+                  const uint32_t start_state[4], double *records, int *n_records, double radiance[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,8 @@ def lib():
         L.mo_render.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, u64, u32, vp, vp, vp,
                                 vp, i32]
         L.mo_render.restype = i32
+        L.mo_probe_path.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, C.POINTER(i32), vp]
+        L.mo_probe_path.restype = i32
         _lib = L
     return _lib
 
@@ -137,6 +139,16 @@ class OracleScene:
         if rc:
             raise RuntimeError("mo_trace failed: %d" % rc)
         return out
+
+    def probe_path(self, frame, px, py, start_state, maxPathLength=16, plane=None):
+        rec = np.zeros((maxPathLength, 16))
+        n = C.c_int(0)
+        rad = np.zeros(3)
+        rc = lib().mo_probe_path(self.h, _p(_c(frame, "<f8")), px, py, maxPathLength, _p(_c(plane, "<f4")),
+                                 _p(_c(start_state, "<u4")), _p(rec), C.byref(n), _p(rad))
+        if rc:
+            raise RuntimeError("mo_probe_path failed: %d" % rc)
+        return rec[: n.value], rad
 
     def render(self, frame, W, H, maxPathLength=16, passes=1, plane=None, rng_mode=RNG_HASH, stream_state=None,
                rng_states=None, seed=1, pass_base=0, window=None, count=None, want_states=False, nthreads=0):
