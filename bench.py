@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s + ms/frame of the render hot path on N MI355X GPUs (BASELINE.json metric).
+
+Workload (configs[1]): cornellbox_suzanne, 1920x1080, 16 spp, 4 bounces (maxPathLength 5), plane on,
+eye (0,0,20) -> (0,0,0), per-(pixel,pass) seeding, seed 1.  One "step" = one whole frame: 16 passes of Render()
+semantics accumulated on the device in one persistent-kernel launch per GPU (+ one RCCL gather of the row strips to
+rank 0 when N > 1).  The scene (mesh arrays from tests/golden, BVH built by this library's host builder) is resident
+in HBM before the timed region; the frame stays in HBM.
+
+"rays" = BVH traversals actually performed ("real" rays: primary + bounce rays up to and including a path's first
+miss); the reference's post-miss continuation rays are finished analytically and are NOT counted.
+
+Launch:  python bench.py [--gpus N --steps K --warmup W]
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+                bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes per event: fp64 reference-layout node, pre-gathered fp64 triangle + face id,
+# ray in (org+dir) + hit out (t,u,v,id)
+B_NODE, B_TRI, B_RAY = 64, 76, 80
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+WORKLOAD = dict(scene="cornellbox_suzanne", width=1920, height=1080, spp=16, bounces=4, plane=True, eye=(0.0, 0.0, 20.0),
+                lookat=(0.0, 0.0, 0.0), seed=1)
+
+
+def load_scene_arrays():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "cornell_obj.npz"))
+    return g["verts"].astype(np.float64), g["faces"], g["matIDs"], g["normals"]
+
+
+def cpu_baseline(frame, plane, mpl):
+    """The oracle (this repo's CPU restatement, pinned bit-exact to the reference) timed on the host cores on a bounded
+    sample of the same workload: the same 1920x1080 frame, same path length and seeding, `spp_sample` passes."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O  # the checker -- used here only as the timed CPU baseline
+    verts, faces, mats, normals = load_scene_arrays()
+    nodes, idx, _ = O.bvh_build(verts, faces)
+    osc = O.OracleScene(verts, faces, mats, normals, None, nodes, idx)
+    cores = len(os.sched_getaffinity(0))
+    W, H = WORKLOAD["width"], WORKLOAD["height"]
+    # warm-up band (thread start-up, page faults), then the sample: whole frames of the workload until >= ~10 s of
+    # wall time or 4 frames, whichever comes first
+    osc.render(frame, W, H, mpl, 1, plane, O.RNG_HASH, seed=WORKLOAD["seed"], window=(0, 512, W, 576), nthreads=cores)
+    spp_sample, dt, rays = 0, 0.0, 0
+    while dt < 10.0 and spp_sample < 4 * WORKLOAD["spp"]:
+        t0 = time.perf_counter()
+        _, _, st, _ = osc.render(frame, W, H, mpl, WORKLOAD["spp"], plane, O.RNG_HASH, seed=WORKLOAD["seed"],
+                                 pass_base=spp_sample, nthreads=cores)
+        dt += time.perf_counter() - t0
+        rays += st["real_rays"]
+        spp_sample += WORKLOAD["spp"]
+    st = dict(real_rays=rays)
+    return dict(value=round(st["real_rays"] / dt / 1e6, 3), unit="Mrays/s", cores=cores, kind="port",
+                sample="%dx%d frames of the workload, %d passes in total (%d spp each), maxPathLength %d, OpenMP %d "
+                              "threads, %.1f s wall, %.0f ms/pass" % (W, H, spp_sample, WORKLOAD["spp"], mpl, cores, dt,
+                                                                      1e3 * dt / spp_sample))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import mallie_amd as M
+    from mallie_amd.frame import FrameRenderer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available() or M.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    W, H = WORKLOAD["width"], WORKLOAD["height"]
+    mpl, spp = WORKLOAD["bounces"] + 1, WORKLOAD["spp"]
+    verts, faces, mats, normals = load_scene_arrays()
+    scene = M.Scene(verts, faces, mats, normals, None, device=local_rank)  # BVH: this library's host builder
+    frame = M.camera_frame(WORKLOAD["eye"], WORKLOAD["lookat"], width=W, height=H)
+    plane = scene.plane() if WORKLOAD["plane"] else None
+    fr = FrameRenderer(scene, frame, W, H, mpl, spp, plane, WORKLOAD["seed"], rank, world, dev)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        fr.render()
+    sync_all()
+    scene.stats_read(reset=True)
+    scene.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fr.render()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = scene.timing_read()
+    st = scene.stats_read(reset=True)
+
+    # max elapsed over ranks, sum of work over ranks
+    red = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    work = torch.tensor([st["real_rays"], st["nodes"], st["tris"], st["trace_calls"], st["paths"]], dtype=torch.float64,
+                        device=dev)
+    kern = torch.tensor([kernel_ms / max(launches, 1)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        dist.all_reduce(work, op=dist.ReduceOp.SUM)
+    elapsed = float(red.item())
+    rays, nodes, tris, trace_calls, paths = [float(x) for x in work.tolist()]
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = rays / elapsed / 1e6
+        # roofline of the dominant kernel (k_render) on THIS rank: algorithmic bytes of one launch / its mean duration
+        alg_bytes_launch = (st["nodes"] * B_NODE + st["tris"] * B_TRI + st["real_rays"] * B_RAY) / max(launches, 1)
+        kernel_avg_ms = float(kern.item())
+        achieved = alg_bytes_launch / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/sec + ms/frame at 1920x1080, cornellbox_suzanne, 1/2/4/8 GPU",
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "cornellbox_suzanne.obj mesh (980 tris, 205-node binned-SAH BVH), 1920x1080, 16 spp, "
+                                   "4 bounces (maxPathLength 5), plane on, eye (0,0,20), per-(pixel,pass) xorshift128 "
+                                   "seeding, seed 1; 1 step = 1 frame",
+                       "parallelism": "replicated scene, interleaved 8-row strips x%d, 1 RCCL gather/frame" % world
+                                      if world > 1 else "single GPU, persistent-threads kernel",
+                       "rays_per_frame": int(rays / args.steps), "trace_calls_per_frame": int(trace_calls / args.steps),
+                       "nodes_per_ray": round(nodes / rays, 3), "tris_per_ray": round(tris / rays, 3),
+                       "mtrace_calls_per_s": round(trace_calls / elapsed / 1e6, 2)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "k_render", "kernel_avg_ms": round(kernel_avg_ms, 3),
+                         "algorithmic_bytes_per_launch": int(alg_bytes_launch),
+                         "note": "algorithmic bytes = nodes*64 + tris*76 + rays*80 (SURVEY 8(d)); the 84 KB scene is "
+                                 "cache-resident, so HBM traffic proper is ~the framebuffer (see profiles/)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frame, plane, mpl)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -138,6 +138,18 @@ int mgpu_render_strips_device(MgpuScene *scene, const double frame[12], int W, i
                               const float plane[4], int rng_mode, const uint32_t *d_rng_states, uint64_t seed,
                               uint32_t pass_base, float *d_image, int32_t *d_count, void *stream, MgpuStats *stats);
 
+/* Device work counters accumulate over every mgpu_render* call made with stats == NULL (calls with stats != NULL zero
+ * them first and return that call's own counts).  mgpu_stats_read synchronises the device and returns the running
+ * totals (kernel_ms / total_ms are left 0); reset != 0 zeroes them afterwards. */
+int mgpu_stats_read(MgpuScene *scene, MgpuStats *out, int reset);
+
+/* Per-launch kernel timing for asynchronous use: after mgpu_timing_enable(scene, 1) every mgpu_render_strips_device call
+ * made with stats == NULL brackets its kernel with HIP events on the launch stream (no synchronisation).
+ * mgpu_timing_read synchronises, returns the summed kernel time and the number of launches since the last read, and
+ * rearms the event ring (at most 4096 launches between reads). */
+int mgpu_timing_enable(MgpuScene *scene, int on);
+int mgpu_timing_read(MgpuScene *scene, double *total_ms, int *launches);
+
 /* Diagnostic: traces ONE eye path (pixel px,py, given 128-bit start state) on the device and returns one record of 16
  * doubles per PathTrace loop iteration actually executed (render.cc:402-453): org[3], dir[3], t, hit (0/1), BVH slot
  * of the mesh hit or -1 (plane / miss), shading normal[3], Intersection::materialID, pathLength, throughput.x and

@@ -64,6 +64,10 @@ struct MgpuScene {
   int num_cu = 0;
   int render_blocks_per_cu = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // per-launch kernel timing (HIP events on the launch stream), enabled by mgpu_timing_enable
+  bool timing_on = false;
+  std::vector<hipEvent_t> t_ev; // pairs: start, stop
+  size_t t_used = 0;            // events used since the last mgpu_timing_read
   double *probe_buf = nullptr; // set only for the duration of mgpu_probe_path
   uint32_t probe_pixel = 0, probe_pass = 0;
 };
@@ -308,6 +312,7 @@ int mgpu_scene_destroy(MgpuScene *s) {
     if (p) (void)hipFree(p);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
+  for (hipEvent_t e : s->t_ev) (void)hipEventDestroy(e);
   delete s;
   return MGPU_OK;
 }
@@ -439,8 +444,24 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
     HIP_TRY(hipMemsetAsync(s->p_stats, 0, sizeof(unsigned long long) * kStatWords, st));
     HIP_TRY(hipEventRecord(s->ev0, st));
   }
+  hipEvent_t tev0 = nullptr, tev1 = nullptr;
+  if (s->timing_on && !stats) {
+    if (s->t_used + 2 > s->t_ev.size()) {
+      if (s->t_ev.size() >= 2 * 4096) return fail(MGPU_ERR_INVALID, "timing ring full: call mgpu_timing_read");
+      hipEvent_t a, b;
+      HIP_TRY(hipEventCreate(&a));
+      HIP_TRY(hipEventCreate(&b));
+      s->t_ev.push_back(a);
+      s->t_ev.push_back(b);
+    }
+    tev0 = s->t_ev[s->t_used];
+    tev1 = s->t_ev[s->t_used + 1];
+    s->t_used += 2;
+    HIP_TRY(hipEventRecord(tev0, st));
+  }
   launch_render(s->cap, dim3((unsigned)blocks), st, s->d, P);
   HIP_TRY(hipGetLastError());
+  if (tev1) HIP_TRY(hipEventRecord(tev1, st));
   if (stats) {
     HIP_TRY(hipEventRecord(s->ev1, st));
     unsigned long long w[kStatWords];
@@ -517,6 +538,43 @@ int mgpu_render(MgpuScene *s, const double origin[3], const double corner[3], co
   }
   return MGPU_OK;
 #undef TRY_R
+}
+
+int mgpu_stats_read(MgpuScene *s, MgpuStats *out, int reset) {
+  if (!s || !out) return fail(MGPU_ERR_INVALID, "NULL argument");
+  int rc = set_device(s);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  unsigned long long w[kStatWords];
+  HIP_TRY(hipMemcpy(w, s->p_stats, sizeof(w), hipMemcpyDeviceToHost));
+  memset(out, 0, sizeof(*out));
+  read_stats(w, out);
+  if (reset) HIP_TRY(hipMemset(s->p_stats, 0, sizeof(w)));
+  return MGPU_OK;
+}
+
+int mgpu_timing_enable(MgpuScene *s, int on) {
+  if (!s) return fail(MGPU_ERR_INVALID, "scene is NULL");
+  s->timing_on = on != 0;
+  s->t_used = 0;
+  return MGPU_OK;
+}
+
+int mgpu_timing_read(MgpuScene *s, double *total_ms, int *launches) {
+  if (!s || !total_ms || !launches) return fail(MGPU_ERR_INVALID, "NULL argument");
+  int rc = set_device(s);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  double sum = 0.0;
+  for (size_t i = 0; i + 1 < s->t_used; i += 2) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->t_ev[i], s->t_ev[i + 1]));
+    sum += ms;
+  }
+  *total_ms = sum;
+  *launches = (int)(s->t_used / 2);
+  s->t_used = 0;
+  return MGPU_OK;
 }
 
 int mgpu_probe_path(MgpuScene *s, const double frame[12], int W, int H, int px, int py, int maxPathLength,

@@ -1,0 +1,66 @@
+"""Multi-GPU frame rendering: the image is cut into interleaved row strips, one process per GPU renders its strips with
+the scene replicated in its HBM, and ONE gather over RCCL/xGMI brings the float RGB strips to rank 0.
+
+torch is used here for what it is good at -- device buffers, streams, torch.distributed -- while all rendering goes
+through the C ABI (mallie_amd.mgpu).  Pixels are seeded per (pixel, pass), so the frame is independent of the GPU count.
+"""
+import numpy as np
+import torch
+
+from . import mgpu
+
+STRIP_H = 8  # rows per strip; 8 keeps the 8x8 work tiles of the kernel whole and balances the cheap lower half
+
+
+def strip_rows(H, world, rank, strip_h=STRIP_H):
+    """Frame rows owned by `rank`: strips rank, rank+world, ... of strip_h rows each (last strip may be partial)."""
+    ys = np.arange(H)
+    return ys[(ys // strip_h) % world == rank]
+
+
+class FrameRenderer:
+    """Renders whole frames of one camera on `world` GPUs (world == 1: plain single-GPU rendering).
+
+    render() is asynchronous on torch's current stream; after it returns on rank 0, `self.frame_buffer` (H x W x 3
+    float32, device) holds the sum over `passes` passes once the stream is synchronised.
+    """
+
+    def __init__(self, scene, frame, W, H, maxPathLength, passes, plane=None, seed=1, rank=0, world=1, device=None,
+                 strip_h=STRIP_H):
+        self.scene, self.frame = scene, np.ascontiguousarray(frame, "<f8")
+        self.W, self.H, self.mpl, self.passes = W, H, maxPathLength, passes
+        self.plane = None if plane is None else np.ascontiguousarray(plane, "<f4")
+        self.seed, self.rank, self.world, self.strip_h = seed, rank, world, strip_h
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.rows = strip_rows(H, world, rank, strip_h)
+        self.n_rows = len(self.rows)
+        counts = [len(strip_rows(H, world, r, strip_h)) for r in range(world)]
+        self.max_rows = max(counts)
+        # local strips, padded to the largest share so the gather is uniform
+        self.local = torch.zeros((self.max_rows, W, 3), dtype=torch.float32, device=self.device)
+        if world > 1:
+            if rank == 0:
+                self.gathered = [torch.empty_like(self.local) for _ in range(world)]
+                self.frame_buffer = torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
+                self.row_index = [torch.from_numpy(strip_rows(H, world, r, strip_h)).to(self.device) for r in range(world)]
+                self.row_count = counts
+            else:
+                self.gathered, self.frame_buffer = None, None
+        else:
+            self.frame_buffer = self.local  # n_rows == H
+
+    def render(self, pass_base=0):
+        import torch.distributed as dist
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if self.n_rows:
+            self.scene.render_strips_device(self.frame, self.W, self.H, self.local.data_ptr(), self.n_rows,
+                                            y_first=self.rank * self.strip_h, strip_h=self.strip_h,
+                                            y_period=self.strip_h * self.world, maxPathLength=self.mpl,
+                                            passes=self.passes, plane=self.plane, rng_mode=mgpu.RNG_HASH, seed=self.seed,
+                                            pass_base=pass_base, stream=stream)
+        if self.world > 1:
+            dist.gather(self.local, self.gathered if self.rank == 0 else None, dst=0)
+            if self.rank == 0:
+                for r in range(self.world):
+                    self.frame_buffer.index_copy_(0, self.row_index[r], self.gathered[r][: self.row_count[r]])
+        return self.frame_buffer

@@ -81,6 +81,12 @@ def load_library():
                                             u32, vp, vp, vp, vp]
     L.mgpu_render_strips_device.restype = i32
     L.mgpu_hash_state.argtypes = [u64, u32, u32, vp]
+    L.mgpu_stats_read.argtypes = [vp, vp, i32]
+    L.mgpu_stats_read.restype = i32
+    L.mgpu_timing_enable.argtypes = [vp, i32]
+    L.mgpu_timing_enable.restype = i32
+    L.mgpu_timing_read.argtypes = [vp, C.POINTER(dbl), C.POINTER(i32)]
+    L.mgpu_timing_read.restype = i32
     L.mgpu_probe_path.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, C.POINTER(i32)]
     L.mgpu_probe_path.restype = i32
     L.mgpu_camera_frame.argtypes = [vp, vp, vp, vp, dbl, i32, i32, vp]
@@ -225,6 +231,21 @@ class Scene:
                                           x0, y0, x1, y1, maxPathLength, passes, _p(plane), rng_mode, _p(rng_states),
                                           seed, pass_base, _p(image), _p(count), C.byref(st)), "mgpu_render")
         return image, count, st.as_dict()
+
+    def stats_read(self, reset=True):
+        """Running device work counters since the last reset (synchronises)."""
+        st = Stats()
+        _check(load_library().mgpu_stats_read(self.h, C.byref(st), 1 if reset else 0), "mgpu_stats_read")
+        return st.as_dict()
+
+    def timing_enable(self, on=True):
+        _check(load_library().mgpu_timing_enable(self.h, 1 if on else 0), "mgpu_timing_enable")
+
+    def timing_read(self):
+        """(sum of kernel ms, launches) since the last read; HIP events on the launch stream (synchronises)."""
+        ms, n = C.c_double(0), C.c_int(0)
+        _check(load_library().mgpu_timing_read(self.h, C.byref(ms), C.byref(n)), "mgpu_timing_read")
+        return ms.value, n.value
 
     def probe_path(self, frame, W, H, px, py, start_state, maxPathLength=16, plane=None):
         """mgpu_probe_path: per-iteration records (n,16) of one eye path traced on the device."""
