@@ -143,6 +143,13 @@ int mgpu_render_strips_device(MgpuScene *scene, const double frame[12], int W, i
  * totals (kernel_ms / total_ms are left 0); reset != 0 zeroes them afterwards. */
 int mgpu_stats_read(MgpuScene *scene, MgpuStats *out, int reset);
 
+/* Diagnostic: the 32 raw device counter words (layout in mallie_amd/csrc/mgpu_kernels.hpp; words 8.. are only filled by
+ * -DMGPU_UTIL experiment builds). */
+int mgpu_debug_words(MgpuScene *scene, unsigned long long *out32);
+
+/* Diagnostic (MGPU_WAVE_LOG=1 + -DMGPU_UTIL builds): per-wave {start tick, end tick, rays, XCC id}. */
+int mgpu_debug_wave_log(MgpuScene *scene, unsigned long long *out, size_t n_waves);
+
 /* Per-launch kernel timing for asynchronous use: after mgpu_timing_enable(scene, 1) every mgpu_render_strips_device call
  * made with stats == NULL brackets its kernel with HIP events on the launch stream (no synchronisation).
  * mgpu_timing_read synchronises, returns the summed kernel time and the number of launches since the last read, and

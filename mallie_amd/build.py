@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmallie_mgpu.so")
-SOURCES = ["mgpu_kernels.hip", "mgpu_api.hip", "host/bvh_build.cc", "host/camera.cc", "host/scene_render.cc",
+SOURCES = ["mgpu_kernels.hip", "mgpu_render_sm.hip", "mgpu_api.hip", "host/bvh_build.cc", "host/camera.cc", "host/scene_render.cc",
            "host/mesh_io.cc"]
 HEADERS = ["mgpu_device.hpp", "mgpu_kernels.hpp", "host/mesh_io.hpp", os.path.join("..", "..", "include", "mgpu.h"),
            os.path.join("..", "..", "include", "mallie", "mallie_api.hpp")]
@@ -33,6 +33,16 @@ def is_stale():
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_variant(out_path, extra_flags):
+    """A/B builds for kernel experiments: same sources, extra -D flags, separate output (load via MALLIE_MGPU_LIB)."""
+    cmd = [hipcc()] + FLAGS + list(extra_flags) + ["-o", out_path] + [os.path.join(CSRC, f) for f in SOURCES]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed building %s" % out_path)
+    return out_path
 
 
 def build(force=False, verbose=False):

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -68,6 +69,9 @@ struct MgpuScene {
   bool timing_on = false;
   std::vector<hipEvent_t> t_ev; // pairs: start, stop
   size_t t_used = 0;            // events used since the last mgpu_timing_read
+  float *p_planes = nullptr;   // per-pass radiance planes of k_render_sm (grow-only)
+  size_t planes_floats = 0;
+  unsigned long long *p_wave_log = nullptr; // 4 words x 16384 waves, diagnostic
   double *probe_buf = nullptr; // set only for the duration of mgpu_probe_path
   uint32_t probe_pixel = 0, probe_pass = 0;
 };
@@ -307,7 +311,7 @@ int mgpu_scene_destroy(MgpuScene *s) {
   (void)hipSetDevice(s->device);
   (void)hipDeviceSynchronize();
   void *ptrs[] = {s->p_nodes, s->p_tris, s->p_slotn, s->p_mat, s->p_verts, s->p_faces, s->p_fvn, s->p_fvuv,
-                  s->p_overflow, s->p_counters, s->p_stats};
+                  s->p_overflow, s->p_counters, s->p_stats, s->p_planes, s->p_wave_log};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -406,17 +410,40 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   if (win_w == 0 || n_rows == 0) return MGPU_OK;
   hipStream_t st = (hipStream_t)stream;
 
-  // persistent grid: as many workgroups as stay resident, capped by the work available
-  if (!s->render_blocks_per_cu) {
-    s->render_blocks_per_cu = 2;
-    // 169-ish VGPRs -> 2 waves/SIMD -> 2 workgroups of 4 waves per CU; the query is advisory
+  // kernel choice: "sm_lds" (state machine, scene staged in LDS, one 1024-thread workgroup per CU) when the BVH fits
+  // next to the stacks, else "sm" (state machine, scene through L1/L2); "v1" = the first, ray-synchronous kernel.
+  const size_t scene_lds = sizeof(MgpuNode) * s->nn + sizeof(DTri) * s->nf;
+  int kern = 2; // 0 = v1, 1 = sm, 2 = sm_lds
+  if (const char *e = getenv("MGPU_RENDER_KERNEL")) {
+    if (!strcmp(e, "v1")) kern = 0;
+    else if (!strcmp(e, "sm")) kern = 1;
+    else if (!strcmp(e, "sm_lds")) kern = 2;
+    else return fail(MGPU_ERR_INVALID, "MGPU_RENDER_KERNEL=%s (expected v1|sm|sm_lds)", e);
   }
+  int block = kern == 2 ? 1024 : kBlock;
+  size_t shmem = (size_t)(block / 64) * s->cap * 64 * sizeof(uint32_t);
+  if (kern == 2) {
+    if (shmem + scene_lds > kLdsBudget) {
+      block = 512;
+      shmem = (size_t)(block / 64) * s->cap * 64 * sizeof(uint32_t);
+    }
+    if (shmem + scene_lds > kLdsBudget) {
+      kern = 1;
+      block = kBlock;
+      shmem = (size_t)(block / 64) * s->cap * 64 * sizeof(uint32_t);
+    } else {
+      shmem += scene_lds;
+    }
+  }
+  int per_cu = kern == 2 ? 1 : 2;
+  if (const char *e = getenv("MGPU_RENDER_BLOCKS_PER_CU")) per_cu = atoi(e) < 1 ? 1 : atoi(e);
+  // persistent grid: as many workgroups as stay resident, capped by the work available
   const uint64_t tiles = (uint64_t)((win_w + 7) / 8) * (uint64_t)((n_rows + 7) / 8);
-  uint64_t blocks = (uint64_t)s->num_cu * (uint64_t)s->render_blocks_per_cu;
-  const uint64_t max_useful = (tiles * 64 + kBlock - 1) / kBlock;
+  uint64_t blocks = (uint64_t)s->num_cu * (uint64_t)per_cu;
+  const uint64_t max_useful = (tiles * 64 + block - 1) / block;
   if (blocks > max_useful) blocks = max_useful;
   if (blocks < 1) blocks = 1;
-  rc = ensure_overflow(s, blocks * kBlock);
+  rc = ensure_overflow(s, blocks * block);
   if (rc) return rc;
 
   RenderParams P;
@@ -433,8 +460,35 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   P.pass_base = pass_base;
   P.image = d_image;
   P.count = d_count;
+  P.out = d_image;
+  P.pass_stride = 0;
+  const size_t n_floats = 3 * (size_t)n_rows * (size_t)win_w;
+  if (kern != 0 && passes > 1) {
+    const size_t need = n_floats * (size_t)passes;
+    if (need > s->planes_floats) {
+      if (s->p_planes) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(s->p_planes));
+        s->device_bytes -= s->planes_floats * sizeof(float);
+        s->p_planes = nullptr;
+        s->planes_floats = 0;
+      }
+      rc = dev_alloc(s, (void **)&s->p_planes, need * sizeof(float));
+      if (rc) return rc;
+      s->planes_floats = need;
+    }
+    P.out = s->p_planes;
+    P.pass_stride = n_floats;
+  }
   P.work_counter = s->p_counters + (s->launch_seq++ % kCounterRing);
   P.stats = s->p_stats;
+  P.lds_nodes_bytes = (uint32_t)(sizeof(MgpuNode) * s->nn);
+  P.lds_tris_bytes = (uint32_t)(sizeof(DTri) * s->nf);
+  if (!s->p_wave_log && getenv("MGPU_WAVE_LOG")) {
+    rc = dev_alloc(s, (void **)&s->p_wave_log, sizeof(unsigned long long) * 4 * 16384);
+    if (rc) return rc;
+  }
+  P.wave_log = s->p_wave_log;
   P.probe = s->probe_buf;
   P.probe_pixel = s->probe_pixel;
   P.probe_pass = s->probe_pass;
@@ -459,8 +513,18 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
     s->t_used += 2;
     HIP_TRY(hipEventRecord(tev0, st));
   }
-  launch_render(s->cap, dim3((unsigned)blocks), st, s->d, P);
-  HIP_TRY(hipGetLastError());
+  if (kern == 0) {
+    launch_render(s->cap, dim3((unsigned)blocks), st, s->d, P);
+    HIP_TRY(hipGetLastError());
+  } else {
+    HIP_TRY(launch_render_sm(s->cap, kern == 2, block, dim3((unsigned)blocks), st, shmem, s->d, P));
+    if (passes > 1) {
+      launch_accumulate(st, s->p_planes, n_floats, passes, n_floats, d_image, d_count);
+      HIP_TRY(hipGetLastError());
+    } else if (d_count) {
+      launch_accumulate(st, nullptr, 0, 1, n_floats, d_image, d_count); // single pass: only count[px] += 1
+    }
+  }
   if (tev1) HIP_TRY(hipEventRecord(tev1, st));
   if (stats) {
     HIP_TRY(hipEventRecord(s->ev1, st));
@@ -550,6 +614,22 @@ int mgpu_stats_read(MgpuScene *s, MgpuStats *out, int reset) {
   memset(out, 0, sizeof(*out));
   read_stats(w, out);
   if (reset) HIP_TRY(hipMemset(s->p_stats, 0, sizeof(w)));
+  return MGPU_OK;
+}
+
+int mgpu_debug_words(MgpuScene *s, unsigned long long *out32) {
+  if (!s || !out32) return fail(MGPU_ERR_INVALID, "NULL argument");
+  int rc = set_device(s);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out32, s->p_stats, sizeof(unsigned long long) * kStatWords, hipMemcpyDeviceToHost));
+  return MGPU_OK;
+}
+
+int mgpu_debug_wave_log(MgpuScene *s, unsigned long long *out, size_t n_waves) {
+  if (!s || !out || !s->p_wave_log || n_waves > 16384) return fail(MGPU_ERR_INVALID, "no wave log");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, s->p_wave_log, sizeof(unsigned long long) * 4 * n_waves, hipMemcpyDeviceToHost));
   return MGPU_OK;
 }
 

@@ -11,6 +11,10 @@
 
 #include "../../include/mgpu.h"
 
+#ifndef MGPU_SAMPLE_MATH
+#define MGPU_SAMPLE_MATH 1 // 0 = acos/sincos transcription, 1 = algebraically reduced evaluation (default)
+#endif
+
 namespace mgpu {
 
 constexpr uint32_t kNoMaterial = 0xFFFFFFFFu;
@@ -54,6 +58,9 @@ struct Hit {
 
 struct Counters {
   uint32_t rays, nodes, tris;
+#ifdef MGPU_UTIL
+  uint32_t node_steps, node_lanes, tri_steps, tri_lanes; // per-wave step counts (lane 0 meaningful) and active-lane sums
+#endif
 };
 
 struct V3 {
@@ -143,6 +150,12 @@ __device__ __forceinline__ void traverse(const DScene &sc, const Stack<CAP> &stk
   uint32_t nnodes = 0, ntris = 0;
   for (;;) {
     while (sp >= 0 && leaf_cnt == 0) {
+#ifdef MGPU_UTIL
+      { // one count per wave-level execution of this body: the first active lane books it
+        const unsigned long long act = __ballot(1);
+        if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)act) - 1)) c.node_steps += 1;
+      }
+#endif
       const uint32_t ni = stk.get(sp);
       --sp;
       ++nnodes;
@@ -179,6 +192,12 @@ __device__ __forceinline__ void traverse(const DScene &sc, const Stack<CAP> &stk
     if (leaf_cnt == 0) break;
     // TestLeafNode + TriangleIsect, bvh_accel.cc:595-697
     for (uint32_t i = 0; i < leaf_cnt; ++i) {
+#ifdef MGPU_UTIL
+      {
+        const unsigned long long act = __ballot(1);
+        if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)act) - 1)) c.tri_steps += 1;
+      }
+#endif
       const DTri *tp = sc.tris + (leaf_first + i);
       const double2 a0 = reinterpret_cast<const double2 *>(tp)[0]; // p0.x p0.y
       const double2 a1 = reinterpret_cast<const double2 *>(tp)[1]; // p0.z e1.x
@@ -250,12 +269,27 @@ __device__ __forceinline__ V3 sample_diffuse(V3 n, Rng &rng) {
   t.z = use_z ? 0.0 : (use_y ? n.x : n.y);
   t = normalized(t);
   const V3 b = normalized(cross(t, n));
-  const double theta = acos(sqrt(1.0 - rng_next(rng)));
-  const double phi = 6.283185307179586 * rng_next(rng); // 2.0 * M_PI, folded exactly
-  const double cos_theta = cos(theta);
-  const double sin_theta = sin(theta);
-  const V3 T = scale(scale(t, cos(phi)), sin_theta);
-  const V3 B = scale(scale(b, sin(phi)), sin_theta);
+  // theta = acos(sqrt(1 - u1)), phi = 2*pi*u2 (render.cc:325-326); only sin/cos of the two angles are ever used.
+  const double x = sqrt(1.0 - rng_next(rng)); // = cos(theta) before the reference's acos -> cos round trip
+  const double u2 = rng_next(rng);
+  double sin_theta, cos_theta, sin_phi, cos_phi;
+#if MGPU_SAMPLE_MATH == 0
+  // literal transcription: device acos / sincos of the same arguments (<= 1 ulp from glibc's results)
+  const double theta = acos(x);
+  const double phi = 6.283185307179586 * u2; // 2.0 * M_PI, folded exactly
+  sincos(theta, &sin_theta, &cos_theta);
+  sincos(phi, &sin_phi, &cos_phi);
+#else
+  // same quantities without the inverse-function round trip: cos(acos(x)) = x and sin(acos(x)) = sqrt(1 - x^2)
+  // (1 - x^2 with a single rounding), both within 1 ulp of the exact value the reference approximates to ~2 ulp;
+  // sin/cos(2*pi*u2) through sincospi of the exactly representable 2*u2 (the reference rounds 2*pi*u2 first:
+  // <= 1.5e-15 absolute difference).  See DESIGN.md "Numerics" for why this cannot move a pixel.
+  cos_theta = x;
+  sin_theta = sqrt(fma(-x, x, 1.0));
+  sincospi(2.0 * u2, &sin_phi, &cos_phi);
+#endif
+  const V3 T = scale(scale(t, cos_phi), sin_theta);
+  const V3 B = scale(scale(b, sin_phi), sin_theta);
   const V3 N = scale(n, cos_theta);
   return (T + B) + N;
 }

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(DScene sc, const MgpuRay *__re
   Stack<CAP> stk;
   stk.lds = &s_stack[wave][0][lane];
   stk.overflow = sc.stack_overflow ? sc.stack_overflow + gid * sc.overflow_cap : nullptr;
-  Counters c{0, 0, 0};
+  Counters c{};
   if (gid < n) {
     const MgpuRay *r = rays + gid;
     const V3 org = v3(r->org[0], r->org[1], r->org[2]);
@@ -106,8 +106,11 @@ __global__ __launch_bounds__(kBlock) void k_trace(DScene sc, const MgpuRay *__re
 // exactly Render() + AccumImage (main_sdl.cc:138-143); no atomics touch the image.
 enum : int { S_NEED_PIXEL = 0, S_NEED_PATH = 1, S_TRACE = 2 };
 
+#ifndef MGPU_RENDER_MIN_WAVES
+#define MGPU_RENDER_MIN_WAVES 1
+#endif
 template <int CAP>
-__global__ __launch_bounds__(kBlock) void k_render(DScene sc, RenderParams P) {
+__global__ __launch_bounds__(kBlock, MGPU_RENDER_MIN_WAVES) void k_render(DScene sc, RenderParams P) {
   __shared__ uint32_t s_stack[kBlock / 64][CAP][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t gid = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -133,8 +136,11 @@ __global__ __launch_bounds__(kBlock) void k_render(DScene sc, RenderParams P) {
   double thr0 = 1, thr1 = 1, thr2 = 1, rad0 = 0, rad1 = 0, rad2 = 0;
   int pathLength = 1;
   uint32_t last_mat = kNoMaterial; // Intersection::materialID as the reference would still hold it (stale on a miss)
-  Counters c{0, 0, 0};
+  Counters c{};
   uint32_t trace_calls = 0, paths = 0;
+#ifdef MGPU_UTIL
+  uint32_t u_outer = 0, u_trace = 0, u_shade = 0, u_gen = 0;
+#endif
   bool probe_on = false;
 
   for (;;) {
@@ -175,6 +181,10 @@ __global__ __launch_bounds__(kBlock) void k_render(DScene sc, RenderParams P) {
       }
     }
 
+#ifdef MGPU_UTIL
+    u_outer += 1;
+    u_gen += (uint32_t)__popcll(__ballot(state == S_NEED_PATH));
+#endif
     // ---- 2. start a new eye path (PathTrace prologue, render.cc:387-400) ----------------------------------------
     if (state == S_NEED_PATH) {
       const uint32_t j = ly;
@@ -206,6 +216,9 @@ __global__ __launch_bounds__(kBlock) void k_render(DScene sc, RenderParams P) {
     h.slot = kNoHit;
     h.t = kDblMax;
     h.u = h.v = 0.0;
+#ifdef MGPU_UTIL
+    u_trace += (uint32_t)__popcll(__ballot(state == S_TRACE));
+#endif
     if (state == S_TRACE) traverse<CAP>(sc, stk, org, dir, h, c);
 
     // ---- 4. the rest of one PathTrace loop iteration (render.cc:403-452) ----------------------------------------
@@ -321,7 +334,27 @@ __global__ __launch_bounds__(kBlock) void k_render(DScene sc, RenderParams P) {
     atomicAdd(&P.stats[kStatNodes], v2);
     atomicAdd(&P.stats[kStatTris], v3_);
     atomicAdd(&P.stats[kStatPaths], v4);
+#ifdef MGPU_UTIL
+    // lane 0 took part in every wave-level step it counted only while active itself, so steps are counted per lane and
+    // the wave-level step count is the maximum over lanes; sums of active lanes are exact.
+#endif
   }
+#ifdef MGPU_UTIL
+  {
+    unsigned long long a = c.node_steps, b = c.tri_steps;
+    for (int off = 32; off; off >>= 1) {
+      a += __shfl_down(a, off);
+      b += __shfl_down(b, off);
+    }
+    if (lane == 0) {
+      atomicAdd(&P.stats[kUtilNodeSteps], a);
+      atomicAdd(&P.stats[kUtilTriSteps], b);
+      atomicAdd(&P.stats[kUtilOuter], (unsigned long long)u_outer);
+      atomicAdd(&P.stats[kUtilTraceLanes], (unsigned long long)u_trace);
+      atomicAdd(&P.stats[kUtilGenLanes], (unsigned long long)u_gen);
+    }
+  }
+#endif
 }
 
 // =====================================================================================================================

@@ -9,10 +9,14 @@
 namespace mgpu {
 
 constexpr int kBlock = 256;      // 4 waves per workgroup
-constexpr int kChunkTiles = 2;   // 8x8-pixel tiles handed to a wave per global-counter fetch
+constexpr int kChunkTiles = 2;   // k_render v1: 8x8-pixel tiles handed to a wave per global-counter fetch
+constexpr int kChunkItems = 4;   // k_render_sm: (tile, pass) items of 64 eye paths per global-counter fetch
 
 // device-side statistics words (unsigned long long each)
-enum : int { kStatTraceCalls = 0, kStatRays = 1, kStatNodes = 2, kStatTris = 3, kStatPaths = 4, kStatWords = 8 };
+enum : int { kStatTraceCalls = 0, kStatRays = 1, kStatNodes = 2, kStatTris = 3, kStatPaths = 4,
+              // wave-level utilisation probes, filled only by -DMGPU_UTIL builds (scratch experiments)
+              kUtilNodeSteps = 8, kUtilNodeLanes = 9, kUtilTriSteps = 10, kUtilTriLanes = 11, kUtilOuter = 12,
+              kUtilTraceLanes = 13, kUtilShadeLanes = 14, kUtilGenLanes = 15, kStatWords = 32 };
 
 struct RenderParams {
   double frame[12]; // origin, corner, du, dv  (Camera::BuildCameraFrame, camera.cc:40-220)
@@ -26,10 +30,14 @@ struct RenderParams {
   const uint32_t *rng_states; // device, MGPU_RNG_TABLE layout, or null
   unsigned long long seed;
   uint32_t pass_base;
-  float *image;     // device, 3 * n_rows * (x1-x0)
+  float *image;     // device, 3 * n_rows * (x1-x0)  (k_render v1 writes the pass-ordered sum here itself)
   int32_t *count;   // device or null
+  float *out;       // k_render_sm: where per-pass radiance goes: pass planes (passes > 1) or the image (passes == 1)
+  size_t pass_stride; // floats between consecutive pass planes of `out` (0 when passes == 1)
   uint32_t *work_counter;        // device, zeroed before the launch
   unsigned long long *stats;     // device, kStatWords, accumulated
+  uint32_t lds_nodes_bytes, lds_tris_bytes; // k_render_sm<LDS_SCENE>: bytes of nodes / triangles staged into LDS
+  unsigned long long *wave_log;  // device or null: 4 words per wave (diagnostic builds only)
   double *probe;                 // device or null: kProbeStride doubles per PathTrace iteration of ONE path
   uint32_t probe_pixel, probe_pass; // full-frame pixel index and pass of the probed path
 };
@@ -40,5 +48,11 @@ void launch_trace(int cap, dim3 grid, hipStream_t s, const DScene &sc, const Mgp
                   MgpuIntersection *out, uint8_t *hit, unsigned long long *stats);
 void launch_render(int cap, dim3 grid, hipStream_t s, const DScene &sc, const RenderParams &p);
 int pick_stack_cap(int needed_entries);
+// wave-scheduled state-machine renderer (mgpu_render_sm.hip); shmem = stacks (+ scene when lds_scene)
+hipError_t launch_render_sm(int cap, bool lds_scene, int block, dim3 grid, hipStream_t s, size_t shmem, const DScene &sc,
+                            const RenderParams &p);
+void launch_accumulate(hipStream_t s, const float *planes, size_t plane_stride, int passes, size_t n_floats, float *image,
+                       int32_t *count);
+constexpr size_t kLdsBudget = 160 * 1024; // bytes of LDS per CU on gfx950
 
 } // namespace mgpu

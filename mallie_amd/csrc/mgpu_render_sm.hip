@@ -1,0 +1,539 @@
+// mgpu_render_sm.hip -- k_render_sm: the wave-scheduled ("state machine") persistent path tracer for gfx950.
+//
+// Same per-path arithmetic as PathTrace / BVHAccel::Traverse (see mgpu_device.hpp for the contract); what changes is
+// HOW a 64-lane wave walks through it.  Measured on the first kernel (k_render, mgpu_kernels.hip), a wave that runs
+// "trace every lane's ray to completion, then shade every lane" spends 40 node steps and 40 triangle steps per ray
+// batch where 5.5 and 7.7 would do (lane utilisation 14 % / 19 %): rays of very different length share a wave and
+// everybody waits for the longest.  Here every lane carries an explicit state
+//
+//     NODE  : pop one BVH node, slab-test it, push children / open a leaf       (bvh_accel.cc:805-834, 550-593)
+//     TRI   : test ONE triangle of the open leaf                                 (bvh_accel.cc:595-697)
+//     SHADE : finish the ray (plane, miss / bounce logic, sampling), start the next ray, path, pass or pixel
+//                                                                                (render.cc:381-456, 657-681)
+//
+// and each trip of the wave loop executes the ONE body that the most lanes are waiting for, with exactly those lanes
+// active.  A lane that finishes its ray early gets shaded and re-armed while its neighbours are still traversing, so
+// nobody waits for the longest ray any more; per-ray operation order (pop order, leaf order, RNG draws) is untouched,
+// hence results are bit-identical to k_render and to the oracle.
+//
+// Work distribution: the unit handed to a wave is one (8x8 pixel tile, pass) pair = 64 eye paths, drawn in chunks of
+// kChunkItems from one global counter; inside the wave, a lane whose path ends takes the next free path of the wave's
+// current item at its next SHADE step.  Items are this fine because path cost varies ~50x over the frame (sky: one
+// root-miss ray, Suzanne: five deep traversals): with a lane owning a pixel for all its passes the slowest wave ran
+// 2.2x longer than the median one and set the frame time.  The price is that a pixel's passes are no longer summed by
+// one lane, so every pass's float radiance goes to its own plane of `pass_buf` and k_accumulate adds the planes in
+// pass order afterwards -- the same float32 additions, in the same order, as Render() + AccumImage
+// (main_sdl.cc:138-143).  With passes == 1 the radiance is written straight into the image.
+//
+// Scene placement: with LDS_SCENE the whole BVH (64 B nodes + 80 B triangles) is staged once per workgroup into LDS
+// (cornellbox_suzanne: 13 KB + 78 KB) next to the traversal stacks; otherwise both are read from HBM through L1/L2.
+#include "mgpu_device.hpp"
+#include "mgpu_kernels.hpp"
+
+namespace mgpu {
+
+enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
+
+
+#ifndef MGPU_SHADE_MIN
+#define MGPU_SHADE_MIN 32
+#endif
+
+template <int CAP, bool LDS_SCENE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_render_sm(DScene sc, RenderParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int kWaves = BLOCK / 64;
+  uint32_t *s_stack = reinterpret_cast<uint32_t *>(smem); // [kWaves][CAP][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  Stack<CAP> stk;
+  stk.lds = s_stack + ((size_t)wave * CAP) * 64 + lane;
+  stk.overflow = sc.stack_overflow ? sc.stack_overflow + gid * sc.overflow_cap : nullptr;
+
+  // ---- optional: stage nodes + triangles into LDS -------------------------------------------------------------
+  const unsigned char *lds_nodes = smem + (size_t)kWaves * CAP * 64 * sizeof(uint32_t);
+  const unsigned char *lds_tris = lds_nodes + (size_t)P.lds_nodes_bytes;
+  if (LDS_SCENE) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(sc.nodes);
+    uint4 *dst = reinterpret_cast<uint4 *>(const_cast<unsigned char *>(lds_nodes));
+    const uint32_t n16 = P.lds_nodes_bytes >> 4;
+    for (uint32_t i = threadIdx.x; i < n16; i += BLOCK) dst[i] = src[i];
+    const uint4 *src2 = reinterpret_cast<const uint4 *>(sc.tris);
+    uint4 *dst2 = reinterpret_cast<uint4 *>(const_cast<unsigned char *>(lds_tris));
+    const uint32_t t16 = P.lds_tris_bytes >> 4;
+    for (uint32_t i = threadIdx.x; i < t16; i += BLOCK) dst2[i] = src2[i];
+    __syncthreads();
+  }
+
+  const int win_w = P.x1 - P.x0;
+  const uint32_t tiles_x = (uint32_t)(win_w + 7) >> 3;
+  const uint32_t tiles_y = (uint32_t)(P.n_rows + 7) >> 3;
+  const uint32_t total_tiles = tiles_x * tiles_y;
+
+  // wave-uniform work cursor: chunk of items [item_next, item_end), path cursor inside the current item
+  const uint32_t total_items = total_tiles * (uint32_t)P.passes;
+  uint32_t item_next = 0, item_end = 0, in_item = 64;
+  bool exhausted = false;
+
+  // ---- per-lane path state --------------------------------------------------------------------------------------
+  int st = ST_SHADE;       // everybody starts by asking for work
+  bool have_ray = false;   // a traversal result is waiting to be shaded
+  bool have_path = false;  // lane was handed a fresh (pixel, pass) it has not started yet
+  uint32_t lx = 0, ly = 0;
+  int pass = 0;
+  Rng rng{1, 0, 0, 0};
+  V3 org = v3(0, 0, 0), dir = v3(0, 0, 1);
+  double thr0 = 1, thr1 = 1, thr2 = 1, rad0 = 0, rad1 = 0, rad2 = 0;
+  int pathLength = 1;
+  uint32_t last_mat = kNoMaterial;
+  // ---- per-lane traversal state ---------------------------------------------------------------------------------
+  double ix = 0, iy = 0, iz = 0;
+  bool sx = false, sy = false, sz = false;
+  int sp = -1;
+  double bt = kDblMax, bu = 0, bv = 0;
+  uint32_t bslot = kNoHit;
+  uint32_t tri_cur = 0, tri_end = 0;
+  // ---- counters -------------------------------------------------------------------------------------------------
+  uint32_t n_rays = 0, n_nodes = 0, n_tris = 0, trace_calls = 0, paths = 0;
+  bool probe_on = false;
+#ifdef MGPU_UTIL
+  uint32_t u_node = 0, u_tri = 0, u_shade = 0, u_shade_lanes = 0;
+  unsigned long long cyc_node = 0, cyc_tri = 0, cyc_shade = 0, cyc_t0 = 0, cyc_s = 0;
+  unsigned long long cyc_sub[6] = {0, 0, 0, 0, 0, 0};
+#define MGPU_TICK() (cyc_t0 = clock64())
+#define MGPU_TOCK(acc) (acc += clock64() - cyc_t0)
+#else
+#define MGPU_TICK()
+#define MGPU_TOCK(acc)
+#endif
+
+#ifdef MGPU_UTIL
+  const unsigned long long cyc_loop0 = clock64();
+#endif
+  for (;;) {
+    const unsigned long long mN = __ballot(st == ST_NODE);
+    const unsigned long long mT = __ballot(st == ST_TRI);
+    const unsigned long long mS = __ballot(st == ST_SHADE);
+    const int cN = __popcll(mN), cT = __popcll(mT), cS = __popcll(mS);
+    if ((cN | cT | cS) == 0) break;
+
+    // Scheduling rule: SHADE is by far the most expensive body (fp64 sqrt/div/acos/sin/cos), so it runs only when at
+    // least MGPU_SHADE_MIN lanes wait for it or nothing else is runnable; otherwise the fuller of NODE / TRI runs.
+    const bool run_shade = (cS >= MGPU_SHADE_MIN) || (cN == 0 && cT == 0);
+    if (!run_shade && cN >= cT) {
+      // ================================ NODE step ================================
+      MGPU_TICK();
+      if (st == ST_NODE) {
+#ifdef MGPU_UTIL
+        if (lane == __ffsll((long long)mN) - 1) u_node++;
+#endif
+        const uint32_t ni = stk.get(sp);
+        --sp;
+        ++n_nodes;
+        double2 b0, b1, b2;
+        int4 meta;
+        if (LDS_SCENE) {
+          const unsigned char *nd = lds_nodes + (size_t)ni * 64;
+          b0 = *reinterpret_cast<const double2 *>(nd);
+          b1 = *reinterpret_cast<const double2 *>(nd + 16);
+          b2 = *reinterpret_cast<const double2 *>(nd + 32);
+          meta = *reinterpret_cast<const int4 *>(nd + 48);
+        } else {
+          const MgpuNode *nd = sc.nodes + ni;
+          b0 = *reinterpret_cast<const double2 *>(&nd->bmin[0]);
+          b1 = *reinterpret_cast<const double2 *>(&nd->bmin[2]);
+          b2 = *reinterpret_cast<const double2 *>(&nd->bmax[1]);
+          meta = *reinterpret_cast<const int4 *>(&nd->flag);
+        }
+        // IntersectRayAABB, bvh_accel.cc:550-593
+        const double nx = sx ? b1.y : b0.x, fx = sx ? b0.x : b1.y;
+        const double ny = sy ? b2.x : b0.y, fy = sy ? b0.y : b2.x;
+        const double nz = sz ? b2.y : b1.x, fz = sz ? b1.x : b2.y;
+        const double tmin_x = (nx - org.x) * ix, tmax_x = (fx - org.x) * ix;
+        const double tmin_y = (ny - org.y) * iy, tmax_y = (fy - org.y) * iy;
+        double tmin = (tmin_x > tmin_y) ? tmin_x : tmin_y;
+        double tmax = (tmax_x < tmax_y) ? tmax_x : tmax_y;
+        const double tmin_z = (nz - org.z) * iz, tmax_z = (fz - org.z) * iz;
+        tmin = (tmin > tmin_z) ? tmin : tmin_z;
+        tmax = (tmax < tmax_z) ? tmax : tmax_z;
+        const bool hit = (tmax > 0.0) && (tmin <= tmax) && (tmin <= bt);
+        if (hit) {
+          if (meta.x == 0) {
+            const bool nearIsSecond = (meta.y == 0) ? sx : ((meta.y == 1) ? sy : sz); // dirSign[node.axis]
+            const uint32_t c0 = (uint32_t)meta.z, c1 = (uint32_t)meta.w;
+            stk.put(sp + 1, nearIsSecond ? c0 : c1); // far
+            stk.put(sp + 2, nearIsSecond ? c1 : c0); // near: popped first
+            sp += 2;
+          } else if (meta.z != 0) {
+            tri_cur = (uint32_t)meta.w;
+            tri_end = (uint32_t)meta.w + (uint32_t)meta.z;
+            st = ST_TRI;
+          }
+        }
+        if (st == ST_NODE && sp < 0) st = ST_SHADE;
+      }
+      MGPU_TOCK(cyc_node);
+    } else if (!run_shade) {
+      // ================================ TRI step =================================
+      MGPU_TICK();
+      if (st == ST_TRI) {
+#ifdef MGPU_UTIL
+        if (lane == __ffsll((long long)mT) - 1) u_tri++;
+#endif
+        double2 a0, a1, a2, a3;
+        double e2z;
+        if (LDS_SCENE) {
+          const unsigned char *tp = lds_tris + (size_t)tri_cur * 80;
+          a0 = *reinterpret_cast<const double2 *>(tp);
+          a1 = *reinterpret_cast<const double2 *>(tp + 16);
+          a2 = *reinterpret_cast<const double2 *>(tp + 32);
+          a3 = *reinterpret_cast<const double2 *>(tp + 48);
+          e2z = *reinterpret_cast<const double *>(tp + 64);
+        } else {
+          const DTri *tp = sc.tris + tri_cur;
+          a0 = reinterpret_cast<const double2 *>(tp)[0];
+          a1 = reinterpret_cast<const double2 *>(tp)[1];
+          a2 = reinterpret_cast<const double2 *>(tp)[2];
+          a3 = reinterpret_cast<const double2 *>(tp)[3];
+          e2z = tp->e2[2];
+        }
+        ++n_tris;
+        // TriangleIsect, bvh_accel.cc:595-638
+        const V3 p0 = v3(a0.x, a0.y, a1.x), e1 = v3(a1.y, a2.x, a2.y), e2 = v3(a3.x, a3.y, e2z);
+        const V3 p = cross(dir, e2);
+        const double det = dot(e1, p);
+        if (!(fabs(det) < kDblEps1024)) {
+          const double invDet = 1.0 / det;
+          const V3 s = org - p0;
+          const V3 q = cross(s, e1);
+          const double u = dot(s, p) * invDet;
+          const double v = dot(q, dir) * invDet;
+          const double t = dot(e2, q) * invDet;
+          const bool rej = (u < 0.0 || u > 1.0) || (v < 0.0 || u + v > 1.0) || (t < 0.0 || t > bt);
+          if (!rej) {
+            bt = t;
+            bu = u;
+            bv = v;
+            bslot = tri_cur;
+          }
+        }
+        ++tri_cur;
+        if (tri_cur == tri_end) st = (sp < 0) ? ST_SHADE : ST_NODE;
+      }
+      MGPU_TOCK(cyc_tri);
+    } else {
+      MGPU_TICK();
+      // ================================ SHADE step ===============================
+      // Three parts: (1) lanes in SHADE finish their ray; (2) ALL lanes of the wave run the pixel hand-out so the
+      // work cursor stays wave-uniform; (3) lanes in SHADE start their next path / arm their next traversal.
+      const bool shade_lane = (st == ST_SHADE);
+      bool path_done = false, want_pixel = false;
+      if (shade_lane) {
+#ifdef MGPU_UTIL
+        if (lane == __ffsll((long long)mS) - 1) { u_shade++; u_shade_lanes += (uint32_t)cS; }
+#endif
+#ifdef MGPU_UTIL
+        cyc_s = clock64();
+#endif
+        path_done = !have_ray; // a lane without a ray is between paths
+        if (have_ray) {
+          // ---- the rest of one PathTrace loop iteration (render.cc:403-452) ----
+          bool hit = bt < kDblMax; // bvh_accel.cc:838
+          double t = bt;
+          V3 n = v3(0, 0, 0);
+          if (bslot != kNoHit) last_mat = sc.tris[bslot].mat; // written by TestLeafNode on every accepted triangle
+          if (hit) {
+            if (sc.has_fv_normals) { // barycentric lerp, not renormalised (bvh_accel.cc:745-748)
+              const double *nn = sc.slot_normal + 9 * (size_t)bslot;
+              const double w = 1.0 - bu - bv;
+              n.x = w * nn[0] + bu * nn[3] + bv * nn[6];
+              n.y = w * nn[1] + bu * nn[4] + bv * nn[7];
+              n.z = w * nn[2] + bu * nn[5] + bv * nn[8];
+            } else {
+              const double *gn = sc.slot_normal + 3 * (size_t)bslot;
+              n = v3(gn[0], gn[1], gn[2]);
+            }
+          }
+          if (P.has_plane && plane_hit(P.plane, org, dir, t, n)) {
+            hit = true;
+            last_mat = kNoMaterial; // prim-plane.cc:34
+          }
+          if (P.probe && probe_on) {
+            double *rec = P.probe + (size_t)(pathLength - 1) * kProbeStride;
+            rec[0] = org.x; rec[1] = org.y; rec[2] = org.z; rec[3] = dir.x; rec[4] = dir.y; rec[5] = dir.z;
+            rec[6] = t; rec[7] = hit ? 1.0 : 0.0; rec[8] = (bt < kDblMax && t == bt) ? (double)bslot : -1.0;
+            rec[9] = n.x; rec[10] = n.y; rec[11] = n.z; rec[12] = (double)last_mat; rec[13] = (double)pathLength;
+            rec[14] = thr0; rec[15] = rad0;
+          }
+#ifdef MGPU_UTIL
+          cyc_sub[0] += clock64() - cyc_s; cyc_s = clock64();
+#endif
+          if (!hit) {
+            path_done = true;
+            if (pathLength < 2) {
+              trace_calls += 1; // eye ray -> background: radiance stays 0 (render.cc:409-412)
+            } else {
+              // First miss of a path that has bounced: the reference iterates on to kMaxPathLength with the stale
+              // intersection record; every one of those rays starts ~1e308 away and misses, adds
+              // throughput*0.5/length and re-applies the stale material.  Their RNG draws cannot reach
+              // this pixel's value, so the tail is evaluated in closed loop: same adds, same multiplies, same order.
+              trace_calls += (uint32_t)P.maxPathLength;
+              double d0 = 0.5, d1 = 0.5, d2 = 0.5; // Material().diffuse default (material.h:12-15)
+              const bool mul = last_mat != kNoMaterial;
+              if (mul && (size_t)(int)last_mat < (size_t)sc.nm) {
+                d0 = sc.mat_diffuse[3 * (size_t)last_mat + 0];
+                d1 = sc.mat_diffuse[3 * (size_t)last_mat + 1];
+                d2 = sc.mat_diffuse[3 * (size_t)last_mat + 2];
+              }
+              if (thr0 == thr1 && thr1 == thr2 && rad0 == rad1 && rad1 == rad2 && d0 == d1 && d1 == d2) {
+                // grey path (every material the reference can load from .obj/.eson is grey): the three channels
+                // perform identical operations on identical values, so evaluate one and copy -- same bits, 1/3 of the
+                // fp64 divisions
+                for (int L = pathLength;; ++L) {
+                  rad0 += thr0 * 0.5 / (double)(unsigned)L;
+                  if (L >= P.maxPathLength) break;
+                  if (mul) thr0 *= d0;
+                }
+                rad1 = rad2 = rad0;
+                thr1 = thr2 = thr0;
+              } else {
+                for (int L = pathLength;; ++L) {
+                  const double dl = (double)(unsigned)L;
+                  rad0 += thr0 * 0.5 / dl;
+                  rad1 += thr1 * 0.5 / dl;
+                  rad2 += thr2 * 0.5 / dl;
+                  if (L >= P.maxPathLength) break;
+                  if (mul) { thr0 *= d0; thr1 *= d1; thr2 *= d2; }
+                }
+              }
+            }
+          } else if (pathLength >= P.maxPathLength) {
+            path_done = true;
+            trace_calls += (uint32_t)P.maxPathLength;
+          } else {
+            const V3 hitP = org + scale(dir, t);
+            (void)rng_next(rng); // `double r = randomreal();` drawn and never used (render.cc:430)
+            const double ndoti = dot(n, neg(dir));
+            if (ndoti < 0.0) n = neg(n);
+            const V3 sd = sample_diffuse(n, rng);
+            if (last_mat != kNoMaterial) { // Scene::GetMaterial, scene.h:58-65
+              if ((size_t)(int)last_mat < (size_t)sc.nm) {
+                thr0 *= sc.mat_diffuse[3 * (size_t)last_mat + 0];
+                thr1 *= sc.mat_diffuse[3 * (size_t)last_mat + 1];
+                thr2 *= sc.mat_diffuse[3 * (size_t)last_mat + 2];
+              } else {
+                thr0 *= 0.5; thr1 *= 0.5; thr2 *= 0.5;
+              }
+            }
+            org = hitP + scale(sd, 1.0e-3);
+            dir = sd;
+            ++pathLength;
+          }
+          if (path_done) {
+            // image[...] = radiance (double -> float, render.cc:673-675); passes are summed later, in order
+            float *dst = P.out + (size_t)pass * P.pass_stride + 3 * ((size_t)ly * (size_t)win_w + lx);
+            dst[0] = (float)rad0;
+            dst[1] = (float)rad1;
+            dst[2] = (float)rad2;
+          }
+        }
+        have_ray = false;
+        want_pixel = path_done;
+      }
+
+#ifdef MGPU_UTIL
+      cyc_sub[2] += clock64() - cyc_s; cyc_s = clock64();
+#endif
+      // ---- (2) path hand-out, executed by the whole wave (cursor variables are wave-uniform) ----
+      for (;;) {
+        const unsigned long long want = __ballot(want_pixel);
+        if (!want || exhausted) break;
+        if (in_item >= 64) { // current item used up: take the next one, refilling the chunk when it is empty
+          if (item_next >= item_end) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(P.work_counter, (uint32_t)kChunkItems);
+            base = __shfl(base, 0);
+            item_next = base;
+            item_end = min(base + (uint32_t)kChunkItems, total_items);
+            if (base >= total_items) { exhausted = true; item_end = item_next = total_items; break; }
+          }
+          in_item = 0;
+        }
+        if (want_pixel) {
+          const uint32_t rank = __popcll(want & ((1ull << lane) - 1ull));
+          const uint32_t slot = in_item + rank;
+          if (slot < 64) {
+            const uint32_t tile = item_next / (uint32_t)P.passes; // tile-major: a tile's passes are consecutive items
+            const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+            const uint32_t x = tx * 8 + (slot & 7), y = ty * 8 + (slot >> 3);
+            if (x < (uint32_t)win_w && y < (uint32_t)P.n_rows) { // slots of an edge tile outside the window are skipped
+              lx = x; ly = y;
+              pass = (int)(item_next % (uint32_t)P.passes);
+              have_path = true;
+              want_pixel = false;
+            }
+          }
+        }
+        in_item += (uint32_t)__popcll(want);
+        if (in_item >= 64) { in_item = 64; ++item_next; }
+      }
+
+      // ---- (3) next path / next traversal ----
+      if (shade_lane) {
+        if (path_done && have_path) {
+          have_path = false;
+          // start a new eye path (PathTrace prologue, render.cc:387-400)
+          const uint32_t j = ly;
+          const int gy = P.y_first + (int)(j / (uint32_t)P.strip_h) * P.y_period + (int)(j % (uint32_t)P.strip_h);
+          const int gx = P.x0 + (int)lx;
+          const uint32_t gpix = (uint32_t)gy * (uint32_t)P.W + (uint32_t)gx;
+          uint32_t s4[4];
+          if (P.rng_mode == MGPU_RNG_TABLE) {
+            const uint4 q = reinterpret_cast<const uint4 *>(P.rng_states)[(size_t)pass * P.W * P.H + gpix];
+            s4[0] = q.x; s4[1] = q.y; s4[2] = q.z; s4[3] = q.w;
+          } else {
+            hash_state(P.seed, P.pass_base + (uint32_t)pass, gpix, s4);
+          }
+          rng = Rng{s4[0], s4[1], s4[2], s4[3]};
+          probe_on = P.probe && gpix == P.probe_pixel && (uint32_t)pass == P.probe_pass;
+          const float ju = (float)(rng_next(rng) - 0.5);
+          const float jv = (float)(rng_next(rng) - 0.5);
+          org = v3(P.frame[0], P.frame[1], P.frame[2]);
+          dir = camera_dir(P.frame, (double)((float)gx + ju), (double)((float)gy + jv));
+          thr0 = thr1 = thr2 = 1.0;
+          rad0 = rad1 = rad2 = 0.0;
+          pathLength = 1;
+          ++paths;
+          path_done = false;
+        }
+        if (path_done) {
+          st = ST_IDLE; // the work counter is exhausted: this lane is finished
+        } else {
+#ifdef MGPU_UTIL
+          cyc_sub[4] += clock64() - cyc_s; cyc_s = clock64();
+#endif
+          // arm the traversal of (org, dir): BVHAccel::Traverse prologue, bvh_accel.cc:774-802
+          sx = dir.x < 0.0; sy = dir.y < 0.0; sz = dir.z < 0.0;
+          ix = 1.0 / dir.x; iy = 1.0 / dir.y; iz = 1.0 / dir.z; // no zero guard, as the reference
+          bt = kDblMax; bu = 0.0; bv = 0.0; bslot = kNoHit;
+          sp = 0;
+          stk.put(0, 0u);
+          have_ray = true;
+          ++n_rays;
+          st = ST_NODE;
+        }
+      }
+#ifdef MGPU_UTIL
+      cyc_sub[5] += clock64() - cyc_s;
+#endif
+      MGPU_TOCK(cyc_shade);
+    }
+  }
+
+  // ---- counters: one atomic per wave and word -----------------------------------------------------------------
+  unsigned long long v0 = trace_calls, v1 = n_rays, v2 = n_nodes, v3_ = n_tris, v4 = paths;
+  for (int off = 32; off; off >>= 1) {
+    v0 += __shfl_down(v0, off);
+    v1 += __shfl_down(v1, off);
+    v2 += __shfl_down(v2, off);
+    v3_ += __shfl_down(v3_, off);
+    v4 += __shfl_down(v4, off);
+  }
+  if (lane == 0 && P.stats) {
+    atomicAdd(&P.stats[kStatTraceCalls], v0);
+    atomicAdd(&P.stats[kStatRays], v1);
+    atomicAdd(&P.stats[kStatNodes], v2);
+    atomicAdd(&P.stats[kStatTris], v3_);
+    atomicAdd(&P.stats[kStatPaths], v4);
+  }
+#ifdef MGPU_UTIL
+  {
+    unsigned long long a = u_node, b = u_tri, cc = u_shade, d = u_shade_lanes;
+    for (int off = 32; off; off >>= 1) {
+      a += __shfl_down(a, off);
+      b += __shfl_down(b, off);
+      cc += __shfl_down(cc, off);
+      d += __shfl_down(d, off);
+    }
+    if (lane == 0) {
+      atomicAdd(&P.stats[kUtilNodeSteps], a);
+      atomicAdd(&P.stats[kUtilTriSteps], b);
+      atomicAdd(&P.stats[kUtilOuter], cc);
+      atomicAdd(&P.stats[kUtilShadeLanes], d);
+      atomicAdd(&P.stats[16], cyc_node);
+      atomicAdd(&P.stats[17], cyc_tri);
+      atomicAdd(&P.stats[18], cyc_shade);
+      for (int k = 0; k < 6; ++k) atomicAdd(&P.stats[19 + k], cyc_sub[k]);
+      const unsigned long long loop_cyc = clock64() - cyc_loop0;
+      atomicAdd(&P.stats[25], loop_cyc);
+      atomicMax(&P.stats[26], loop_cyc);
+      atomicAdd(&P.stats[27], 1ull);
+      if (P.wave_log) {
+        const size_t wid = (size_t)blockIdx.x * kWaves + wave;
+        if (wid < 16384) {
+          unsigned xcc;
+          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+          P.wave_log[4 * wid + 0] = cyc_loop0;
+          P.wave_log[4 * wid + 1] = clock64();
+          P.wave_log[4 * wid + 2] = v1;
+          P.wave_log[4 * wid + 3] = xcc & 0xf;
+        }
+      }
+    }
+  }
+#endif
+}
+
+// =====================================================================================================================
+// k_accumulate: image[px] = pass 0 + pass 1 + ... in float32, in pass order (AccumImage, main_sdl.cc:138-143); count += passes
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void k_accumulate(const float *__restrict__ planes, size_t plane_stride, int passes,
+                                                     size_t n_floats, float *__restrict__ image,
+                                                     int32_t *__restrict__ count) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (planes && i < n_floats) { // planes == null: single pass already written in place, only count is due
+    float acc = 0.f;
+    for (int p = 0; p < passes; ++p) acc += planes[(size_t)p * plane_stride + i];
+    image[i] = acc;
+  }
+  if (count && i < n_floats / 3) count[i] += passes;
+}
+
+void launch_accumulate(hipStream_t s, const float *planes, size_t plane_stride, int passes, size_t n_floats, float *image,
+                       int32_t *count) {
+  const unsigned blocks = (unsigned)((n_floats + 255) / 256);
+  hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, s, planes, plane_stride, passes, n_floats, image, count);
+}
+
+// =====================================================================================================================
+// launcher
+// =====================================================================================================================
+template <int CAP, bool LDS, int BLOCK>
+static hipError_t launch_one(dim3 grid, hipStream_t s, size_t shmem, const DScene &sc, const RenderParams &p) {
+  auto kern = k_render_sm<CAP, LDS, BLOCK>;
+  if (shmem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)shmem);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(BLOCK), shmem, s, sc, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_render_sm(int cap, bool lds_scene, int block, dim3 grid, hipStream_t s, size_t shmem, const DScene &sc,
+                            const RenderParams &p) {
+#define MGPU_CASE(C)                                                                     \
+  if (cap == C) {                                                                        \
+    if (lds_scene && block == 1024) return launch_one<C, true, 1024>(grid, s, shmem, sc, p);  \
+    if (lds_scene && block == 512) return launch_one<C, true, 512>(grid, s, shmem, sc, p);    \
+    if (!lds_scene && block == 256) return launch_one<C, false, 256>(grid, s, shmem, sc, p);  \
+    if (!lds_scene && block == 512) return launch_one<C, false, 512>(grid, s, shmem, sc, p);  \
+  }
+  MGPU_CASE(16)
+  MGPU_CASE(24)
+  MGPU_CASE(32)
+#undef MGPU_CASE
+  return hipErrorInvalidConfiguration;
+}
+
+} // namespace mgpu

@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libmallie_mgpu.so")
+_LIB_PATH = os.environ.get("MALLIE_MGPU_LIB") or os.path.join(_HERE, "libmallie_mgpu.so")  # override: A/B builds
 
 RNG_STREAM, RNG_TABLE, RNG_HASH = 0, 1, 2
 
@@ -83,6 +83,10 @@ def load_library():
     L.mgpu_hash_state.argtypes = [u64, u32, u32, vp]
     L.mgpu_stats_read.argtypes = [vp, vp, i32]
     L.mgpu_stats_read.restype = i32
+    L.mgpu_debug_words.argtypes = [vp, vp]
+    L.mgpu_debug_words.restype = i32
+    L.mgpu_debug_wave_log.argtypes = [vp, vp, sz]
+    L.mgpu_debug_wave_log.restype = i32
     L.mgpu_timing_enable.argtypes = [vp, i32]
     L.mgpu_timing_enable.restype = i32
     L.mgpu_timing_read.argtypes = [vp, C.POINTER(dbl), C.POINTER(i32)]
@@ -237,6 +241,16 @@ class Scene:
         st = Stats()
         _check(load_library().mgpu_stats_read(self.h, C.byref(st), 1 if reset else 0), "mgpu_stats_read")
         return st.as_dict()
+
+    def debug_words(self):
+        w = np.zeros(32, "<u8")
+        _check(load_library().mgpu_debug_words(self.h, _p(w)), "mgpu_debug_words")
+        return w
+
+    def wave_log(self, n_waves):
+        w = np.zeros((n_waves, 4), "<u8")
+        _check(load_library().mgpu_debug_wave_log(self.h, _p(w), n_waves), "mgpu_debug_wave_log")
+        return w
 
     def timing_enable(self, on=True):
         _check(load_library().mgpu_timing_enable(self.h, 1 if on else 0), "mgpu_timing_enable")

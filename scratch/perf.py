@@ -1,0 +1,50 @@
+import sys, os, time, json
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np, torch
+import mallie_amd as M
+g = np.load("tests/golden/cornell_obj.npz")
+sc = M.Scene(g["verts"].astype(np.float64), g["faces"], g["matIDs"], g["normals"], None)
+W, H, mpl, spp = 1920, 1080, 5, 16
+if len(sys.argv) > 1: mpl = int(sys.argv[1])
+frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+buf = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+plane = sc.plane()
+ts = []
+for i in range(6):
+    st = sc.render_strips_device(frame, W, H, buf.data_ptr(), H, maxPathLength=mpl, passes=spp, plane=plane, seed=1, want_stats=True)
+    ts.append(st["kernel_ms"])
+ms = float(np.median(ts[1:]))
+print("%s blocks/cu=%s mpl=%d: kernel %.2f ms  %.0f Mrays/s  (rays %d nodes/ray %.2f tris/ray %.2f) checksum %.6f" % (
+    os.environ.get("MALLIE_MGPU_LIB", "default"), os.environ.get("MGPU_RENDER_BLOCKS_PER_CU", "2"), mpl, ms, st["real_rays"] / ms / 1e3, st["real_rays"],
+    st["nodes"] / st["real_rays"], st["tris"] / st["real_rays"], float(buf.double().sum().item())))
+if os.environ.get("UTIL"):
+    sc.render_strips_device(frame, W, H, buf.data_ptr(), H, maxPathLength=mpl, passes=spp, plane=plane, seed=1, want_stats=True)
+    w = sc.debug_words()
+    ns, nl, ts_, tl, outer, trl, shl, genl = [int(x) for x in w[8:16]]
+    print("  wave-level: outer iters %d (ideal %d, trace-lane util %.3f), node steps %d (lane util %.3f), tri steps %d (lane util %.3f), new paths/iter %.1f" % (
+        outer, st["real_rays"] // 64, trl / max(1, 64 * outer), ns, st["nodes"] / max(1, 64 * ns), ts_, st["tris"] / max(1, 64 * ts_), genl / max(1, outer)))
+    print("  per outer iter: node steps %.2f (ideal %.2f)  tri steps %.2f (ideal %.2f)" % (ns / outer, st["nodes"] / 64 / outer, ts_ / outer, st["tris"] / 64 / outer))
+    cn, ct, cs = [int(x) for x in w[16:19]]
+    if cn:
+        tot = cn + ct + cs
+        print("  cycle share: node %.1f%% (%.0f cyc/step)  tri %.1f%% (%.0f cyc/step)  shade %.1f%% (%.0f cyc/step)  [wave wall-clock cycles incl. interleaving]" % (
+            100 * cn / tot, cn / max(1, ns), 100 * ct / tot, ct / max(1, ts_), 100 * cs / tot, cs / max(1, outer)))
+    sub = [int(x) for x in w[19:25]]
+    if sum(sub):
+        names = ["1a normals+plane", "(unused)", "1b miss/bounce/accum", "2 hand-out", "3a new path", "3b arm"]
+        print("  SHADE sub-parts (lane-0 samples): " + ", ".join("%s %.1f%%" % (n, 100.0 * v / sum(sub)) for n, v in zip(names, sub)))
+    if int(w[27]):
+        print("  per-wave loop cycles: avg %.1fM  max %.1fM  waves %d ; sum of body cycles per wave %.1fM" % (int(w[25]) / int(w[27]) / 1e6, int(w[26]) / 1e6, int(w[27]), (cn + ct + cs) / int(w[27]) / 1e6))
+    if os.environ.get("MGPU_WAVE_LOG"):
+        nw = int(w[27])
+        wl = sc.wave_log(nw).astype(np.float64)
+        t0 = wl[:, 0].min()
+        start, end, rays, xcc = (wl[:, 0] - t0) / 1e6, (wl[:, 1] - t0) / 1e6, wl[:, 2], wl[:, 3]
+        dur = end - start
+        print("  waves %d: start min/max %.2f/%.2f M, end pctl 10/50/90/100: %s M, dur pctl: %s" % (nw, start.min(), start.max(), np.percentile(end, [10, 50, 90, 100]).round(1), np.percentile(dur, [10, 50, 90, 100]).round(1)))
+        print("  rays per wave pctl 0/10/50/90/100: %s ; corr(rays,dur)=%.3f" % (np.percentile(rays, [0, 10, 50, 90, 100]).round(0), np.corrcoef(rays, dur)[0, 1]))
+        for x in range(8):
+            m = xcc == x
+            if m.any(): print("   xcc %d: waves %d end median %.1f max %.1f rays/wave %.0f" % (x, m.sum(), np.median(end[m]), end[m].max(), rays[m].mean()))
+        # per block
+        bl = np.arange(nw) // (nw // 256 if nw >= 256 else 1)
