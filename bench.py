@@ -158,10 +158,11 @@ def main():
                        "mtrace_calls_per_s": round(trace_calls / elapsed / 1e6, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "k_render", "kernel_avg_ms": round(kernel_avg_ms, 3),
+                         "kernel": "k_render_sm", "kernel_avg_ms": round(kernel_avg_ms, 3),
                          "algorithmic_bytes_per_launch": int(alg_bytes_launch),
-                         "note": "algorithmic bytes = nodes*64 + tris*76 + rays*80 (SURVEY 8(d)); the 84 KB scene is "
-                                 "cache-resident, so HBM traffic proper is ~the framebuffer (see profiles/)"},
+                         "note": "algorithmic bytes = nodes*64 + tris*76 + rays*80 (SURVEY 8(d)). The 92 KB BVH of this "
+                                 "scene is staged in LDS, so these bytes are served on-chip and real HBM traffic is the "
+                                 "per-pass radiance planes + framebuffer (see DESIGN.md and profiles/)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frame, plane, mpl)

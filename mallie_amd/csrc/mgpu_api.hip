@@ -518,16 +518,20 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
     HIP_TRY(hipGetLastError());
   } else {
     HIP_TRY(launch_render_sm(s->cap, kern == 2, block, dim3((unsigned)blocks), st, shmem, s->d, P));
+  }
+  // kernel_ms / the timing ring measure the dominant kernel alone (k_render or k_render_sm), not the pass summation
+  if (tev1) HIP_TRY(hipEventRecord(tev1, st));
+  if (stats) HIP_TRY(hipEventRecord(s->ev1, st));
+  if (kern != 0) {
     if (passes > 1) {
       launch_accumulate(st, s->p_planes, n_floats, passes, n_floats, d_image, d_count);
       HIP_TRY(hipGetLastError());
     } else if (d_count) {
       launch_accumulate(st, nullptr, 0, 1, n_floats, d_image, d_count); // single pass: only count[px] += 1
+      HIP_TRY(hipGetLastError());
     }
   }
-  if (tev1) HIP_TRY(hipEventRecord(tev1, st));
   if (stats) {
-    HIP_TRY(hipEventRecord(s->ev1, st));
     unsigned long long w[kStatWords];
     HIP_TRY(hipMemcpyAsync(w, s->p_stats, sizeof(w), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -26,12 +26,18 @@ class FrameRenderer:
     """
 
     def __init__(self, scene, frame, W, H, maxPathLength, passes, plane=None, seed=1, rank=0, world=1, device=None,
-                 strip_h=STRIP_H):
+                 strip_h=STRIP_H, render_local=None):
+        """render_local(rows, out, pass_base): optional replacement for the device renderer -- fills out[:len(rows)]
+        (float32, len(rows) x W x 3) for the given frame rows.  Used by the CPU (gloo) tests of the partition/gather
+        logic, where `device` is torch.device("cpu"); the product path leaves it None and renders through the C ABI."""
+        self.render_local = render_local
         self.scene, self.frame = scene, np.ascontiguousarray(frame, "<f8")
         self.W, self.H, self.mpl, self.passes = W, H, maxPathLength, passes
         self.plane = None if plane is None else np.ascontiguousarray(plane, "<f4")
         self.seed, self.rank, self.world, self.strip_h = seed, rank, world, strip_h
-        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = device
         self.rows = strip_rows(H, world, rank, strip_h)
         self.n_rows = len(self.rows)
         counts = [len(strip_rows(H, world, r, strip_h)) for r in range(world)]
@@ -51,8 +57,11 @@ class FrameRenderer:
 
     def render(self, pass_base=0):
         import torch.distributed as dist
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        if self.n_rows:
+        if self.render_local is not None:
+            if self.n_rows:
+                self.render_local(self.rows, self.local, pass_base)
+        elif self.n_rows:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
             self.scene.render_strips_device(self.frame, self.W, self.H, self.local.data_ptr(), self.n_rows,
                                             y_first=self.rank * self.strip_h, strip_h=self.strip_h,
                                             y_period=self.strip_h * self.world, maxPathLength=self.mpl,

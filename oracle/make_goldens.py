@@ -38,9 +38,10 @@ HIT_DT = np.dtype([("hit", "<u4"), ("faceID", "<u4"), ("materialID", "<u4"), ("f
 assert NODE_DT.itemsize == 64 and HIT_DT.itemsize == 136
 
 
-def run(args, stdin=None):
+def run(args, stdin=None, cwd=None):
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    r = subprocess.run([DRIVER] + [str(a) for a in args], cwd=REF, env=env, input=stdin, capture_output=True, text=True)
+    r = subprocess.run([DRIVER] + [str(a) for a in args], cwd=cwd or REF, env=env, input=stdin, capture_output=True,
+                       text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout[-2000:] + r.stderr[-2000:])
         raise SystemExit("ref_driver failed: %r" % (args,))
@@ -67,9 +68,9 @@ def read_mesh(prefix):
                 has_uvs=np.uint8(hu), nodes=nodes, indices=idx)
 
 
-def gen_mesh(tmp, kind, fname, name):
+def gen_mesh(tmp, kind, fname, name, cwd=None):
     prefix = os.path.join(tmp, name)
-    run(["mesh", kind, fname, 1.0, prefix])
+    run(["mesh", kind, fname, 1.0, prefix], cwd=cwd)
     m = read_mesh(prefix)
     # uvs of these scenes are all-zero placeholders (mesh_loader.cc:64-65); store only the flag when so.
     if m["uvs"].size and not m["uvs"].any():
@@ -196,6 +197,10 @@ def main():
         mc = gen_mesh(tmp, "obj", "cornellbox_suzanne.obj", "cornell_obj")
         gen_mesh(tmp, "eson", "cornellbox_suzanne.eson", "cornell_eson")
         mt = gen_mesh(tmp, "obj", "teapot.obj", "teapot_obj")
+        # authored .obj inputs (tests/golden/objs/) through the reference loader: loader-behaviour goldens for mesh_io.cc
+        objs = os.path.join(OUT, "objs")
+        gen_mesh(tmp, "obj", "quirks.obj", "objload_quirks", cwd=objs)
+        gen_mesh(tmp, "obj", "nomtl.obj", "objload_nomtl", cwd=objs)
         rng = np.random.default_rng(20260929)
         gen_trace(tmp, "obj", "cornellbox_suzanne.obj", "trace_cornell_obj",
                   make_rays(rng, mc, 1500, 1500, 700, 300, np.array([0.0, 0.0, 20.0])))

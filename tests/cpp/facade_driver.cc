@@ -1,0 +1,100 @@
+// tests/cpp/facade_driver.cc -- a Mallie-style driver written ONLY against the reference's header names
+// ("scene.h", "render.h", "camera.h": here the forwarding headers in include/mallie/) and linked with
+// libmallie_mgpu.so, the way main_console.cc (main_console.cc:57-79) uses the reference's own objects.
+// It doubles as the harness of tests/test_facade.py.
+//
+//   facade_driver mesh   <obj|eson> <file> <scale> <out_prefix>          (CPU only: loader + BVH build)
+//   facade_driver render <obj|eson> <file> <W> <H> <plane> <passes> <maxPathLength> <seed> <out.f32>   (GPU)
+//   facade_driver trace  <obj|eson> <file> <rays.bin> <out.bin>                                          (GPU)
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdint.h>
+
+#include "common.h"
+#include "scene.h"
+#include "render.h"
+#include "camera.h"
+
+static bool init(mallie::Scene &scene, const char *kind, const char *file, double scale) {
+  std::string obj, eson, vox, mat;
+  if (!strcmp(kind, "obj")) obj = file; else eson = file;
+  return scene.Init(obj, eson, vox, mat, scale, false);
+}
+
+static void wr(FILE *fp, const void *p, size_t n) { if (n && fwrite(p, 1, n, fp) != n) { perror("write"); exit(2); } }
+
+int main(int argc, char **argv) {
+  if (argc < 2) return 2;
+  if (!strcmp(argv[1], "mesh") && argc >= 6) {
+    mallie::Scene scene;
+    if (!init(scene, argv[2], argv[3], atof(argv[4]))) return 3;
+    const Mesh &m = scene.GetMesh();
+    std::string out = argv[5];
+    FILE *fp = fopen((out + ".mesh").c_str(), "wb");
+    uint64_t nv = m.numVertices, nf = m.numFaces;
+    uint8_t hn = m.facevarying_normals ? 1 : 0, hu = m.facevarying_uvs ? 1 : 0;
+    wr(fp, &nv, 8); wr(fp, &nf, 8); wr(fp, &hn, 1); wr(fp, &hu, 1);
+    wr(fp, m.vertices, 24 * nv); wr(fp, m.faces, 12 * nf); wr(fp, m.materialIDs, 4 * nf);
+    if (hn) wr(fp, m.facevarying_normals, 72 * nf);
+    if (hu) wr(fp, m.facevarying_uvs, 48 * nf);
+    fclose(fp);
+    // BVHAccel::Dump writes the reference's binary layout (bvh_accel.cc:484-512)
+    if (!scene.GetAccel().Dump((out + ".bvh").c_str())) return 4;
+    // and Load must read it back
+    BVHAccel again;
+    if (!again.Load((out + ".bvh").c_str()) || again.GetNodes().size() != scene.GetAccel().GetNodes().size()) return 5;
+    return 0;
+  }
+  if (!strcmp(argv[1], "render") && argc >= 11) {
+    mallie::Scene scene;
+    if (!init(scene, argv[2], argv[3], 1.0)) return 3;
+    mallie::RenderConfig config;                    // eye (0,0,-5) default is overridden like config.json does
+    config.width = atoi(argv[4]); config.height = atoi(argv[5]); config.plane = atoi(argv[6]) != 0;
+    const int passes = atoi(argv[7]);
+    config.eye[0] = 0; config.eye[1] = 0; config.eye[2] = 20;
+    mallie::SetMaxPathLength(atoi(argv[8]));
+    mallie::SetRenderSeed(strtoull(argv[9], NULL, 10));
+    std::vector<float> image(3 * (size_t)config.width * config.height), accum(image.size(), 0.0f);
+    std::vector<int> count((size_t)config.width * config.height, 0);
+    for (int p = 0; p < passes; p++) {              // the RenderThread loop of main_sdl.cc:569-643
+      mallie::Render(scene, config, image, count, config.eye, config.lookat, config.up, config.quat, 1);
+      for (size_t i = 0; i < image.size(); i++) accum[i] += image[i];   // AccumImage
+    }
+    FILE *fp = fopen(argv[10], "wb");
+    wr(fp, &accum[0], 4 * accum.size()); wr(fp, &count[0], 4 * count.size());
+    fclose(fp);
+    // same frame in one multi-pass launch must give the same bits
+    mallie::SetRenderSeed(strtoull(argv[9], NULL, 10));
+    std::vector<float> image2(image.size()); std::vector<int> count2(count.size(), 0);
+    if (!mallie::RenderPasses(scene, config, image2, count2, config.eye, config.lookat, config.up, config.quat, passes)) return 6;
+    if (memcmp(&image2[0], &accum[0], 4 * accum.size()) != 0) { fprintf(stderr, "RenderPasses != Render+AccumImage\n"); return 7; }
+    return 0;
+  }
+  if (!strcmp(argv[1], "trace") && argc >= 6) {
+    mallie::Scene scene;
+    if (!init(scene, argv[2], argv[3], 1.0)) return 3;
+    FILE *fi = fopen(argv[4], "rb");
+    fseek(fi, 0, SEEK_END); size_t n = ftell(fi) / 48; rewind(fi);
+    std::vector<double> rays(6 * n);
+    if (fread(&rays[0], 48, n, fi) != n) return 4;
+    fclose(fi);
+    FILE *fo = fopen(argv[5], "wb");
+    for (size_t i = 0; i < n; i++) {                // single-ray Scene::Trace, as PathTrace calls it (render.cc:403)
+      Ray ray;
+      ray.org = real3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
+      ray.dir = real3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+      Intersection isect;
+      memset(&isect, 0, sizeof(isect));
+      const bool hit = scene.Trace(isect, ray);
+      uint32_t h = hit ? 1 : 0;
+      wr(fo, &h, 4); wr(fo, &isect.faceID, 4); wr(fo, &isect.t, 8); wr(fo, &isect.u, 8); wr(fo, &isect.v, 8);
+      wr(fo, &isect.normal, 24);
+    }
+    fclose(fo);
+    return 0;
+  }
+  return 2;
+}
