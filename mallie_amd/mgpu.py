@@ -192,7 +192,11 @@ class Scene:
             load_library().mgpu_scene_destroy(self.h)
             self.h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
     def bbox(self):
         lo, hi = np.zeros(3), np.zeros(3)

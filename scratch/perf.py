@@ -25,8 +25,11 @@ if os.environ.get("UTIL"):
         outer, st["real_rays"] // 64, trl / max(1, 64 * outer), ns, st["nodes"] / max(1, 64 * ns), ts_, st["tris"] / max(1, 64 * ts_), genl / max(1, outer)))
     print("  per outer iter: node steps %.2f (ideal %.2f)  tri steps %.2f (ideal %.2f)" % (ns / outer, st["nodes"] / 64 / outer, ts_ / outer, st["tris"] / 64 / outer))
     cn, ct, cs = [int(x) for x in w[16:19]]
+    cb, nb = int(w[28]), int(w[29])
+    if cb:
+        print("  bounce: %d steps, %.0f cyc/step, share of all body cycles %.1f%%" % (nb, cb / max(1, nb), 100.0 * cb / (cn + ct + cs + cb)))
     if cn:
-        tot = cn + ct + cs
+        tot = cn + ct + cs + cb
         print("  cycle share: node %.1f%% (%.0f cyc/step)  tri %.1f%% (%.0f cyc/step)  shade %.1f%% (%.0f cyc/step)  [wave wall-clock cycles incl. interleaving]" % (
             100 * cn / tot, cn / max(1, ns), 100 * ct / tot, ct / max(1, ts_), 100 * cs / tot, cs / max(1, outer)))
     sub = [int(x) for x in w[19:25]]

@@ -116,9 +116,12 @@ class OracleScene:
             raise RuntimeError("mo_scene_create failed")
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().mo_scene_destroy(self.h)
-            self.h = None
+        try:
+            if getattr(self, "h", None):
+                lib().mo_scene_destroy(self.h)
+                self.h = None
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
     def bbox(self):
         lo, hi = np.zeros(3), np.zeros(3)

@@ -284,3 +284,72 @@ def test_full_size_properties_1080p():
     y0, y1 = 500, 508
     oimg, _, _, _ = osc.render(frame, W, H, mpl, 2, plane, O.RNG_HASH, seed=1, window=(0, y0, W, y1))
     assert_images_match(a[y0:y1].cpu().numpy(), oimg[y0:y1], "1080p rows")
+
+
+def _deep_scene(n=120, base=8.0):
+    """Exponentially spaced triangles: every SAH split peels one off, giving a tree deeper than the 32-entry LDS part of
+    the traversal stack (exercises the per-lane HBM overflow column)."""
+    rng = np.random.default_rng(3)
+    cx = base ** np.arange(n)
+    tri = np.zeros((n, 3, 3))
+    tri[:, :, 0] = cx[:, None] * (1 + rng.random((n, 3)) * 0.1)
+    tri[:, :, 1] = rng.random((n, 3)) * cx[:, None]
+    tri[:, :, 2] = rng.random((n, 3)) * cx[:, None]
+    return tri.reshape(-1, 3), np.arange(3 * n, dtype="u4").reshape(n, 3)
+
+
+def test_deep_tree_uses_stack_overflow_column():
+    verts, faces = _deep_scene()
+    nodes, idx, st = M.bvh_build(verts, faces)
+    assert st["maxTreeDepth"] > 32
+    sc = M.Scene(verts, faces, None, None, None, nodes, idx)
+    osc = O.OracleScene(verts, faces, None, None, None, nodes, idx)
+    rng = np.random.default_rng(9)
+    n = 20000
+    tgt = verts[rng.integers(0, len(verts), n)] * (1 + 0.05 * rng.normal(size=(n, 3)))
+    org = np.tile(np.array([-5.0, 0.3, 0.4]), (n, 1)) * (1 + rng.random((n, 1)) * 50)
+    d = tgt - org
+    rays = np.hstack([org, d / np.linalg.norm(d, axis=1, keepdims=True)])
+    out, hit, st = sc.trace(rays, want_stats=True)
+    ost = O.Stats()
+    ref = osc.trace(rays, ost)
+    assert np.array_equal(hit, ref["hit"].astype("u1")) and hit.sum() > 100
+    h = ref["hit"] == 1
+    for f in ("t", "u", "v", "faceID", "materialID", "geometricNormal", "normal"):
+        assert out[f][h].tobytes() == ref[f][h].tobytes(), f
+    assert np.all(out["materialID"][h] == 0xFFFFFFFF)          # no materialIDs array (bvh_accel.cc:687-691)
+    assert (st["nodes"], st["tris"]) == (ost.nodes, ost.tris) and ost.max_stack > 32
+    # and through the renderer (non-LDS state machine, geometric normals, no plane)
+    W, H = 48, 40
+    frame = M.camera_frame((-20.0, 0.5, 0.5), (8.0 ** 3, 100.0, 100.0), width=W, height=H)
+    img, _, _ = sc.render(frame, W, H, 4, 2, None, M.RNG_HASH, seed=2)
+    oimg, _, _, _ = osc.render(frame, W, H, 4, 2, None, O.RNG_HASH, seed=2)
+    assert_images_match(img, oimg, "deep tree")
+
+
+def test_million_triangle_grid_rows_vs_oracle():
+    """BASELINE config C4's scene (32x32 suzanne grid, 991 232 triangles, depth-23 tree, HBM-resident BVH): a band of
+    rows of the 1920x1080 frame against the oracle, plus whole-frame determinism and work-counter sanity."""
+    import torch
+    from mallie_amd.scenes import suzanne_grid
+    c = O.load_golden("cornell_obj")
+    verts, faces, mats, normals = suzanne_grid(c["verts"], c["faces"], 32)
+    assert len(faces) == 991232
+    nodes, idx, st = M.bvh_build(verts, faces)
+    assert st["maxTreeDepth"] == 23
+    sc = M.Scene(verts, faces, mats, normals, None, nodes, idx)
+    osc = O.OracleScene(verts, faces, mats, normals, None, nodes, idx)
+    W, H, mpl = 1920, 1080, 5
+    frame = M.camera_frame((0, 40, 80), (0, 0, 0), width=W, height=H)
+    plane = osc.plane()
+    y0, rows = 600, 6
+    oimg, _, ost, _ = osc.render(frame, W, H, mpl, 2, plane, O.RNG_HASH, seed=1, window=(0, y0, W, y0 + rows))
+    buf = torch.empty((rows, W, 3), dtype=torch.float32, device="cuda")
+    st = sc.render_strips_device(frame, W, H, buf.data_ptr(), rows, y_first=y0, strip_h=rows, y_period=rows,
+                                 maxPathLength=mpl, passes=2, plane=plane, seed=1, want_stats=True)
+    assert_images_match(buf.cpu().numpy(), oimg[y0:y0 + rows], "grid rows")
+    assert_same_work(st, ost)
+    full = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    st = sc.render_strips_device(frame, W, H, full.data_ptr(), H, maxPathLength=mpl, passes=2, plane=plane, seed=1,
+                                 want_stats=True)
+    assert torch.equal(full[y0:y0 + rows], buf) and st["paths"] == 2 * W * H
