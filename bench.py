@@ -34,6 +34,20 @@ WORKLOAD = dict(scene="cornellbox_suzanne", width=1920, height=1080, spp=16, bou
                 lookat=(0.0, 0.0, 0.0), seed=1)
 
 
+def hbm_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json,
+    produced by profiles/collect_r1.sh + profiles/summarize_csv.py on this same bench command); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            d = json.load(f)
+        for k, v in d["bytes_per_launch"].items():
+            if kernel_prefix in k:
+                return int(v)
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def load_scene_arrays():
     g = np.load(os.path.join(ROOT, "tests", "golden", "cornell_obj.npz"))
     return g["verts"].astype(np.float64), g["faces"], g["matIDs"], g["normals"]
@@ -157,7 +171,7 @@ def main():
                        "nodes_per_ray": round(nodes / rays, 3), "tris_per_ray": round(tris / rays, 3),
                        "mtrace_calls_per_s": round(trace_calls / elapsed / 1e6, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": hbm_traffic("k_render_sm") if world == 1 else None,
                          "kernel": "k_render_sm", "kernel_avg_ms": round(kernel_avg_ms, 3),
                          "algorithmic_bytes_per_launch": int(alg_bytes_launch),
                          "note": "algorithmic bytes = nodes*64 + tris*76 + rays*80 (SURVEY 8(d)). The 92 KB BVH of this "
