@@ -435,7 +435,7 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
       shmem += scene_lds;
     }
   }
-  int per_cu = kern == 2 ? 1 : 2;
+  int per_cu = kern == 2 ? 1 : (kern == 1 ? 4 : 2); // workgroups per CU: 16 waves per CU for the state-machine kernels
   if (const char *e = getenv("MGPU_RENDER_BLOCKS_PER_CU")) per_cu = atoi(e) < 1 ? 1 : atoi(e);
   // persistent grid: as many workgroups as stay resident, capped by the work available
   const uint64_t tiles = (uint64_t)((win_w + 7) / 8) * (uint64_t)((n_rows + 7) / 8);

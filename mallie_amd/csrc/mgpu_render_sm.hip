@@ -39,8 +39,14 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 #define MGPU_SHADE_MIN 32
 #endif
 
+// 4 waves per SIMD (<= 128 VGPRs; the compiler then keeps ~40 cold path-state dwords in scratch, touched only by
+// SHADE): measured 12.3 -> 9.4 ms on the 1M-triangle grid and 38.7 -> 28.0 ms on teapot vs the natural 175-VGPR /
+// 2-wave allocation; 5 and 6 waves spill into the NODE / TRI bodies and lose (11.1 / 15.6 ms).
+#ifndef MGPU_SM_MIN_WAVES
+#define MGPU_SM_MIN_WAVES 4
+#endif
 template <int CAP, bool LDS_SCENE, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_render_sm(DScene sc, RenderParams P) {
+__global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) void k_render_sm(DScene sc, RenderParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int kWaves = BLOCK / 64;
   uint32_t *s_stack = reinterpret_cast<uint32_t *>(smem); // [kWaves][CAP][64]
