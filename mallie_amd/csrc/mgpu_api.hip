@@ -275,7 +275,7 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
   TRY_OR_FREE(upload(s, &s->p_faces, faces, sizeof(uint32_t) * 3 * nf));
   TRY_OR_FREE(upload(s, &s->p_fvn, fv_normals, fv_normals ? sizeof(double) * 9 * nf : 0));
   TRY_OR_FREE(upload(s, &s->p_fvuv, fv_uvs, fv_uvs ? sizeof(double) * 6 * nf : 0));
-  TRY_OR_FREE(dev_alloc(s, (void **)&s->p_counters, sizeof(uint32_t) * kCounterRing));
+  TRY_OR_FREE(dev_alloc(s, (void **)&s->p_counters, sizeof(uint32_t) * kCounterRing * kShards));
   TRY_OR_FREE(dev_alloc(s, (void **)&s->p_stats, sizeof(unsigned long long) * kStatWords));
   {
     hipError_t e = hipMemset(s->p_stats, 0, sizeof(unsigned long long) * kStatWords);
@@ -480,7 +480,7 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
     P.out = s->p_planes;
     P.pass_stride = n_floats;
   }
-  P.work_counter = s->p_counters + (s->launch_seq++ % kCounterRing);
+  P.work_counter = s->p_counters + (size_t)(s->launch_seq++ % kCounterRing) * kShards;
   P.stats = s->p_stats;
   P.lds_nodes_bytes = (uint32_t)(sizeof(MgpuNode) * s->nn);
   P.lds_tris_bytes = (uint32_t)(sizeof(DTri) * s->nf);
@@ -493,7 +493,7 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   P.probe_pixel = s->probe_pixel;
   P.probe_pass = s->probe_pass;
 
-  HIP_TRY(hipMemsetAsync(P.work_counter, 0, sizeof(uint32_t), st));
+  HIP_TRY(hipMemsetAsync(P.work_counter, 0, sizeof(uint32_t) * kShards, st));
   if (stats) {
     HIP_TRY(hipMemsetAsync(s->p_stats, 0, sizeof(unsigned long long) * kStatWords, st));
     HIP_TRY(hipEventRecord(s->ev0, st));

@@ -10,6 +10,7 @@ namespace mgpu {
 
 constexpr int kBlock = 256;      // 4 waves per workgroup
 constexpr int kChunkTiles = 2;   // k_render v1: 8x8-pixel tiles handed to a wave per global-counter fetch
+constexpr int kShards = 8;       // k_render_sm: work counters per launch = XCDs of an MI355X
 constexpr int kChunkItems = 4;   // k_render_sm: (tile, pass) items of 64 eye paths per global-counter fetch
 
 // device-side statistics words (unsigned long long each)
@@ -34,7 +35,7 @@ struct RenderParams {
   int32_t *count;   // device or null
   float *out;       // k_render_sm: where per-pass radiance goes: pass planes (passes > 1) or the image (passes == 1)
   size_t pass_stride; // floats between consecutive pass planes of `out` (0 when passes == 1)
-  uint32_t *work_counter;        // device, zeroed before the launch
+  uint32_t *work_counter;        // device, kShards words (k_render v1 uses the first), zeroed before the launch
   unsigned long long *stats;     // device, kStatWords, accumulated
   uint32_t lds_nodes_bytes, lds_tris_bytes; // k_render_sm<LDS_SCENE>: bytes of nodes / triangles staged into LDS
   unsigned long long *wave_log;  // device or null: 4 words per wave (diagnostic builds only)

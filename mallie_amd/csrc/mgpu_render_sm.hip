@@ -80,6 +80,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
   const uint32_t total_items = total_tiles * (uint32_t)P.passes;
   uint32_t item_next = 0, item_end = 0, in_item = 64;
   bool exhausted = false;
+  // (with the BVH in LDS there is no L2 locality to protect: one part, one counter, best balance)
+  const uint32_t shard_items = LDS_SCENE ? total_items : (total_items + (uint32_t)kShards - 1) / (uint32_t)kShards;
+  uint32_t home_shard = 0, shard_off = 0;
+  if (!LDS_SCENE) {
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(home_shard)); // which XCD this wave runs on (0..7)
+    home_shard &= 7u;
+  }
 
   // ---- per-lane path state --------------------------------------------------------------------------------------
   int st = ST_SHADE;       // everybody starts by asking for work
@@ -356,12 +363,25 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
         if (!want || exhausted) break;
         if (in_item >= 64) { // current item used up: take the next one, refilling the chunk when it is empty
           if (item_next >= item_end) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(P.work_counter, (uint32_t)kChunkItems);
-            base = __shfl(base, 0);
-            item_next = base;
-            item_end = min(base + (uint32_t)kChunkItems, total_items);
-            if (base >= total_items) { exhausted = true; item_end = item_next = total_items; break; }
+            // XCD-aware draw: the item range is cut into kShards contiguous parts, one per XCD, so the waves of one XCD
+            // (one L2) walk one image region; a wave whose home part is used up moves on to the next part for good
+            bool got = false;
+            while (shard_off < (uint32_t)kShards) {
+              const uint32_t sh = (home_shard + shard_off) % (uint32_t)kShards;
+              uint32_t base = 0;
+              if (lane == 0) base = atomicAdd(P.work_counter + sh, (uint32_t)kChunkItems);
+              base = __shfl(base, 0);
+              const uint32_t lo = sh * shard_items;
+              const uint32_t hi = min(lo + shard_items, total_items);
+              if (lo < hi && base < hi - lo) {
+                item_next = lo + base;
+                item_end = min(item_next + (uint32_t)kChunkItems, hi);
+                got = true;
+                break;
+              }
+              ++shard_off;
+            }
+            if (!got) { exhausted = true; item_end = item_next = total_items; break; }
           }
           in_item = 0;
         }
