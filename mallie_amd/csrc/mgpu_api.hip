@@ -420,6 +420,7 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
     else if (!strcmp(e, "sm_lds")) kern = 2;
     else return fail(MGPU_ERR_INVALID, "MGPU_RENDER_KERNEL=%s (expected v1|sm|sm_lds)", e);
   }
+  if (kern == 2 && (s->cap > 24 || s->stack_need > s->cap)) kern = 1; // deep trees never fit the LDS budget anyway
   int block = kern == 2 ? 1024 : kBlock;
   size_t shmem = (size_t)(block / 64) * s->cap * 64 * sizeof(uint32_t);
   if (kern == 2) {

@@ -122,22 +122,30 @@ __host__ __device__ __forceinline__ void hash_state(uint64_t seed, uint32_t pass
 }
 
 // ---- traversal stack: first CAP entries in LDS (entry-major, lane-minor: conflict-free), rest in HBM ---------------
-template <int CAP> struct Stack {
+// OVF = false: the tree is at most CAP-1 deep, every access is a plain ds_read/ds_write_b32 (the mixed form makes hipcc
+// select between an LDS and an HBM ADDRESS and issue a flat_load, which waits on both memory counters).
+template <int CAP, bool OVF = true> struct Stack {
   uint32_t *lds;      // &s_stack[wave][0][lane]
-  uint32_t *overflow; // this lane's overflow column (may be null when overflow_cap == 0)
+  uint32_t *overflow; // this lane's overflow column (null when !OVF)
   __device__ __forceinline__ void put(int i, uint32_t v) const {
-    if (i < CAP) lds[i * 64] = v;
+    if (!OVF || i < CAP) lds[i * 64] = v;
     else overflow[i - CAP] = v;
   }
-  __device__ __forceinline__ uint32_t get(int i) const { return (i < CAP) ? lds[i * 64] : overflow[i - CAP]; }
+  __device__ __forceinline__ uint32_t get(int i) const {
+    if (!OVF) return lds[i * 64];
+    uint32_t v;
+    if (i < CAP) v = lds[i * 64];
+    else v = overflow[i - CAP];
+    return v;
+  }
 };
 
 // ---- BVHAccel::Traverse (bvh_accel.cc:773-844) without the final BuildIntersection ----------------------------------
 // while-while form: every lane pops and box-tests nodes until it holds a leaf (or runs dry), then the wave tests leaf
 // triangles together.  Pop order, the near/far push order and the in-leaf triangle order are the reference's, so
 // exact-t ties resolve identically and node/triangle counts equal the CPU's.
-template <int CAP>
-__device__ __forceinline__ void traverse(const DScene &sc, const Stack<CAP> &stk, V3 org, V3 dir, Hit &h, Counters &c) {
+template <int CAP, bool OVF>
+__device__ __forceinline__ void traverse(const DScene &sc, const Stack<CAP, OVF> &stk, V3 org, V3 dir, Hit &h, Counters &c) {
   const bool sx = dir.x < 0.0, sy = dir.y < 0.0, sz = dir.z < 0.0;
   const double ix = 1.0 / dir.x, iy = 1.0 / dir.y, iz = 1.0 / dir.z; // no zero guard, as the reference
   h.t = kDblMax;

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(DScene sc, const MgpuRay *__re
   __shared__ uint32_t s_stack[kBlock / 64][CAP][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t gid = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  Stack<CAP> stk;
+  Stack<CAP, true> stk;
   stk.lds = &s_stack[wave][0][lane];
   stk.overflow = sc.stack_overflow ? sc.stack_overflow + gid * sc.overflow_cap : nullptr;
   Counters c{};
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(DScene sc, const MgpuRay *__re
     const V3 org = v3(r->org[0], r->org[1], r->org[2]);
     const V3 dir = v3(r->dir[0], r->dir[1], r->dir[2]);
     Hit h;
-    traverse<CAP>(sc, stk, org, dir, h, c);
+    traverse<CAP, true>(sc, stk, org, dir, h, c);
     MgpuIntersection is;
     // a miss leaves t = DBL_MAX, u = v = 0, faceID = -1 (bvh_accel.cc:782-786); every other field is zeroed here
     is.t = h.t; is.u = h.u; is.v = h.v;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kBlock, MGPU_RENDER_MIN_WAVES) void k_render(DScene
   __shared__ uint32_t s_stack[kBlock / 64][CAP][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t gid = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  Stack<CAP> stk;
+  Stack<CAP, true> stk;
   stk.lds = &s_stack[wave][0][lane];
   stk.overflow = sc.stack_overflow ? sc.stack_overflow + gid * sc.overflow_cap : nullptr;
 
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kBlock, MGPU_RENDER_MIN_WAVES) void k_render(DScene
 #ifdef MGPU_UTIL
     u_trace += (uint32_t)__popcll(__ballot(state == S_TRACE));
 #endif
-    if (state == S_TRACE) traverse<CAP>(sc, stk, org, dir, h, c);
+    if (state == S_TRACE) traverse<CAP, true>(sc, stk, org, dir, h, c);
 
     // ---- 4. the rest of one PathTrace loop iteration (render.cc:403-452) ----------------------------------------
     if (state == S_TRACE) {

@@ -45,16 +45,16 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 #ifndef MGPU_SM_MIN_WAVES
 #define MGPU_SM_MIN_WAVES 4
 #endif
-template <int CAP, bool LDS_SCENE, int BLOCK>
+template <int CAP, bool LDS_SCENE, int BLOCK, bool OVF>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) void k_render_sm(DScene sc, RenderParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int kWaves = BLOCK / 64;
   uint32_t *s_stack = reinterpret_cast<uint32_t *>(smem); // [kWaves][CAP][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  Stack<CAP> stk;
+  Stack<CAP, OVF> stk;
   stk.lds = s_stack + ((size_t)wave * CAP) * 64 + lane;
-  stk.overflow = sc.stack_overflow ? sc.stack_overflow + gid * sc.overflow_cap : nullptr;
+  stk.overflow = (OVF && sc.stack_overflow) ? sc.stack_overflow + gid * sc.overflow_cap : nullptr;
 
   // ---- optional: stage nodes + triangles into LDS -------------------------------------------------------------
   const unsigned char *lds_nodes = smem + (size_t)kWaves * CAP * 64 * sizeof(uint32_t);
@@ -534,9 +534,9 @@ void launch_accumulate(hipStream_t s, const float *planes, size_t plane_stride, 
 // =====================================================================================================================
 // launcher
 // =====================================================================================================================
-template <int CAP, bool LDS, int BLOCK>
+template <int CAP, bool LDS, int BLOCK, bool OVF>
 static hipError_t launch_one(dim3 grid, hipStream_t s, size_t shmem, const DScene &sc, const RenderParams &p) {
-  auto kern = k_render_sm<CAP, LDS, BLOCK>;
+  auto kern = k_render_sm<CAP, LDS, BLOCK, OVF>;
   if (shmem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)shmem);
@@ -546,19 +546,23 @@ static hipError_t launch_one(dim3 grid, hipStream_t s, size_t shmem, const DScen
   return hipGetLastError();
 }
 
+// Instantiations: LDS-resident scene (small trees only: CAP 16 / 24, never an overflow column) with 1024- or 512-thread
+// workgroups; HBM-resident scene with 256-thread workgroups, CAP 16 / 24 / 32, the overflow column only for CAP 32.
 hipError_t launch_render_sm(int cap, bool lds_scene, int block, dim3 grid, hipStream_t s, size_t shmem, const DScene &sc,
                             const RenderParams &p) {
-#define MGPU_CASE(C)                                                                     \
-  if (cap == C) {                                                                        \
-    if (lds_scene && block == 1024) return launch_one<C, true, 1024>(grid, s, shmem, sc, p);  \
-    if (lds_scene && block == 512) return launch_one<C, true, 512>(grid, s, shmem, sc, p);    \
-    if (!lds_scene && block == 256) return launch_one<C, false, 256>(grid, s, shmem, sc, p);  \
-    if (!lds_scene && block == 512) return launch_one<C, false, 512>(grid, s, shmem, sc, p);  \
+  const bool ovf = sc.overflow_cap != 0;
+  if (lds_scene && !ovf) {
+    if (cap == 16 && block == 1024) return launch_one<16, true, 1024, false>(grid, s, shmem, sc, p);
+    if (cap == 16 && block == 512) return launch_one<16, true, 512, false>(grid, s, shmem, sc, p);
+    if (cap == 24 && block == 1024) return launch_one<24, true, 1024, false>(grid, s, shmem, sc, p);
+    if (cap == 24 && block == 512) return launch_one<24, true, 512, false>(grid, s, shmem, sc, p);
   }
-  MGPU_CASE(16)
-  MGPU_CASE(24)
-  MGPU_CASE(32)
-#undef MGPU_CASE
+  if (!lds_scene && block == 256) {
+    if (cap == 16 && !ovf) return launch_one<16, false, 256, false>(grid, s, shmem, sc, p);
+    if (cap == 24 && !ovf) return launch_one<24, false, 256, false>(grid, s, shmem, sc, p);
+    if (cap == 32 && !ovf) return launch_one<32, false, 256, false>(grid, s, shmem, sc, p);
+    if (cap == 32 && ovf) return launch_one<32, false, 256, true>(grid, s, shmem, sc, p);
+  }
   return hipErrorInvalidConfiguration;
 }
 
