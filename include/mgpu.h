@@ -164,6 +164,13 @@ int mgpu_timing_read(MgpuScene *scene, double *total_ms, int *launches);
 int mgpu_probe_path(MgpuScene *scene, const double frame[12], int W, int H, int px, int py, int maxPathLength,
                     const float plane[4], const uint32_t start_state[4], double *records, int *n_records);
 
+/* Display transforms of the reference's drivers, fused with the per-pixel 1/count (device pointers, asynchronous):
+ *   MGPU_TONEMAP_LINEAR_RGB8   HDRToLDR + fclamp, main_console.cc:25-43: 3 bytes/pixel, clamp(int((in/count) * 255.5))
+ *   MGPU_TONEMAP_GAMMA22_BGRA8 Display + fclamp, main_sdl.cc:157-165,420-477: 4 bytes/pixel B,G,R,255, gamma 2.2 */
+enum { MGPU_TONEMAP_LINEAR_RGB8 = 0, MGPU_TONEMAP_GAMMA22_BGRA8 = 1 };
+int mgpu_tonemap_device(int device, const float *d_image, const int32_t *d_count, size_t npix, int mode,
+                        unsigned char *d_out, void *stream);
+
 /* The per-(pixel,pass) start state of MGPU_RNG_HASH (host helper; the device uses the same function). */
 void mgpu_hash_state(uint64_t seed, uint32_t pass, uint32_t pixel, uint32_t state[4]);
 

@@ -5,8 +5,9 @@ is the thin Python host layer used by the tests, the benchmark and multi-GPU plu
 importing works anywhere (the library only needs the HIP runtime), but every compute call needs a GPU.
 """
 from .mgpu import (MgpuError, Scene, Stats, RNG_HASH, RNG_STREAM, RNG_TABLE, NODE_DT, RAY_DT, ISECT_DT, abi_version,
-                   bvh_build, camera_frame, device_count, hash_state, lib_path, plane_from_bbox, load_library)
+                   bvh_build, camera_frame, device_count, hash_state, lib_path, plane_from_bbox, load_library, tonemap_device,
+                   TONEMAP_LINEAR_RGB8, TONEMAP_GAMMA22_BGRA8)
 
 __all__ = ["MgpuError", "Scene", "Stats", "RNG_HASH", "RNG_STREAM", "RNG_TABLE", "NODE_DT", "RAY_DT", "ISECT_DT",
            "abi_version", "bvh_build", "camera_frame", "device_count", "hash_state", "lib_path", "plane_from_bbox",
-           "load_library"]
+           "load_library", "tonemap_device", "TONEMAP_LINEAR_RGB8", "TONEMAP_GAMMA22_BGRA8"]

@@ -662,6 +662,18 @@ int mgpu_timing_read(MgpuScene *s, double *total_ms, int *launches) {
   return MGPU_OK;
 }
 
+int mgpu_tonemap_device(int device, const float *d_image, const int32_t *d_count, size_t npix, int mode,
+                        unsigned char *d_out, void *stream) {
+  if (!d_image || !d_count || !d_out) return fail(MGPU_ERR_INVALID, "NULL argument");
+  if (mode != MGPU_TONEMAP_LINEAR_RGB8 && mode != MGPU_TONEMAP_GAMMA22_BGRA8) return fail(MGPU_ERR_INVALID, "bad mode %d", mode);
+  if (device < 0 || device >= mgpu_device_count()) return fail(MGPU_ERR_NO_DEVICE, "device %d not available", device);
+  HIP_TRY(hipSetDevice(device));
+  if (npix == 0) return MGPU_OK;
+  launch_tonemap((hipStream_t)stream, d_image, d_count, npix, mode, d_out);
+  HIP_TRY(hipGetLastError());
+  return MGPU_OK;
+}
+
 int mgpu_probe_path(MgpuScene *s, const double frame[12], int W, int H, int px, int py, int maxPathLength,
                     const float plane[4], const uint32_t start_state[4], double *records, int *n_records) {
   if (!s || !frame || !start_state || !records || !n_records) return fail(MGPU_ERR_INVALID, "NULL argument");

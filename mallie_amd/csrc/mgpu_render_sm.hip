@@ -30,6 +30,8 @@
 #include "mgpu_device.hpp"
 #include "mgpu_kernels.hpp"
 
+#include <climits>
+
 namespace mgpu {
 
 enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
@@ -529,6 +531,44 @@ void launch_accumulate(hipStream_t s, const float *planes, size_t plane_stride, 
                        int32_t *count) {
   const unsigned blocks = (unsigned)((n_floats + 255) / 256);
   hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, s, planes, plane_stride, passes, n_floats, image, count);
+}
+
+// =====================================================================================================================
+// k_tonemap: the display transforms of the reference's two drivers, fused with the 1/count normalisation
+//   mode 0: HDRToLDR + fclamp of the console driver (main_console.cc:25-43): RGB8, out = clamp(int((in / count) * 255.5))
+//   mode 1: Display + fclamp of the SDL driver (main_sdl.cc:157-165,420-477): BGRA8, gamma 2.2,
+//           out = clamp(int(powf((1.0f / count) * in, 1.0f / 2.2f) * 255.5))
+// The float -> double -> int conversion follows x86's cvttsd2si (out-of-range and NaN give INT_MIN, i.e. 0 after clamp).
+// =====================================================================================================================
+__device__ __forceinline__ unsigned char to_byte(double scaled) {
+  int i;
+  if (!(scaled < 2147483648.0) || scaled < -2147483648.0) i = INT_MIN; // also catches NaN
+  else i = (int)scaled;
+  return (unsigned char)(i < 0 ? 0 : (i > 255 ? 255 : i));
+}
+
+__global__ __launch_bounds__(256) void k_tonemap(const float *__restrict__ image, const int32_t *__restrict__ count,
+                                                  size_t npix, int mode, unsigned char *__restrict__ out) {
+  const size_t px = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (px >= npix) return;
+  const int c = count[px];
+  const float r = image[3 * px + 0], g = image[3 * px + 1], b = image[3 * px + 2];
+  if (mode == 0) {
+    out[3 * px + 0] = to_byte((double)(r / (float)c) * 255.5);
+    out[3 * px + 1] = to_byte((double)(g / (float)c) * 255.5);
+    out[3 * px + 2] = to_byte((double)(b / (float)c) * 255.5);
+  } else {
+    const float scale = 1.0f / (float)c;
+    const float inv_gamma = 1.0f / 2.2f;
+    out[4 * px + 2] = to_byte((double)powf(scale * r, inv_gamma) * 255.5);
+    out[4 * px + 1] = to_byte((double)powf(scale * g, inv_gamma) * 255.5);
+    out[4 * px + 0] = to_byte((double)powf(scale * b, inv_gamma) * 255.5);
+    out[4 * px + 3] = 255;
+  }
+}
+
+void launch_tonemap(hipStream_t s, const float *image, const int32_t *count, size_t npix, int mode, unsigned char *out) {
+  hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, image, count, npix, mode, out);
 }
 
 // =====================================================================================================================

@@ -91,6 +91,8 @@ def load_library():
     L.mgpu_timing_enable.restype = i32
     L.mgpu_timing_read.argtypes = [vp, C.POINTER(dbl), C.POINTER(i32)]
     L.mgpu_timing_read.restype = i32
+    L.mgpu_tonemap_device.argtypes = [i32, vp, vp, sz, i32, vp, vp]
+    L.mgpu_tonemap_device.restype = i32
     L.mgpu_probe_path.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, C.POINTER(i32)]
     L.mgpu_probe_path.restype = i32
     L.mgpu_camera_frame.argtypes = [vp, vp, vp, vp, dbl, i32, i32, vp]
@@ -154,6 +156,15 @@ def bvh_build(verts, faces, costTaabb=0.2, minLeaf=16, maxDepth=256, binSize=64)
     L.mgpu_free(pn)
     L.mgpu_free(pi)
     return nodes, idx, dict(maxTreeDepth=st[0], numLeafNodes=st[1], numBranchNodes=st[2])
+
+
+TONEMAP_LINEAR_RGB8, TONEMAP_GAMMA22_BGRA8 = 0, 1
+
+
+def tonemap_device(d_image_ptr, d_count_ptr, npix, mode, d_out_ptr, device=0, stream=None):
+    """mgpu_tonemap_device: 1/count + the console (linear RGB8) or SDL (gamma 2.2 BGRA8) display transform, on device."""
+    _check(load_library().mgpu_tonemap_device(device, d_image_ptr, d_count_ptr, npix, mode, d_out_ptr, stream),
+           "mgpu_tonemap_device")
 
 
 def plane_from_bbox(bmin, bmax):

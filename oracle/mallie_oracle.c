@@ -969,3 +969,30 @@ int mo_probe_path(const mo_scene *s, const double frame[12], int px, int py, int
   if (radiance) { radiance[0] = rad[0]; radiance[1] = rad[1]; radiance[2] = rad[2]; }
   return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* display transforms of the two drivers (main_console.cc:25-43; main_sdl.cc:157-165,420-477)        */
+/* ------------------------------------------------------------------------------------------------ */
+static unsigned char to_byte(double scaled) {
+  /* `int i = x * 255.5;` on x86-64 is cvttsd2si: NaN and out-of-range give INT_MIN */
+  int i;
+  if (!(scaled < 2147483648.0) || scaled < -2147483648.0) i = (-2147483647 - 1);
+  else i = (int)scaled;
+  return (unsigned char)(i < 0 ? 0 : (i > 255 ? 255 : i));
+}
+
+void mo_tonemap(const float *image, const int32_t *count, size_t npix, int mode, unsigned char *out) {
+  for (size_t px = 0; px < npix; px++) {
+    const int c = count[px];
+    if (mode == 0) { /* HDRToLDR: out[i] = fclamp(in[i] / in_count[i / 3]) */
+      for (int k = 0; k < 3; k++) out[3 * px + k] = to_byte((double)(image[3 * px + k] / (float)c) * 255.5);
+    } else { /* Display: scale = 1.0f / count; BGRA; fclamp with gamma 2.2 */
+      const float scale = 1.0f / (float)c;
+      const float gamma = 2.2f;
+      out[4 * px + 2] = to_byte((double)powf(scale * image[3 * px + 0], 1.0f / gamma) * 255.5);
+      out[4 * px + 1] = to_byte((double)powf(scale * image[3 * px + 1], 1.0f / gamma) * 255.5);
+      out[4 * px + 0] = to_byte((double)powf(scale * image[3 * px + 2], 1.0f / gamma) * 255.5);
+      out[4 * px + 3] = 255;
+    }
+  }
+}

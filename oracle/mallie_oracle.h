@@ -128,6 +128,10 @@ int mo_render(const mo_scene *s, const double frame[12], int W, int H, int x0, i
               const uint32_t *rng_states, uint64_t seed, uint32_t pass_base, float *image, int32_t *count,
               uint32_t *states_out, mo_stats *stats, int nthreads);
 
+/* Display transforms: mode 0 = HDRToLDR/fclamp of main_console.cc:25-43 (RGB8, linear), mode 1 = Display/fclamp of
+ * main_sdl.cc:157-165,420-477 (BGRA8, gamma 2.2); both divide by the per-pixel count first. */
+void mo_tonemap(const float *image, const int32_t *count, size_t npix, int mode, unsigned char *out);
+
 /* One eye path with per-iteration records: see mallie_oracle.c. records: 16*maxPathLength doubles. */
 int mo_probe_path(const mo_scene *s, const double frame[12], int px, int py, int maxPathLength, const float *plane,
                   const uint32_t start_state[4], double *records, int *n_records, double radiance[3]);

@@ -65,6 +65,7 @@ def lib():
         L.mo_render.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, u64, u32, vp, vp, vp,
                                 vp, i32]
         L.mo_render.restype = i32
+        L.mo_tonemap.argtypes = [vp, vp, sz, i32, vp]
         L.mo_probe_path.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, C.POINTER(i32), vp]
         L.mo_probe_path.restype = i32
         _lib = L
@@ -170,6 +171,14 @@ class OracleScene:
         if rc:
             raise RuntimeError("mo_render failed: %d" % rc)
         return image, count, st.as_dict(), states_out
+
+
+def tonemap(image, count, mode):
+    image = _c(image, "<f4").reshape(-1, 3)
+    count = _c(count, "<i4").reshape(-1)
+    out = np.zeros((len(count), 3 if mode == 0 else 4), "u1")
+    lib().mo_tonemap(_p(image), _p(count), len(count), mode, _p(out))
+    return out
 
 
 def camera_frame(eye, lookat, up=(0, 1, 0), quat=(0, 0, 0, 0), fov=45.0, width=512, height=512):

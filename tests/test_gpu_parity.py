@@ -353,3 +353,28 @@ def test_million_triangle_grid_rows_vs_oracle():
     st = sc.render_strips_device(frame, W, H, full.data_ptr(), H, maxPathLength=mpl, passes=2, plane=plane, seed=1,
                                  want_stats=True)
     assert torch.equal(full[y0:y0 + rows], buf) and st["paths"] == 2 * W * H
+
+
+def test_tonemap_matches_driver_transforms():
+    """1/count + fclamp of the console driver (exact) and of the SDL driver (gamma 2.2 through powf: the device's powf
+    may differ from glibc's in the last ulp, which can move a value across an integer boundary -> at most 1 LSB)."""
+    import torch
+    sc, osc = gpu_scene("cornell_obj"), O.scene_from_golden("cornell_obj")
+    W, H, passes = 160, 120, 4
+    frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    img, count, _ = sc.render(frame, W, H, 5, passes, osc.plane(), M.RNG_HASH, seed=1)
+    img[0, 0] = (np.inf, np.nan, -1.0)      # conversions the reference leaves to cvttsd2si
+    img[0, 1] = (1e30, 3.0, 0.999)
+    count[0, 2] = 0                          # division by zero -> inf / nan
+    d_img = torch.from_numpy(img).cuda()
+    d_cnt = torch.from_numpy(count).cuda()
+    for mode, ch in ((M.TONEMAP_LINEAR_RGB8, 3), (M.TONEMAP_GAMMA22_BGRA8, 4)):
+        d_out = torch.zeros((H * W, ch), dtype=torch.uint8, device="cuda")
+        M.tonemap_device(d_img.data_ptr(), d_cnt.data_ptr(), W * H, mode, d_out.data_ptr())
+        torch.cuda.synchronize()
+        got, ref = d_out.cpu().numpy(), O.tonemap(img, count, mode)
+        if mode == M.TONEMAP_LINEAR_RGB8:
+            assert np.array_equal(got, ref)
+        else:
+            diff = np.abs(got.astype(int) - ref.astype(int))
+            assert diff.max() <= 1 and (diff != 0).mean() < 1e-3 and np.all(got[:, 3] == 255)
