@@ -46,10 +46,16 @@ class FrameRenderer:
         self.local = torch.zeros((self.max_rows, W, 3), dtype=torch.float32, device=self.device)
         if world > 1:
             if rank == 0:
-                self.gathered = [torch.empty_like(self.local) for _ in range(world)]
+                # one contiguous landing area [world, max_rows, W, 3]; rank r's padded strips arrive in slab r
+                self.slab = torch.empty((world, self.max_rows, W, 3), dtype=torch.float32, device=self.device)
+                self.gathered = list(self.slab.unbind(0))
+                # frame row y lives at slab row perm[y] = owner(y) * max_rows + local index of y at its owner
+                perm = np.empty(H, np.int64)
+                for r in range(world):
+                    rows = strip_rows(H, world, r, strip_h)
+                    perm[rows] = r * self.max_rows + np.arange(len(rows))
+                self.perm = torch.from_numpy(perm).to(self.device)
                 self.frame_buffer = torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
-                self.row_index = [torch.from_numpy(strip_rows(H, world, r, strip_h)).to(self.device) for r in range(world)]
-                self.row_count = counts
             else:
                 self.gathered, self.frame_buffer = None, None
         else:
@@ -69,7 +75,7 @@ class FrameRenderer:
                                             pass_base=pass_base, stream=stream)
         if self.world > 1:
             dist.gather(self.local, self.gathered if self.rank == 0 else None, dst=0)
-            if self.rank == 0:
-                for r in range(self.world):
-                    self.frame_buffer.index_copy_(0, self.row_index[r], self.gathered[r][: self.row_count[r]])
+            if self.rank == 0:  # re-interleave the strips: one gather kernel over rows
+                torch.index_select(self.slab.view(self.world * self.max_rows, self.W, 3), 0, self.perm,
+                                   out=self.frame_buffer)
         return self.frame_buffer
