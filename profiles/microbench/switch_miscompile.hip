@@ -1,4 +1,4 @@
-#include "../mallie_amd/csrc/mgpu_device.hpp"
+#include "../../mallie_amd/csrc/mgpu_device.hpp"
 #include <cstdio>
 using namespace mgpu;
 __global__ void k(const double* nin, double* out) {

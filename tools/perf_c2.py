@@ -1,5 +1,5 @@
 import sys, os, time, json
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os as _os; _R = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))); sys.path.insert(0, _R); sys.path.insert(0, _os.path.join(_R, "tests")); _os.chdir(_R)
 import numpy as np, torch
 import mallie_amd as M
 g = np.load("tests/golden/cornell_obj.npz")
