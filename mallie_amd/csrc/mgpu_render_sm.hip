@@ -16,8 +16,8 @@
 // nobody waits for the longest ray any more; per-ray operation order (pop order, leaf order, RNG draws) is untouched,
 // hence results are bit-identical to k_render and to the oracle.
 //
-// Work distribution: the unit handed to a wave is one (8x8 pixel tile, pass) pair = 64 eye paths, drawn in chunks of
-// kChunkItems from one global counter; inside the wave, a lane whose path ends takes the next free path of the wave's
+// Work distribution: the unit handed to a wave is one (8x8 pixel tile, pass) pair = 64 eye paths, drawn 2 or 4 at a time
+// from one of eight per-XCD counters; inside the wave, a lane whose path ends takes the next free path of the wave's
 // current item at its next SHADE step.  Items are this fine because path cost varies ~50x over the frame (sky: one
 // root-miss ray, Suzanne: five deep traversals): with a lane owning a pixel for all its passes the slowest wave ran
 // 2.2x longer than the median one and set the frame time.  The price is that a pixel's passes are no longer summed by
@@ -82,13 +82,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
   const uint32_t total_items = total_tiles * (uint32_t)P.passes;
   uint32_t item_next = 0, item_end = 0, in_item = 64;
   bool exhausted = false;
-  // (with the BVH in LDS there is no L2 locality to protect: one part, one counter, best balance)
-  const uint32_t shard_items = LDS_SCENE ? total_items : (total_items + (uint32_t)kShards - 1) / (uint32_t)kShards;
-  uint32_t home_shard = 0, shard_off = 0;
-  if (!LDS_SCENE) {
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(home_shard)); // which XCD this wave runs on (0..7)
-    home_shard &= 7u;
-  }
+  // The item range is dealt to kShards work counters, one per XCD (less contention on each; a wave draws from its own
+  // XCD's counter first).  HBM-resident scenes: part s = the s-th CONTIGUOUS eighth of the items, so the waves of one
+  // XCD (one L2) walk one image region.  LDS-resident scenes have no L2 locality to protect: part s = every 8th item
+  // (item = k * kShards + s), which balances the parts by construction.
+  constexpr uint32_t kChunk = LDS_SCENE ? (uint32_t)kChunkItemsLds : (uint32_t)kChunkItemsHbm;
+  const uint32_t shard_items = (total_items + (uint32_t)kShards - 1) / (uint32_t)kShards;
+  uint32_t home_shard = 0, shard_off = 0, cur_shard = 0;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(home_shard)); // which XCD this wave runs on (0..7)
+  home_shard &= 7u;
 
   // ---- per-lane path state --------------------------------------------------------------------------------------
   int st = ST_SHADE;       // everybody starts by asking for work
@@ -371,13 +373,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
             while (shard_off < (uint32_t)kShards) {
               const uint32_t sh = (home_shard + shard_off) % (uint32_t)kShards;
               uint32_t base = 0;
-              if (lane == 0) base = atomicAdd(P.work_counter + sh, (uint32_t)kChunkItems);
+              if (lane == 0) base = atomicAdd(P.work_counter + sh, kChunk);
               base = __shfl(base, 0);
-              const uint32_t lo = sh * shard_items;
-              const uint32_t hi = min(lo + shard_items, total_items);
-              if (lo < hi && base < hi - lo) {
-                item_next = lo + base;
-                item_end = min(item_next + (uint32_t)kChunkItems, hi);
+              // local index range of part sh: [0, n_sh)
+              const uint32_t n_sh = LDS_SCENE ? (total_items > sh ? (total_items - sh + (uint32_t)kShards - 1) / (uint32_t)kShards : 0u)
+                                              : (sh * shard_items < total_items ? min(shard_items, total_items - sh * shard_items) : 0u);
+              if (base < n_sh) {
+                cur_shard = sh;
+                item_next = base;                                     // LOCAL indices within the part
+                item_end = min(base + kChunk, n_sh);
                 got = true;
                 break;
               }
@@ -391,12 +395,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
           const uint32_t rank = __popcll(want & ((1ull << lane) - 1ull));
           const uint32_t slot = in_item + rank;
           if (slot < 64) {
-            const uint32_t tile = item_next / (uint32_t)P.passes; // tile-major: a tile's passes are consecutive items
+            const uint32_t item = LDS_SCENE ? item_next * (uint32_t)kShards + cur_shard : cur_shard * shard_items + item_next;
+            const uint32_t tile = item / (uint32_t)P.passes; // tile-major: a tile's passes are consecutive items
             const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
             const uint32_t x = tx * 8 + (slot & 7), y = ty * 8 + (slot >> 3);
             if (x < (uint32_t)win_w && y < (uint32_t)P.n_rows) { // slots of an edge tile outside the window are skipped
               lx = x; ly = y;
-              pass = (int)(item_next % (uint32_t)P.passes);
+              pass = (int)(item % (uint32_t)P.passes);
               have_path = true;
               want_pixel = false;
             }
