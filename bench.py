@@ -158,6 +158,7 @@ def main():
         # roofline of the dominant kernel (k_render) on THIS rank: algorithmic bytes of one launch / its mean duration
         alg_bytes_launch = (st["nodes"] * B_NODE + st["tris"] * B_TRI + st["real_rays"] * B_RAY) / max(launches, 1)
         kernel_avg_ms = float(kern.item())
+        traffic = hbm_traffic("k_render_sm") if world == 1 else None
         achieved = alg_bytes_launch / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
         out = {
             "metric": "Mrays/sec + ms/frame at 1920x1080, cornellbox_suzanne, 1/2/4/8 GPU",
@@ -173,12 +174,15 @@ def main():
                        "nodes_per_ray": round(nodes / rays, 3), "tris_per_ray": round(tris / rays, 3),
                        "mtrace_calls_per_s": round(trace_calls / elapsed / 1e6, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": hbm_traffic("k_render_sm") if world == 1 else None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "k_render_sm", "kernel_avg_ms": round(kernel_avg_ms, 3),
                          "algorithmic_bytes_per_launch": int(alg_bytes_launch),
-                         "note": "algorithmic bytes = nodes*64 + tris*76 + rays*80 (SURVEY 8(d)). The 92 KB BVH of this "
-                                 "scene is staged in LDS, so these bytes are served on-chip and real HBM traffic is the "
-                                 "per-pass radiance planes + framebuffer (see DESIGN.md and profiles/)"},
+                         "note": "achieved = algorithmic bytes (nodes*64 + tris*76 + rays*80, SURVEY 8(d)) / kernel time, "
+                                 "priced against HBM peak as the contract asks. This scene's 92 KB BVH is staged in LDS, so "
+                                 "those bytes are served on-chip (frac can exceed 1); measured HBM traffic is `traffic` "
+                                 "(radiance planes + frame, rocprofv3 PMC) = %s GB/s. The kernel is VALU-issue bound "
+                                 "(SQ_ACTIVE_INST_VALU 89%% of SIMD cycles, profiles/). HBM-resident scenes: DESIGN.md 7."
+                                 % (round(traffic / (kernel_avg_ms * 1e-3) / 1e9, 1) if traffic else "n/a")},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frame, plane, mpl)
