@@ -128,3 +128,31 @@ def test_facade_render_and_trace_on_gpu(driver, tmp_path):
     h = ref["hit"] == 1
     for f in ("faceID", "t", "u", "v", "normal"):
         assert rec[f][h].tobytes() == ref[f][h].tobytes(), f
+
+
+@pytest.mark.gpu
+def test_facade_build_routes_large_meshes_to_the_device_builder(driver, tmp_path):
+    """BVHAccel::Build sends meshes of >= 65536 triangles to mgpu_bvh_build_device; the tree must equal the host
+    builder's (and MALLIE_BVH_BUILD=host must give the same file)."""
+    from mallie_amd.scenes import suzanne_grid
+    c = O.load_golden("cornell_obj")
+    verts, faces, _, _ = suzanne_grid(c["verts"], c["faces"], 9)          # 78 408 triangles
+    assert len(faces) >= 65536
+    obj = str(tmp_path / "grid9.obj")
+    with open(obj, "w") as f:
+        for v in verts:
+            f.write("v %r %r %r\n" % (float(v[0]), float(v[1]), float(v[2])))
+        for a, b, cc in faces:
+            f.write("f %d %d %d\n" % (a + 1, b + 1, cc + 1))
+    out = {}
+    for mode in ("device", "host"):
+        prefix = str(tmp_path / ("m_" + mode))
+        env = dict(os.environ, MALLIE_BVH_BUILD=mode)
+        r = subprocess.run([driver, "mesh", "obj", obj, "1.0", prefix], capture_output=True, text=True, env=env,
+                           cwd=str(tmp_path))
+        assert r.returncode == 0, r.stdout + r.stderr
+        out[mode] = read_mesh(prefix)
+    assert np.array_equal(out["device"]["verts"], verts) and np.array_equal(out["device"]["faces"], faces)
+    nodes, idx, _ = M.bvh_build(verts, faces)
+    for mode in ("device", "host"):
+        assert out[mode]["nodes"].tobytes() == nodes.tobytes() and np.array_equal(out[mode]["indices"], idx), mode
