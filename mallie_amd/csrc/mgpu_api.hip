@@ -464,8 +464,16 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   P.out = d_image;
   P.pass_stride = 0;
   const size_t n_floats = 3 * (size_t)n_rows * (size_t)win_w;
+  // Passes are rendered `group` at a time so that the per-pass planes stay below a fixed budget (1 GiB unless
+  // MGPU_PLANES_MAX_MB says otherwise); k_accumulate carries the running float sum from one group to the next, so the
+  // additions and their order are those of a single launch.
+  int group = passes;
   if (kern != 0 && passes > 1) {
-    const size_t need = n_floats * (size_t)passes;
+    size_t budget = (size_t)1 << 30;
+    if (const char *e = getenv("MGPU_PLANES_MAX_MB")) budget = (size_t)(atoll(e) < 1 ? 1 : atoll(e)) << 20;
+    const size_t fit = budget / (n_floats * sizeof(float));
+    if ((size_t)group > fit) group = fit < 1 ? 1 : (int)fit;
+    const size_t need = n_floats * (size_t)group;
     if (need > s->planes_floats) {
       if (s->p_planes) {
         HIP_TRY(hipDeviceSynchronize());
@@ -481,7 +489,6 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
     P.out = s->p_planes;
     P.pass_stride = n_floats;
   }
-  P.work_counter = s->p_counters + (size_t)(s->launch_seq++ % kCounterRing) * kShards;
   P.stats = s->p_stats;
   P.lds_nodes_bytes = (uint32_t)(sizeof(MgpuNode) * s->nn);
   P.lds_tris_bytes = (uint32_t)(sizeof(DTri) * s->nf);
@@ -492,9 +499,7 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   P.wave_log = s->p_wave_log;
   P.probe = s->probe_buf;
   P.probe_pixel = s->probe_pixel;
-  P.probe_pass = s->probe_pass;
 
-  HIP_TRY(hipMemsetAsync(P.work_counter, 0, sizeof(uint32_t) * kShards, st));
   if (stats) {
     HIP_TRY(hipMemsetAsync(s->p_stats, 0, sizeof(unsigned long long) * kStatWords, st));
     HIP_TRY(hipEventRecord(s->ev0, st));
@@ -514,21 +519,36 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
     s->t_used += 2;
     HIP_TRY(hipEventRecord(tev0, st));
   }
-  if (kern == 0) {
-    launch_render(s->cap, dim3((unsigned)blocks), st, s->d, P);
-    HIP_TRY(hipGetLastError());
-  } else {
-    HIP_TRY(launch_render_sm(s->cap, kern == 2, block, dim3((unsigned)blocks), st, shmem, s->d, P));
+  for (int g0 = 0; g0 < passes; g0 += group) {
+    const int g = passes - g0 < group ? passes - g0 : group;
+    P.passes = g;
+    P.pass_base = pass_base + (uint32_t)g0;
+    P.rng_states = d_rng_states ? d_rng_states + (size_t)g0 * (size_t)W * (size_t)H * 4 : nullptr;
+    P.probe_pass = s->probe_pass - (uint32_t)g0; // wraps out of range for passes of other groups
+    P.work_counter = s->p_counters + (size_t)(s->launch_seq++ % kCounterRing) * kShards;
+    HIP_TRY(hipMemsetAsync(P.work_counter, 0, sizeof(uint32_t) * kShards, st));
+    if (kern == 0) {
+      launch_render(s->cap, dim3((unsigned)blocks), st, s->d, P);
+      HIP_TRY(hipGetLastError());
+    } else {
+      HIP_TRY(launch_render_sm(s->cap, kern == 2, block, dim3((unsigned)blocks), st, shmem, s->d, P));
+    }
+    if (g0 + g < passes) { // not the last group: fold it into the image now, the planes are reused
+      launch_accumulate(st, s->p_planes, n_floats, g, n_floats, d_image, d_count, g0 > 0);
+      HIP_TRY(hipGetLastError());
+    }
   }
-  // kernel_ms / the timing ring measure the dominant kernel alone (k_render or k_render_sm), not the pass summation
+  // kernel_ms / the timing ring measure the dominant kernel alone (k_render or k_render_sm) when the passes fit one
+  // group (the benchmarked case); with several groups the interleaved partial sums are inside the bracket
   if (tev1) HIP_TRY(hipEventRecord(tev1, st));
   if (stats) HIP_TRY(hipEventRecord(s->ev1, st));
   if (kern != 0) {
     if (passes > 1) {
-      launch_accumulate(st, s->p_planes, n_floats, passes, n_floats, d_image, d_count);
+      const int last = passes - ((passes - 1) / group) * group;
+      launch_accumulate(st, s->p_planes, n_floats, last, n_floats, d_image, d_count, passes > group);
       HIP_TRY(hipGetLastError());
     } else if (d_count) {
-      launch_accumulate(st, nullptr, 0, 1, n_floats, d_image, d_count); // single pass: only count[px] += 1
+      launch_accumulate(st, nullptr, 0, 1, n_floats, d_image, d_count, false); // single pass: only count[px] += 1
       HIP_TRY(hipGetLastError());
     }
   }

@@ -54,7 +54,7 @@ int pick_stack_cap(int needed_entries);
 hipError_t launch_render_sm(int cap, bool lds_scene, int block, dim3 grid, hipStream_t s, size_t shmem, const DScene &sc,
                             const RenderParams &p);
 void launch_accumulate(hipStream_t s, const float *planes, size_t plane_stride, int passes, size_t n_floats, float *image,
-                       int32_t *count);
+                       int32_t *count, bool resume);
 void launch_tonemap(hipStream_t s, const float *image, const int32_t *count, size_t npix, int mode, unsigned char *out);
 constexpr size_t kLdsBudget = 160 * 1024; // bytes of LDS per CU on gfx950
 

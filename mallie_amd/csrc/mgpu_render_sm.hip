@@ -519,13 +519,14 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
 
 // =====================================================================================================================
 // k_accumulate: image[px] = pass 0 + pass 1 + ... in float32, in pass order (AccumImage, main_sdl.cc:138-143); count += passes
+// `resume`: the planes hold a later group of passes and the sum continues from the image's current value.
 // =====================================================================================================================
 __global__ __launch_bounds__(256) void k_accumulate(const float *__restrict__ planes, size_t plane_stride, int passes,
                                                      size_t n_floats, float *__restrict__ image,
-                                                     int32_t *__restrict__ count) {
+                                                     int32_t *__restrict__ count, bool resume) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (planes && i < n_floats) { // planes == null: single pass already written in place, only count is due
-    float acc = 0.f;
+    float acc = resume ? image[i] : 0.f;
     for (int p = 0; p < passes; ++p) acc += planes[(size_t)p * plane_stride + i];
     image[i] = acc;
   }
@@ -533,9 +534,10 @@ __global__ __launch_bounds__(256) void k_accumulate(const float *__restrict__ pl
 }
 
 void launch_accumulate(hipStream_t s, const float *planes, size_t plane_stride, int passes, size_t n_floats, float *image,
-                       int32_t *count) {
+                       int32_t *count, bool resume) {
   const unsigned blocks = (unsigned)((n_floats + 255) / 256);
-  hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, s, planes, plane_stride, passes, n_floats, image, count);
+  hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, s, planes, plane_stride, passes, n_floats, image, count,
+                     resume);
 }
 
 // =====================================================================================================================

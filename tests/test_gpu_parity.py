@@ -193,6 +193,25 @@ def test_render_hash_mode_vs_oracle(mpl, passes):
     assert ost["garbage_hits"] == 0
 
 
+def test_pass_groups_keep_the_accumulation_order(monkeypatch):
+    """Many passes rendered in groups (bounded per-pass plane memory) give the bits of the single-launch sum and of the
+    oracle's Render + AccumImage loop; count advances by the total."""
+    sc, osc = gpu_scene("cornell_obj"), O.scene_from_golden("cornell_obj")
+    W, H, passes = 320, 288, 7  # one plane = 1.05 MiB
+    frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    plane = osc.plane()
+    ref, rcount, rst = sc.render(frame, W, H, 6, passes, plane, M.RNG_HASH, seed=11, pass_base=2)
+    oimg, ocount, _, _ = osc.render(frame, W, H, 6, passes, plane, O.RNG_HASH, seed=11, pass_base=2)
+    assert_images_match(ref, oimg, "ungrouped")
+    for mb in ("1", "2", "3"):  # groups of 1, 1 and 2 passes -> 7, 7 and 4 launches
+        monkeypatch.setenv("MGPU_PLANES_MAX_MB", mb)
+        img, count, st = sc.render(frame, W, H, 6, passes, plane, M.RNG_HASH, seed=11, pass_base=2)
+        assert np.array_equal(img.view("u4"), ref.view("u4")), "grouped by %s MiB" % mb
+        assert np.array_equal(count, rcount) and int(count[0, 0]) == passes
+        assert (st["trace_calls"], st["paths"], st["real_rays"]) == (rst["trace_calls"], rst["paths"], rst["real_rays"])
+    monkeypatch.delenv("MGPU_PLANES_MAX_MB")
+
+
 def test_render_materials_and_no_matids():
     """materials_ filled (the .vox path of the reference) incl. an out-of-range id -> default 0.5; and a mesh without
     materialIDs (every hit carries 0xFFFFFFFF: throughput never multiplied)."""
