@@ -71,6 +71,10 @@ struct MgpuScene {
   size_t t_used = 0;            // events used since the last mgpu_timing_read
   float *p_planes = nullptr;   // per-pass radiance planes of k_render_sm (grow-only)
   size_t planes_floats = 0;
+  uint32_t *p_tile_cost = nullptr;  // per 8x8 tile: cost of the last launch's pass 0 (k_render_sm), feeds k_order_tiles
+  uint32_t *p_tile_order = nullptr; // hand-out order of the current launch
+  size_t tile_cap = 0;
+  long long tile_key[6] = {-1, -1, -1, -1, -1, -1}; // window/strip layout the costs belong to
   unsigned long long *p_wave_log = nullptr; // 4 words x 16384 waves, diagnostic
   double *probe_buf = nullptr; // set only for the duration of mgpu_probe_path
   uint32_t probe_pixel = 0, probe_pass = 0;
@@ -311,7 +315,7 @@ int mgpu_scene_destroy(MgpuScene *s) {
   (void)hipSetDevice(s->device);
   (void)hipDeviceSynchronize();
   void *ptrs[] = {s->p_nodes, s->p_tris, s->p_slotn, s->p_mat, s->p_verts, s->p_faces, s->p_fvn, s->p_fvuv,
-                  s->p_overflow, s->p_counters, s->p_stats, s->p_planes, s->p_wave_log};
+                  s->p_overflow, s->p_counters, s->p_stats, s->p_planes, s->p_wave_log, s->p_tile_cost, s->p_tile_order};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -422,6 +426,7 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   }
   if (kern == 2 && (s->cap > 24 || s->stack_need > s->cap)) kern = 1; // deep trees never fit the LDS budget anyway
   int block = kern == 2 ? 1024 : kBlock;
+  if (kern == 2 && getenv("MGPU_RENDER_BLOCK") && atoi(getenv("MGPU_RENDER_BLOCK")) == 512) block = 512; // experiments
   size_t shmem = (size_t)(block / 64) * s->cap * 64 * sizeof(uint32_t);
   if (kern == 2) {
     if (shmem + scene_lds > kLdsBudget) {
@@ -500,6 +505,36 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   P.probe = s->probe_buf;
   P.probe_pixel = s->probe_pixel;
 
+  // Cost-ordered hand-out (LDS-resident scenes): the tiles that were expensive in the previous launch of this layout go
+  // first, so the launch drains on cheap paths.  MGPU_TILE_ORDER=0 keeps the image order.
+  P.tile_order = nullptr;
+  P.tile_cost = nullptr;
+  bool use_order = kern == 2 && tiles >= 2 * blocks;
+  if (const char *e = getenv("MGPU_TILE_ORDER")) use_order = use_order && atoi(e) != 0;
+  if (use_order) {
+    if (tiles > s->tile_cap) {
+      HIP_TRY(hipDeviceSynchronize());
+      if (s->p_tile_cost) { HIP_TRY(hipFree(s->p_tile_cost)); s->p_tile_cost = nullptr; }
+      if (s->p_tile_order) { HIP_TRY(hipFree(s->p_tile_order)); s->p_tile_order = nullptr; }
+      s->device_bytes -= 2 * s->tile_cap * sizeof(uint32_t);
+      s->tile_cap = 0;
+      rc = dev_alloc(s, (void **)&s->p_tile_cost, tiles * sizeof(uint32_t));
+      if (rc) return rc;
+      rc = dev_alloc(s, (void **)&s->p_tile_order, tiles * sizeof(uint32_t));
+      if (rc) return rc;
+      s->tile_cap = tiles;
+      s->tile_key[0] = -1;
+    }
+    const long long key[6] = {win_w, n_rows, x0, y_first, strip_h, y_period};
+    if (memcmp(key, s->tile_key, sizeof(key)) != 0) {
+      HIP_TRY(hipMemsetAsync(s->p_tile_cost, 0, tiles * sizeof(uint32_t), st)); // all-zero costs = image order
+      memcpy(s->tile_key, key, sizeof(key));
+    }
+    P.tile_order = s->p_tile_order;
+    P.tile_cost = s->p_tile_cost;
+    launch_order_tiles(st, s->p_tile_cost, (uint32_t)tiles, s->p_tile_order); // outside the kernel-time bracket
+    HIP_TRY(hipGetLastError());
+  }
   if (stats) {
     HIP_TRY(hipMemsetAsync(s->p_stats, 0, sizeof(unsigned long long) * kStatWords, st));
     HIP_TRY(hipEventRecord(s->ev0, st));
@@ -520,6 +555,10 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
     HIP_TRY(hipEventRecord(tev0, st));
   }
   for (int g0 = 0; g0 < passes; g0 += group) {
+    if (use_order && g0 > 0) {
+      launch_order_tiles(st, s->p_tile_cost, (uint32_t)tiles, s->p_tile_order);
+      HIP_TRY(hipGetLastError());
+    }
     const int g = passes - g0 < group ? passes - g0 : group;
     P.passes = g;
     P.pass_base = pass_base + (uint32_t)g0;

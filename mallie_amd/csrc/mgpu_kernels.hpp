@@ -38,6 +38,10 @@ struct RenderParams {
   size_t pass_stride; // floats between consecutive pass planes of `out` (0 when passes == 1)
   uint32_t *work_counter;        // device, kShards words (k_render v1 uses the first), zeroed before the launch
   unsigned long long *stats;     // device, kStatWords, accumulated
+  // Cost-ordered hand-out (k_render_sm): tile_order[i] = the tile handed out i-th (most expensive first, from the
+  // previous launch's costs), or null = image order; tile_cost[tile] accumulates this launch's cost of pass 0.
+  const uint32_t *tile_order;
+  uint32_t *tile_cost;
   uint32_t lds_nodes_bytes, lds_tris_bytes; // k_render_sm<LDS_SCENE>: bytes of nodes / triangles staged into LDS
   unsigned long long *wave_log;  // device or null: 4 words per wave (diagnostic builds only)
   double *probe;                 // device or null: kProbeStride doubles per PathTrace iteration of ONE path
@@ -55,7 +59,9 @@ hipError_t launch_render_sm(int cap, bool lds_scene, int block, dim3 grid, hipSt
                             const RenderParams &p);
 void launch_accumulate(hipStream_t s, const float *planes, size_t plane_stride, int passes, size_t n_floats, float *image,
                        int32_t *count, bool resume);
+// tile_order[0..n) = tile indices by descending cost (256 log buckets); zeroes cost[]. One workgroup.
+void launch_order_tiles(hipStream_t s, uint32_t *cost, uint32_t n_tiles, uint32_t *order);
 void launch_tonemap(hipStream_t s, const float *image, const int32_t *count, size_t npix, int mode, unsigned char *out);
-constexpr size_t kLdsBudget = 160 * 1024; // bytes of LDS per CU on gfx950
+constexpr size_t kLdsBudget = 160 * 1024 - 64; // bytes of LDS per CU on gfx950, less the kernels' static cursor words
 
 } // namespace mgpu

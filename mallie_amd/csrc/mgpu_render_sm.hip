@@ -44,6 +44,13 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 // 4 waves per SIMD (<= 128 VGPRs; the compiler then keeps ~40 cold path-state dwords in scratch, touched only by
 // SHADE): measured 12.3 -> 9.4 ms on the 1M-triangle grid and 38.7 -> 28.0 ms on teapot vs the natural 175-VGPR /
 // 2-wave allocation; 5 and 6 waves spill into the NODE / TRI bodies and lose (11.1 / 15.6 ms).
+// items a workgroup reserves per global-counter fetch: 16 waves share them with the BVH in LDS, 4 waves otherwise
+#ifndef MGPU_WG_CHUNK_LDS
+#define MGPU_WG_CHUNK_LDS 16
+#endif
+#ifndef MGPU_WG_CHUNK_HBM
+#define MGPU_WG_CHUNK_HBM 8
+#endif
 #ifndef MGPU_SM_MIN_WAVES
 #define MGPU_SM_MIN_WAVES 4
 #endif
@@ -78,19 +85,35 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
   const uint32_t tiles_y = (uint32_t)(P.n_rows + 7) >> 3;
   const uint32_t total_tiles = tiles_x * tiles_y;
 
-  // wave-uniform work cursor: chunk of items [item_next, item_end), path cursor inside the current item
+  // Work cursor.  The unit handed to a wave is one item = (8x8 tile, pass) = 64 eye paths; `in_item` is the wave's
+  // position inside its current item (wave-uniform).  Items come from a two-level counter: the workgroup reserves
+  // kWgChunk items at a time from one of kShards global counters (one per XCD: less contention on each, a workgroup
+  // draws from its own XCD's counter first) into an LDS cursor, and its waves take single items from that cursor with
+  // one LDS atomic.  Compared with every wave reserving its own chunk this needs ~10x fewer global atomics (thousands
+  // of waves crossing a cheap region used to queue up on the counters) and it leaves less reserved-but-unstarted work
+  // per CU when the counters run dry, i.e. a more even end of the launch.
+  // HBM-resident scenes: part s = the s-th CONTIGUOUS eighth of the items, so the waves of one XCD (one L2) walk one
+  // image region.  LDS-resident scenes have no L2 locality to protect: part s = every 8th item (item = k * kShards + s),
+  // which balances the parts by construction.
   const uint32_t total_items = total_tiles * (uint32_t)P.passes;
-  uint32_t item_next = 0, item_end = 0, in_item = 64;
+  uint32_t in_item = 64;
   bool exhausted = false;
-  // The item range is dealt to kShards work counters, one per XCD (less contention on each; a wave draws from its own
-  // XCD's counter first).  HBM-resident scenes: part s = the s-th CONTIGUOUS eighth of the items, so the waves of one
-  // XCD (one L2) walk one image region.  LDS-resident scenes have no L2 locality to protect: part s = every 8th item
-  // (item = k * kShards + s), which balances the parts by construction.
-  constexpr uint32_t kChunk = LDS_SCENE ? (uint32_t)kChunkItemsLds : (uint32_t)kChunkItemsHbm;
+  constexpr uint32_t kWgChunk = LDS_SCENE ? (uint32_t)MGPU_WG_CHUNK_LDS : (uint32_t)MGPU_WG_CHUNK_HBM;
   const uint32_t shard_items = (total_items + (uint32_t)kShards - 1) / (uint32_t)kShards;
-  uint32_t home_shard = 0, shard_off = 0, cur_shard = 0;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(home_shard)); // which XCD this wave runs on (0..7)
+  uint32_t home_shard = 0;
+  uint32_t item_tile = 0, item_pass = 0; // wave-uniform: tile and pass of the current item
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(home_shard)); // which XCD this workgroup runs on (0..7)
   home_shard &= 7u;
+  // LDS cursor: hi32 = end, lo32 = next, both (shard << 28) | index of the item inside its shard's part
+  __shared__ unsigned long long wg_cursor;
+  __shared__ uint32_t wg_lock, wg_shard_off, wg_dry;
+  if (threadIdx.x == 0) {
+    wg_cursor = 0ull;
+    wg_lock = 0u;
+    wg_shard_off = 0u;
+    wg_dry = 0u;
+  }
+  __syncthreads();
 
   // ---- per-lane path state --------------------------------------------------------------------------------------
   int st = ST_SHADE;       // everybody starts by asking for work
@@ -103,6 +126,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
   double thr0 = 1, thr1 = 1, thr2 = 1, rad0 = 0, rad1 = 0, rad2 = 0;
   int pathLength = 1;
   uint32_t last_mat = kNoMaterial;
+  uint32_t cost_base = 0;  // n_nodes + n_tris + 16 * n_rays when the current path started
   // ---- per-lane traversal state ---------------------------------------------------------------------------------
   double ix = 0, iy = 0, iz = 0;
   bool sx = false, sy = false, sz = false;
@@ -352,6 +376,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
             dst[0] = (float)rad0;
             dst[1] = (float)rad1;
             dst[2] = (float)rad2;
+            if (P.tile_cost && pass == 0) // what this path cost, for the next launch's hand-out order
+              atomicAdd(P.tile_cost + ((ly >> 3) * tiles_x + (lx >> 3)), n_nodes + n_tris + 16u * n_rays - cost_base);
           }
         }
         have_ray = false;
@@ -365,50 +391,80 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
       for (;;) {
         const unsigned long long want = __ballot(want_pixel);
         if (!want || exhausted) break;
-        if (in_item >= 64) { // current item used up: take the next one, refilling the chunk when it is empty
-          if (item_next >= item_end) {
-            // XCD-aware draw: the item range is cut into kShards contiguous parts, one per XCD, so the waves of one XCD
-            // (one L2) walk one image region; a wave whose home part is used up moves on to the next part for good
-            bool got = false;
-            while (shard_off < (uint32_t)kShards) {
-              const uint32_t sh = (home_shard + shard_off) % (uint32_t)kShards;
-              uint32_t base = 0;
-              if (lane == 0) base = atomicAdd(P.work_counter + sh, kChunk);
-              base = __shfl(base, 0);
-              // local index range of part sh: [0, n_sh)
-              const uint32_t n_sh = LDS_SCENE ? (total_items > sh ? (total_items - sh + (uint32_t)kShards - 1) / (uint32_t)kShards : 0u)
-                                              : (sh * shard_items < total_items ? min(shard_items, total_items - sh * shard_items) : 0u);
-              if (base < n_sh) {
-                cur_shard = sh;
-                item_next = base;                                     // LOCAL indices within the part
-                item_end = min(base + kChunk, n_sh);
-                got = true;
-                break;
-              }
-              ++shard_off;
+        if (in_item >= 64) { // current item used up: take the next one from the workgroup's cursor
+          uint32_t cur_shard = 0, item_local = 0;
+          for (;;) {
+            unsigned long long c = 0;
+            if (lane == 0) c = atomicAdd(&wg_cursor, 1ull);
+            const uint32_t nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)c);
+            const uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(c >> 32));
+            if (nxt < end) {
+              cur_shard = nxt >> 28;
+              item_local = nxt & 0x0fffffffu;
+              break;
             }
-            if (!got) { exhausted = true; item_end = item_next = total_items; break; }
+            // the workgroup's reservation is used up: one wave refills it, the others come back and retry
+            uint32_t flag = 0;
+            if (lane == 0) flag = __hip_atomic_load(&wg_dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__builtin_amdgcn_readfirstlane((int)flag)) { exhausted = true; break; }
+            uint32_t won = 0;
+            if (lane == 0) won = (atomicCAS(&wg_lock, 0u, 1u) == 0u) ? 1u : 0u;
+            if (!__builtin_amdgcn_readfirstlane((int)won)) {
+              __builtin_amdgcn_s_sleep(4);
+              continue;
+            }
+            if (lane == 0) {
+              const unsigned long long now = atomicAdd(&wg_cursor, 0ull);
+              if ((uint32_t)now >= (uint32_t)(now >> 32)) { // still empty (nobody refilled it while we took the lock)
+                bool got = false;
+                uint32_t off = wg_shard_off;
+                while (off < (uint32_t)kShards) {
+                  // a workgroup whose home part is used up moves on to the next part for good
+                  const uint32_t sh = (home_shard + off) % (uint32_t)kShards;
+                  const uint32_t base = atomicAdd(P.work_counter + sh, kWgChunk);
+                  // index range of part sh: [0, n_sh)
+                  const uint32_t n_sh = LDS_SCENE ? (total_items > sh ? (total_items - sh + (uint32_t)kShards - 1) / (uint32_t)kShards : 0u)
+                                                  : (sh * shard_items < total_items ? min(shard_items, total_items - sh * shard_items) : 0u);
+                  if (base < n_sh) {
+                    const uint32_t hi = (sh << 28) | min(base + kWgChunk, n_sh), lo = (sh << 28) | base;
+                    atomicExch(&wg_cursor, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+                    got = true;
+                    break;
+                  }
+                  ++off;
+                }
+                wg_shard_off = off;
+                if (!got) __hip_atomic_store(&wg_dry, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+              __threadfence_block();
+              atomicExch(&wg_lock, 0u);
+            }
           }
+          if (exhausted) break;
           in_item = 0;
+          // tile and pass of the new item (tile-major: a tile's passes are consecutive items); with a cost order the
+          // i-th tile handed out is tile_order[i]: most expensive first, so that the launch ends on cheap paths
+          const uint32_t item = LDS_SCENE ? item_local * (uint32_t)kShards + cur_shard : cur_shard * shard_items + item_local;
+          const uint32_t ti = item / (uint32_t)P.passes;
+          item_pass = item - ti * (uint32_t)P.passes;
+          item_tile = P.tile_order ? (uint32_t)__builtin_amdgcn_readfirstlane((int)P.tile_order[ti]) : ti;
         }
         if (want_pixel) {
           const uint32_t rank = __popcll(want & ((1ull << lane) - 1ull));
           const uint32_t slot = in_item + rank;
           if (slot < 64) {
-            const uint32_t item = LDS_SCENE ? item_next * (uint32_t)kShards + cur_shard : cur_shard * shard_items + item_next;
-            const uint32_t tile = item / (uint32_t)P.passes; // tile-major: a tile's passes are consecutive items
-            const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+            const uint32_t tx = item_tile % tiles_x, ty = item_tile / tiles_x;
             const uint32_t x = tx * 8 + (slot & 7), y = ty * 8 + (slot >> 3);
             if (x < (uint32_t)win_w && y < (uint32_t)P.n_rows) { // slots of an edge tile outside the window are skipped
               lx = x; ly = y;
-              pass = (int)(item % (uint32_t)P.passes);
+              pass = (int)item_pass;
               have_path = true;
               want_pixel = false;
             }
           }
         }
         in_item += (uint32_t)__popcll(want);
-        if (in_item >= 64) { in_item = 64; ++item_next; }
+        if (in_item >= 64) in_item = 64;
       }
 
       // ---- (3) next path / next traversal ----
@@ -437,6 +493,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
           rad0 = rad1 = rad2 = 0.0;
           pathLength = 1;
           ++paths;
+          cost_base = n_nodes + n_tris + 16u * n_rays;
           path_done = false;
         }
         if (path_done) {
@@ -538,6 +595,68 @@ void launch_accumulate(hipStream_t s, const float *planes, size_t plane_stride, 
   const unsigned blocks = (unsigned)((n_floats + 255) / 256);
   hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, s, planes, plane_stride, passes, n_floats, image, count,
                      resume);
+}
+
+// =====================================================================================================================
+// k_order_tiles: hand-out order of the next launch = tiles by descending cost in the previous one.
+// A persistent launch ends when its last path ends, and a path that bounces four times is in flight ~10x longer than
+// one that leaves through the sky; with tiles handed out in image order the launch drains for up to ~1 ms on whatever
+// expensive paths happened to come last.  Longest-processing-time-first: expensive tiles go first, and the waves chew
+// on sky tiles while their last expensive paths finish.
+// Counting sort on 256 logarithmic cost buckets, one 1024-thread workgroup; the order inside a bucket is arbitrary,
+// which is harmless: the image does not depend on the order (per-(pixel, pass) RNG).  All-zero costs (first launch of
+// a layout) give the image order.  cost[] is zeroed for the next launch.
+// =====================================================================================================================
+__global__ __launch_bounds__(1024) void k_order_tiles(uint32_t *__restrict__ cost, uint32_t n, uint32_t *__restrict__ order) {
+  __shared__ uint32_t hist[256], start[256];
+  __shared__ uint32_t any;
+  const uint32_t tid = threadIdx.x;
+  if (tid < 256) hist[tid] = 0;
+  if (tid == 0) any = 0;
+  __syncthreads();
+  // bucket = 8 * floor(log2(cost)) + next three bits, clamped to 255; larger cost -> larger bucket
+  auto bucket = [](uint32_t c) -> uint32_t {
+    if (c < 8) return c;
+    const uint32_t e = 31u - (uint32_t)__clz((int)c);
+    const uint32_t b = 8u * (e - 2u) + ((c >> (e - 3u)) & 7u);
+    return b > 255u ? 255u : b;
+  };
+  uint32_t seen = 0;
+  for (uint32_t i = tid; i < n; i += 1024) {
+    const uint32_t c = cost[i];
+    seen |= c;
+    atomicAdd(&hist[bucket(c)], 1u);
+  }
+  if (seen) any = 1;
+  __syncthreads();
+  if (!any) {
+    for (uint32_t i = tid; i < n; i += 1024) order[i] = i;
+    return;
+  }
+  if (tid < 64) { // exclusive scan over the buckets, most expensive first: lane l owns buckets 255-4l .. 252-4l
+    const uint32_t b0 = 255u - 4u * tid;
+    const uint32_t h0 = hist[b0], h1 = hist[b0 - 1], h2 = hist[b0 - 2], h3 = hist[b0 - 3];
+    uint32_t incl = h0 + h1 + h2 + h3;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t v = __shfl_up(incl, off);
+      if ((int)tid >= off) incl += v;
+    }
+    const uint32_t excl = incl - (h0 + h1 + h2 + h3);
+    start[b0] = excl;
+    start[b0 - 1] = excl + h0;
+    start[b0 - 2] = excl + h0 + h1;
+    start[b0 - 3] = excl + h0 + h1 + h2;
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += 1024) {
+    const uint32_t c = cost[i];
+    order[atomicAdd(&start[bucket(c)], 1u)] = i;
+    cost[i] = 0;
+  }
+}
+
+void launch_order_tiles(hipStream_t s, uint32_t *cost, uint32_t n_tiles, uint32_t *order) {
+  hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(1024), 0, s, cost, n_tiles, order);
 }
 
 // =====================================================================================================================
