@@ -150,6 +150,11 @@ int mgpu_debug_words(MgpuScene *scene, unsigned long long *out32);
 /* Diagnostic (MGPU_WAVE_LOG=1 + -DMGPU_UTIL builds): per-wave {start tick, end tick, rays, XCC id}. */
 int mgpu_debug_wave_log(MgpuScene *scene, unsigned long long *out, size_t n_waves);
 
+/* Diagnostic: the cost-ordered hand-out state of the last render launch: per 8x8 tile (row-major over the rendered
+ * window) the cost measured by that launch, and the order in which it handed the tiles out.  Either pointer may be NULL;
+ * n_tiles must not exceed the launch's tile count.  Synchronises the device. */
+int mgpu_debug_tile_order(MgpuScene *scene, uint32_t *cost_out, uint32_t *order_out, size_t n_tiles);
+
 /* Per-launch kernel timing for asynchronous use: after mgpu_timing_enable(scene, 1) every mgpu_render_strips_device call
  * made with stats == NULL brackets its kernel with HIP events on the launch stream (no synchronisation).
  * mgpu_timing_read synchronises, returns the summed kernel time and the number of launches since the last read, and

@@ -691,6 +691,17 @@ int mgpu_debug_words(MgpuScene *s, unsigned long long *out32) {
   return MGPU_OK;
 }
 
+int mgpu_debug_tile_order(MgpuScene *s, uint32_t *cost_out, uint32_t *order_out, size_t n_tiles) {
+  if (!s) return fail(MGPU_ERR_INVALID, "NULL argument");
+  if (!s->p_tile_cost || n_tiles > s->tile_cap) return fail(MGPU_ERR_INVALID, "no tile order for %zu tiles", n_tiles);
+  int rc = set_device(s);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  if (cost_out) HIP_TRY(hipMemcpy(cost_out, s->p_tile_cost, sizeof(uint32_t) * n_tiles, hipMemcpyDeviceToHost));
+  if (order_out) HIP_TRY(hipMemcpy(order_out, s->p_tile_order, sizeof(uint32_t) * n_tiles, hipMemcpyDeviceToHost));
+  return MGPU_OK;
+}
+
 int mgpu_debug_wave_log(MgpuScene *s, unsigned long long *out, size_t n_waves) {
   if (!s || !out || !s->p_wave_log || n_waves > 16384) return fail(MGPU_ERR_INVALID, "no wave log");
   HIP_TRY(hipDeviceSynchronize());

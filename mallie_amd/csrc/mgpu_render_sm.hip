@@ -51,6 +51,12 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 #ifndef MGPU_WG_CHUNK_HBM
 #define MGPU_WG_CHUNK_HBM 8
 #endif
+#ifndef MGPU_NODES_PER_STEP
+#define MGPU_NODES_PER_STEP 4
+#endif
+#ifndef MGPU_TRIS_PER_STEP
+#define MGPU_TRIS_PER_STEP 16
+#endif
 #ifndef MGPU_SM_MIN_WAVES
 #define MGPU_SM_MIN_WAVES 4
 #endif
@@ -168,6 +174,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
 #ifdef MGPU_UTIL
         if (lane == __ffsll((long long)mN) - 1) u_node++;
 #endif
+#pragma unroll 1
+        for (int rep = 0; rep < MGPU_NODES_PER_STEP; ++rep) {
         const uint32_t ni = stk.get(sp);
         --sp;
         ++n_nodes;
@@ -211,6 +219,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
             st = ST_TRI;
           }
         }
+        if (st != ST_NODE || sp < 0) break;
+        }
         if (st == ST_NODE && sp < 0) st = ST_SHADE;
       }
       MGPU_TOCK(cyc_node);
@@ -221,6 +231,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
 #ifdef MGPU_UTIL
         if (lane == __ffsll((long long)mT) - 1) u_tri++;
 #endif
+#pragma unroll 1
+        for (int rep = 0; rep < MGPU_TRIS_PER_STEP; ++rep) {
         double2 a0, a1, a2, a3;
         double e2z;
         if (LDS_SCENE) {
@@ -259,6 +271,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
           }
         }
         ++tri_cur;
+        if (tri_cur == tri_end) break;
+        }
         if (tri_cur == tri_end) st = (sp < 0) ? ST_SHADE : ST_NODE;
       }
       MGPU_TOCK(cyc_tri);

@@ -85,6 +85,8 @@ def load_library():
     L.mgpu_stats_read.restype = i32
     L.mgpu_debug_words.argtypes = [vp, vp]
     L.mgpu_debug_words.restype = i32
+    L.mgpu_debug_tile_order.argtypes = [vp, vp, vp, sz]
+    L.mgpu_debug_tile_order.restype = i32
     L.mgpu_debug_wave_log.argtypes = [vp, vp, sz]
     L.mgpu_debug_wave_log.restype = i32
     L.mgpu_timing_enable.argtypes = [vp, i32]
@@ -274,6 +276,12 @@ class Scene:
         w = np.zeros(32, "<u8")
         _check(load_library().mgpu_debug_words(self.h, _p(w)), "mgpu_debug_words")
         return w
+
+    def tile_order(self, n_tiles):
+        """(cost, order) of the last render launch's cost-ordered hand-out, n_tiles = ceil(w/8) * ceil(rows/8)."""
+        cost, order = np.zeros(n_tiles, "<u4"), np.zeros(n_tiles, "<u4")
+        _check(load_library().mgpu_debug_tile_order(self.h, _p(cost), _p(order), n_tiles), "mgpu_debug_tile_order")
+        return cost, order
 
     def wave_log(self, n_waves):
         w = np.zeros((n_waves, 4), "<u8")
