@@ -457,6 +457,16 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   if (plane) memcpy(P.plane, plane, sizeof(P.plane));
   else memset(P.plane, 0, sizeof(P.plane));
   P.has_plane = plane ? 1 : 0;
+  {
+    // real3::normalize of the plane normal (common.h:48-56): sqrt and division are IEEE-exact on both sides
+    double n[3] = {(double)P.plane[0], (double)P.plane[1], (double)P.plane[2]};
+    const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    if (std::fabs(len) > 1.0e-6) {
+      const double inv = 1.0 / len;
+      n[0] *= inv; n[1] *= inv; n[2] *= inv;
+    }
+    memcpy(P.plane_n, n, sizeof(n));
+  }
   P.W = W; P.H = H; P.x0 = x0; P.x1 = x1;
   P.y_first = y_first; P.strip_h = strip_h; P.y_period = y_period; P.n_rows = n_rows;
   P.maxPathLength = maxPathLength; P.passes = passes;

@@ -240,7 +240,8 @@ __device__ __forceinline__ void traverse(const DScene &sc, const Stack<CAP, OVF>
 
 // ---- Plane::intersect (prim-plane.cc:8-44): float core, double outputs ------------------------------------------------
 // Returns true and overwrites t / normal when the plane is hit closer than `t`.
-__device__ __forceinline__ bool plane_hit(const float pl[4], V3 org, V3 dir, double &t_io, V3 &normal) {
+// `unit_n` = normalized((double)pl[0..2]) computed once on the host (the same IEEE sqrt / division).
+__device__ __forceinline__ bool plane_hit(const float pl[4], const double unit_n[3], V3 org, V3 dir, double &t_io, V3 &normal) {
   V3 n = v3((double)pl[0], (double)pl[1], (double)pl[2]);
   const V3 v = normalized(dir);
   const float vn = (float)dot(v, n);
@@ -249,7 +250,7 @@ __device__ __forceinline__ bool plane_hit(const float pl[4], V3 org, V3 dir, dou
     const float t = -on_d / vn;
     if ((t > 0) && ((double)t < t_io)) {
       t_io = (double)t;
-      normal = normalized(n);
+      normal = v3(unit_n[0], unit_n[1], unit_n[2]);
       return true;
     }
   }

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kBlock, MGPU_RENDER_MIN_WAVES) void k_render(DScene
           n = v3(gn[0], gn[1], gn[2]);
         }
       }
-      if (P.has_plane && plane_hit(P.plane, org, dir, t, n)) {
+      if (P.has_plane && plane_hit(P.plane, P.plane_n, org, dir, t, n)) {
         hit = true;
         last_mat = kNoMaterial; // prim-plane.cc:34
       }

@@ -23,6 +23,7 @@ enum : int { kStatTraceCalls = 0, kStatRays = 1, kStatNodes = 2, kStatTris = 3, 
 struct RenderParams {
   double frame[12]; // origin, corner, du, dv  (Camera::BuildCameraFrame, camera.cc:40-220)
   float plane[4];
+  double plane_n[3]; // normalize((double)plane[0..2]), the normal Plane::intersect returns (prim-plane.cc:30-33); host-computed
   int has_plane;
   int W, H;         // full frame (RNG tables and hash seeds index the full frame)
   int x0, x1;       // window columns
@@ -62,6 +63,6 @@ void launch_accumulate(hipStream_t s, const float *planes, size_t plane_stride, 
 // tile_order[0..n) = tile indices by descending cost (256 log buckets); zeroes cost[]. One workgroup.
 void launch_order_tiles(hipStream_t s, uint32_t *cost, uint32_t n_tiles, uint32_t *order);
 void launch_tonemap(hipStream_t s, const float *image, const int32_t *count, size_t npix, int mode, unsigned char *out);
-constexpr size_t kLdsBudget = 160 * 1024 - 64; // bytes of LDS per CU on gfx950, less the kernels' static cursor words
+constexpr size_t kLdsBudget = 160 * 1024 - 512; // bytes of LDS per CU on gfx950, less the kernels' static cursor words
 
 } // namespace mgpu

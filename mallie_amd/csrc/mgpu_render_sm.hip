@@ -61,7 +61,13 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 #define MGPU_SM_MIN_WAVES 4
 #endif
 template <int CAP, bool LDS_SCENE, int BLOCK, bool OVF>
-__global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) void k_render_sm(DScene sc, RenderParams P) {
+__global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) void k_render_sm(DScene sc, RenderParams P_arg) {
+  // The launch parameters live in LDS, not in scalar registers: the traversal bodies use none of them, SHADE uses
+  // nearly all, and ~60 kernel-argument SGPRs kept alive across the loop were being spilled to VGPR lanes.
+  __shared__ RenderParams s_P;
+  if (threadIdx.x == 0) s_P = P_arg;
+  __syncthreads();
+  const RenderParams &P = s_P;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int kWaves = BLOCK / 64;
   uint32_t *s_stack = reinterpret_cast<uint32_t *>(smem); // [kWaves][CAP][64]
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
               n = v3(gn[0], gn[1], gn[2]);
             }
           }
-          if (P.has_plane && plane_hit(P.plane, org, dir, t, n)) {
+          if (P.has_plane && plane_hit(P.plane, P.plane_n, org, dir, t, n)) {
             hit = true;
             last_mat = kNoMaterial; // prim-plane.cc:34
           }
