@@ -341,8 +341,10 @@ int mgpu_trace(MgpuScene *s, const MgpuRay *rays, size_t n, MgpuIntersection *ou
   if (rc) return rc;
   if (stats) memset(stats, 0, sizeof(*stats));
   if (n == 0) return MGPU_OK;
-  const size_t blocks = (n + kBlock - 1) / kBlock;
-  if (blocks > 0x7FFFFFFFull) return fail(MGPU_ERR_INVALID, "too many rays in one call");
+  size_t blocks = (n + kBlock - 1) / kBlock;
+  size_t resident = (size_t)s->num_cu * 8; // the waves walk the ray array in grid strides
+  if (const char *e = getenv("MGPU_TRACE_BLOCKS_PER_CU")) resident = (size_t)s->num_cu * (size_t)atoi(e);
+  if (blocks > resident) blocks = resident;
   rc = ensure_overflow(s, blocks * kBlock);
   if (rc) return rc;
   MgpuRay *d_rays = nullptr;

@@ -10,86 +10,128 @@
 namespace mgpu {
 
 // =====================================================================================================================
-// k_trace: one lane per ray
+// k_trace: one lane per ray, a wave walks the ray array in strides of the grid (64 consecutive rays per trip).
+// The 184-byte Intersection records of a wave's 64 rays are contiguous in memory: the lanes assemble them in LDS and
+// the wave writes the 11 776 bytes out with full-width stores (a lane storing its own record would touch 64 different
+// cache lines per store instruction).  Counters are reduced per workgroup before the one atomic per word.
 // =====================================================================================================================
+constexpr int kIsectWords = (int)(sizeof(MgpuIntersection) / 4); // 46
+
 template <int CAP>
 __global__ __launch_bounds__(kBlock) void k_trace(DScene sc, const MgpuRay *__restrict__ rays, size_t n,
                                                  MgpuIntersection *__restrict__ out, uint8_t *__restrict__ hit_out,
                                                  unsigned long long *__restrict__ stats) {
-  __shared__ uint32_t s_stack[kBlock / 64][CAP][64];
+  __shared__ __attribute__((aligned(16))) uint32_t s_stack[kBlock / 64][CAP][64];
+  __shared__ unsigned long long s_cnt[3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t gid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const size_t slot = (size_t)blockIdx.x * kBlock + threadIdx.x; // hardware lane slot (stack overflow column)
   Stack<CAP, true> stk;
   stk.lds = &s_stack[wave][0][lane];
-  stk.overflow = sc.stack_overflow ? sc.stack_overflow + gid * sc.overflow_cap : nullptr;
+  stk.overflow = sc.stack_overflow ? sc.stack_overflow + slot * sc.overflow_cap : nullptr;
+  if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0ull;
+  __syncthreads();
   Counters c{};
-  if (gid < n) {
-    const MgpuRay *r = rays + gid;
-    const V3 org = v3(r->org[0], r->org[1], r->org[2]);
-    const V3 dir = v3(r->dir[0], r->dir[1], r->dir[2]);
+  const size_t wave_stride = (size_t)gridDim.x * (kBlock / 64) * 64;
+  for (size_t base = ((size_t)blockIdx.x * (kBlock / 64) + wave) * 64; base < n; base += wave_stride) {
+    const size_t gid = base + lane;
+    const bool live = gid < n;
+    V3 org = v3(0, 0, 0), dir = v3(0, 0, 1);
     Hit h;
-    traverse<CAP, true>(sc, stk, org, dir, h, c);
-    MgpuIntersection is;
-    // a miss leaves t = DBL_MAX, u = v = 0, faceID = -1 (bvh_accel.cc:782-786); every other field is zeroed here
-    is.t = h.t; is.u = h.u; is.v = h.v;
-    is.faceID = 0xFFFFFFFFu; is.materialID = 0; is.f0 = is.f1 = is.f2 = 0; is.pad_ = 0;
-    for (int k = 0; k < 3; ++k) {
-      is.position[k] = 0.0; is.geometricNormal[k] = 0.0; is.normal[k] = 0.0; is.tangent[k] = 0.0; is.binormal[k] = 0.0;
+    h.t = kDblMax; h.u = 0.0; h.v = 0.0; h.slot = kNoHit;
+    if (live) {
+      const MgpuRay *r = rays + gid;
+      org = v3(r->org[0], r->org[1], r->org[2]);
+      dir = v3(r->dir[0], r->dir[1], r->dir[2]);
+      traverse<CAP, true>(sc, stk, org, dir, h, c);
     }
-    is.texcoord[0] = is.texcoord[1] = 0.0;
     // Traverse reports a hit iff isect.t < DBL_MAX (bvh_accel.cc:838): a NaN t (NaN ray) fails that test even though
     // TestLeafNode accepted a triangle and already wrote faceID / materialID.
     const bool hit = h.t < kDblMax;
-    if (!hit && h.slot != kNoHit) {
-      is.faceID = sc.tris[h.slot].face;
-      is.materialID = sc.tris[h.slot].mat;
-    }
-    if (hit) {
-      // BuildIntersection, bvh_accel.cc:699-769
-      const DTri *tp = sc.tris + h.slot;
-      const uint32_t face = tp->face;
-      is.faceID = face;
-      is.materialID = tp->mat;
-      is.f0 = sc.faces[3 * (size_t)face + 0];
-      is.f1 = sc.faces[3 * (size_t)face + 1];
-      is.f2 = sc.faces[3 * (size_t)face + 2];
-      is.position[0] = org.x + h.t * dir.x;
-      is.position[1] = org.y + h.t * dir.y;
-      is.position[2] = org.z + h.t * dir.z;
-      const V3 e1 = v3(tp->e1[0], tp->e1[1], tp->e1[2]), e2 = v3(tp->e2[0], tp->e2[1], tp->e2[2]);
-      const V3 gn = normalized(cross(e1, e2));
-      is.geometricNormal[0] = gn.x; is.geometricNormal[1] = gn.y; is.geometricNormal[2] = gn.z;
-      if (sc.fv_normals) {
-        const double *nn = sc.fv_normals + 9 * (size_t)face;
-        const double w = 1.0 - h.u - h.v;
-        is.normal[0] = w * nn[0] + h.u * nn[3] + h.v * nn[6];
-        is.normal[1] = w * nn[1] + h.u * nn[4] + h.v * nn[7];
-        is.normal[2] = w * nn[2] + h.u * nn[5] + h.v * nn[8];
-      } else {
-        is.normal[0] = gn.x; is.normal[1] = gn.y; is.normal[2] = gn.z;
+    // The wave's traversal stacks are idle now: 16 records at a time are assembled in that LDS area (16 * 184 B = 2944 B
+    // <= CAP * 256 B) by their lanes and streamed out by all 64 lanes.
+    uint32_t *stage = &s_stack[wave][0][0];
+    const size_t cnt = (n - base < 64) ? (n - base) : 64;
+    for (int q = 0; q < 4; ++q) {
+      if (live && (lane >> 4) == q) {
+        MgpuIntersection *is = reinterpret_cast<MgpuIntersection *>(stage + (lane & 15) * kIsectWords);
+        // a miss leaves t = DBL_MAX, u = v = 0, faceID = -1 (bvh_accel.cc:782-786); every other field is zeroed here
+        is->t = h.t; is->u = h.u; is->v = h.v;
+        uint32_t faceID = 0xFFFFFFFFu, materialID = 0, f0 = 0, f1 = 0, f2 = 0;
+        V3 pos = v3(0, 0, 0), gn = v3(0, 0, 0), sn = v3(0, 0, 0);
+        double tc0 = 0.0, tc1 = 0.0;
+        if (!hit && h.slot != kNoHit) {
+          faceID = sc.tris[h.slot].face;
+          materialID = sc.tris[h.slot].mat;
+        }
+        if (hit) {
+          // BuildIntersection, bvh_accel.cc:699-769
+          const DTri *tp = sc.tris + h.slot;
+          const uint32_t face = tp->face;
+          faceID = face;
+          materialID = tp->mat;
+          f0 = sc.faces[3 * (size_t)face + 0];
+          f1 = sc.faces[3 * (size_t)face + 1];
+          f2 = sc.faces[3 * (size_t)face + 2];
+          pos = v3(org.x + h.t * dir.x, org.y + h.t * dir.y, org.z + h.t * dir.z);
+          const V3 e1 = v3(tp->e1[0], tp->e1[1], tp->e1[2]), e2 = v3(tp->e2[0], tp->e2[1], tp->e2[2]);
+          gn = normalized(cross(e1, e2));
+          if (sc.fv_normals) {
+            const double *nn = sc.fv_normals + 9 * (size_t)face;
+            const double w = 1.0 - h.u - h.v;
+            sn = v3(w * nn[0] + h.u * nn[3] + h.v * nn[6], w * nn[1] + h.u * nn[4] + h.v * nn[7],
+                    w * nn[2] + h.u * nn[5] + h.v * nn[8]);
+          } else {
+            sn = gn;
+          }
+          if (sc.fv_uvs) {
+            const double *uv = sc.fv_uvs + 6 * (size_t)face;
+            const double w = 1.0 - h.u - h.v;
+            tc0 = w * uv[0] + h.u * uv[2] + h.v * uv[4];
+            tc1 = w * uv[1] + h.u * uv[3] + h.v * uv[5];
+          }
+        }
+        is->faceID = faceID; is->materialID = materialID; is->f0 = f0; is->f1 = f1; is->f2 = f2; is->pad_ = 0;
+        is->position[0] = pos.x; is->position[1] = pos.y; is->position[2] = pos.z;
+        is->geometricNormal[0] = gn.x; is->geometricNormal[1] = gn.y; is->geometricNormal[2] = gn.z;
+        is->normal[0] = sn.x; is->normal[1] = sn.y; is->normal[2] = sn.z;
+        for (int k = 0; k < 3; ++k) { is->tangent[k] = 0.0; is->binormal[k] = 0.0; }
+        is->texcoord[0] = tc0; is->texcoord[1] = tc1;
       }
-      if (sc.fv_uvs) {
-        const double *uv = sc.fv_uvs + 6 * (size_t)face;
-        const double w = 1.0 - h.u - h.v;
-        is.texcoord[0] = w * uv[0] + h.u * uv[2] + h.v * uv[4];
-        is.texcoord[1] = w * uv[1] + h.u * uv[3] + h.v * uv[5];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int have = (int)cnt - 16 * q; // records of this quarter that exist
+      uint32_t *q_out = reinterpret_cast<uint32_t *>(out + base + 16 * q); // 16-byte aligned: 16 records = 2944 B
+      if (have >= 16) {
+        const uint4 *l4 = reinterpret_cast<const uint4 *>(stage);
+        uint4 *o4 = reinterpret_cast<uint4 *>(q_out);
+        for (int i = lane; i < 16 * kIsectWords / 4; i += 64) o4[i] = l4[i];
+      } else if (have > 0) {
+        for (int i = lane; i < have * kIsectWords; i += 64) q_out[i] = stage[i];
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier(); // the area is rewritten by the next quarter / the next trip's stacks
     }
-    out[gid] = is;
-    hit_out[gid] = hit ? 1 : 0;
+    if (live) hit_out[gid] = hit ? 1 : 0;
   }
-  // counters: one atomic per wave and counter
+  // counters: wave reduction, then one LDS atomic per wave and one global atomic per workgroup and word
   unsigned long long rn = c.rays, nn = c.nodes, tn = c.tris;
   for (int off = 32; off; off >>= 1) {
     rn += __shfl_down(rn, off);
     nn += __shfl_down(nn, off);
     tn += __shfl_down(tn, off);
   }
-  if (lane == 0 && stats) {
-    atomicAdd(&stats[kStatRays], rn);
-    atomicAdd(&stats[kStatNodes], nn);
-    atomicAdd(&stats[kStatTris], tn);
-    atomicAdd(&stats[kStatTraceCalls], rn);
+  if (lane == 0) {
+    atomicAdd(&s_cnt[0], rn);
+    atomicAdd(&s_cnt[1], nn);
+    atomicAdd(&s_cnt[2], tn);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && stats) {
+    atomicAdd(&stats[kStatRays], s_cnt[0]);
+    atomicAdd(&stats[kStatNodes], s_cnt[1]);
+    atomicAdd(&stats[kStatTris], s_cnt[2]);
+    atomicAdd(&stats[kStatTraceCalls], s_cnt[0]);
   }
 }
 
