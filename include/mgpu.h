@@ -110,6 +110,11 @@ size_t mgpu_scene_device_bytes(const MgpuScene *scene);
 /* For each of n rays: out[i] = the Intersection Traverse would fill, hit[i] = its bool result. On a miss out[i] has
  * t = DBL_MAX, u = v = 0, faceID = 0xFFFFFFFF and all other fields zero. stats may be NULL. */
 int mgpu_trace(MgpuScene *scene, const MgpuRay *rays, size_t n, MgpuIntersection *out, uint8_t *hit, MgpuStats *stats);
+/* The same with rays, records and hit flags resident in device memory (d_out 16-byte aligned), enqueued on `stream`
+ * (a hipStream_t, NULL = default stream) without synchronising; with stats != NULL the call waits for the kernel and
+ * returns its counters and time. */
+int mgpu_trace_device(MgpuScene *scene, const MgpuRay *d_rays, size_t n, MgpuIntersection *d_out, uint8_t *d_hit,
+                      void *stream, MgpuStats *stats);
 
 /* -- Render (render.cc:593-708: per-pixel PathTrace, render.cc:381-456) ---------------------------------------------- */
 /* Renders `passes` passes of the window [x0,x1) x [y0,y1) of a W x H frame and returns, per window pixel, the float32

@@ -333,6 +333,43 @@ int mgpu_scene_bbox(const MgpuScene *s, double bmin[3], double bmax[3]) {
 
 size_t mgpu_scene_device_bytes(const MgpuScene *s) { return s ? s->device_bytes : 0; }
 
+int mgpu_trace_device(MgpuScene *s, const MgpuRay *d_rays, size_t n, MgpuIntersection *d_out, uint8_t *d_hit, void *stream,
+                      MgpuStats *stats) {
+  if (!s) return fail(MGPU_ERR_INVALID, "scene is NULL");
+  if (n && (!d_rays || !d_out || !d_hit)) return fail(MGPU_ERR_INVALID, "rays/out/hit must be non-NULL");
+  if ((uintptr_t)d_out & 15u) return fail(MGPU_ERR_INVALID, "d_out must be 16-byte aligned");
+  const double t0 = now_ms();
+  int rc = set_device(s);
+  if (rc) return rc;
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (n == 0) return MGPU_OK;
+  hipStream_t st = (hipStream_t)stream;
+  size_t blocks = (n + kBlock - 1) / kBlock;
+  size_t resident = (size_t)s->num_cu * 8; // the waves walk the ray array in grid strides
+  if (const char *e = getenv("MGPU_TRACE_BLOCKS_PER_CU")) resident = (size_t)s->num_cu * (size_t)(atoi(e) < 1 ? 1 : atoi(e));
+  if (blocks > resident) blocks = resident;
+  rc = ensure_overflow(s, blocks * kBlock);
+  if (rc) return rc;
+  if (stats) {
+    HIP_TRY(hipMemsetAsync(s->p_stats, 0, sizeof(unsigned long long) * kStatWords, st));
+    HIP_TRY(hipEventRecord(s->ev0, st));
+  }
+  launch_trace(s->cap, dim3((unsigned)blocks), st, s->d, d_rays, n, d_out, d_hit, s->p_stats);
+  HIP_TRY(hipGetLastError());
+  if (stats) {
+    HIP_TRY(hipEventRecord(s->ev1, st));
+    unsigned long long w[kStatWords];
+    HIP_TRY(hipMemcpyAsync(w, s->p_stats, sizeof(w), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    read_stats(w, stats);
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    stats->kernel_ms = ms;
+    stats->total_ms = now_ms() - t0;
+  }
+  return MGPU_OK;
+}
+
 int mgpu_trace(MgpuScene *s, const MgpuRay *rays, size_t n, MgpuIntersection *out, uint8_t *hit, MgpuStats *stats) {
   if (!s) return fail(MGPU_ERR_INVALID, "scene is NULL");
   if (n && (!rays || !out || !hit)) return fail(MGPU_ERR_INVALID, "rays/out/hit must be non-NULL");
@@ -341,12 +378,6 @@ int mgpu_trace(MgpuScene *s, const MgpuRay *rays, size_t n, MgpuIntersection *ou
   if (rc) return rc;
   if (stats) memset(stats, 0, sizeof(*stats));
   if (n == 0) return MGPU_OK;
-  size_t blocks = (n + kBlock - 1) / kBlock;
-  size_t resident = (size_t)s->num_cu * 8; // the waves walk the ray array in grid strides
-  if (const char *e = getenv("MGPU_TRACE_BLOCKS_PER_CU")) resident = (size_t)s->num_cu * (size_t)atoi(e);
-  if (blocks > resident) blocks = resident;
-  rc = ensure_overflow(s, blocks * kBlock);
-  if (rc) return rc;
   MgpuRay *d_rays = nullptr;
   MgpuIntersection *d_out = nullptr;
   uint8_t *d_hit = nullptr;
@@ -367,20 +398,16 @@ int mgpu_trace(MgpuScene *s, const MgpuRay *rays, size_t n, MgpuIntersection *ou
   TRY_T(hipMalloc((void **)&d_out, sizeof(MgpuIntersection) * n));
   TRY_T(hipMalloc((void **)&d_hit, n));
   TRY_T(hipMemcpy(d_rays, rays, sizeof(MgpuRay) * n, hipMemcpyHostToDevice));
-  TRY_T(hipMemsetAsync(s->p_stats, 0, sizeof(unsigned long long) * kStatWords, 0));
-  TRY_T(hipEventRecord(s->ev0, 0));
-  launch_trace(s->cap, dim3((unsigned)blocks), 0, s->d, d_rays, n, d_out, d_hit, s->p_stats);
-  TRY_T(hipGetLastError());
-  TRY_T(hipEventRecord(s->ev1, 0));
+  MgpuStats dev_stats;
+  rc = mgpu_trace_device(s, d_rays, n, d_out, d_hit, nullptr, &dev_stats); // waits for the kernel
+  if (rc) {
+    cleanup();
+    return rc;
+  }
   TRY_T(hipMemcpy(out, d_out, sizeof(MgpuIntersection) * n, hipMemcpyDeviceToHost));
   TRY_T(hipMemcpy(hit, d_hit, n, hipMemcpyDeviceToHost));
   if (stats) {
-    unsigned long long w[kStatWords];
-    TRY_T(hipMemcpy(w, s->p_stats, sizeof(w), hipMemcpyDeviceToHost));
-    read_stats(w, stats);
-    float ms = 0.f;
-    TRY_T(hipEventElapsedTime(&ms, s->ev0, s->ev1));
-    stats->kernel_ms = ms;
+    *stats = dev_stats;
     stats->total_ms = now_ms() - t0;
   }
   cleanup();

@@ -85,6 +85,8 @@ def load_library():
     L.mgpu_stats_read.restype = i32
     L.mgpu_debug_words.argtypes = [vp, vp]
     L.mgpu_debug_words.restype = i32
+    L.mgpu_trace_device.argtypes = [vp, vp, sz, vp, vp, vp, C.POINTER(Stats)]
+    L.mgpu_trace_device.restype = i32
     L.mgpu_debug_tile_order.argtypes = [vp, vp, vp, sz]
     L.mgpu_debug_tile_order.restype = i32
     L.mgpu_debug_wave_log.argtypes = [vp, vp, sz]
@@ -248,6 +250,14 @@ class Scene:
         st = Stats()
         _check(load_library().mgpu_trace(self.h, _p(rays), len(rays), _p(out), _p(hit), C.byref(st)), "mgpu_trace")
         return (out, hit, st.as_dict()) if want_stats else (out, hit)
+
+    def trace_device(self, d_rays_ptr, n, d_out_ptr, d_hit_ptr, stream=None, want_stats=False):
+        """mgpu_trace_device: rays (88 B each), Intersection records (184 B) and hit bytes at raw device addresses."""
+        st = Stats()
+        _check(load_library().mgpu_trace_device(self.h, C.c_void_p(d_rays_ptr), n, C.c_void_p(d_out_ptr),
+                                                C.c_void_p(d_hit_ptr), C.c_void_p(stream or 0),
+                                                C.byref(st) if want_stats else None), "mgpu_trace_device")
+        return st.as_dict() if want_stats else None
 
     def render(self, frame, W, H, maxPathLength=16, passes=1, plane=None, rng_mode=RNG_HASH, rng_states=None, seed=1,
                pass_base=0, window=None, image=None, count=None):

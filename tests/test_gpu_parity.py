@@ -87,6 +87,30 @@ def test_trace_edge_cases():
     assert out["faceID"][0] == 7 and out["t"][0] == 24.591497079797261
 
 
+def test_trace_device_buffers_match_host_call():
+    """mgpu_trace_device (rays and records resident in HBM, asynchronous) writes the same bytes as mgpu_trace; sizes
+    chosen to cover a ragged last wave (n % 64 != 0, n % 16 != 0) and a single ray."""
+    import torch
+    sc = gpu_scene("cornell_obj")
+    rng = np.random.default_rng(5)
+    for n in (1, 15, 64, 1000, 70001):
+        rays = np.zeros(n, M.RAY_DT)
+        rays["org"] = rng.uniform(-30, 30, (n, 3))
+        d = rng.normal(size=(n, 3))
+        rays["dir"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+        out, hit = sc.trace(rays)
+        d_rays = torch.from_numpy(rays.view("u1").reshape(n, 88).copy()).cuda()
+        d_out = torch.full((n, 184), 0xAB, dtype=torch.uint8, device="cuda")
+        d_hit = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
+        st = sc.trace_device(d_rays.data_ptr(), n, d_out.data_ptr(), d_hit.data_ptr(),
+                             stream=torch.cuda.current_stream().cuda_stream, want_stats=(n == 1000))
+        torch.cuda.synchronize()
+        assert d_out.cpu().numpy().tobytes() == out.tobytes(), n
+        assert np.array_equal(d_hit.cpu().numpy(), hit), n
+        if st:
+            assert st["real_rays"] == n
+
+
 def test_trace_random_incoherent_vs_oracle_own_bvh():
     """Product-built BVH (mgpu_bvh_build) on the device vs oracle-built BVH on the CPU, 200k incoherent rays."""
     g = O.load_golden("teapot_obj")
