@@ -344,18 +344,32 @@ int mgpu_trace_device(MgpuScene *s, const MgpuRay *d_rays, size_t n, MgpuInterse
   if (stats) memset(stats, 0, sizeof(*stats));
   if (n == 0) return MGPU_OK;
   hipStream_t st = (hipStream_t)stream;
+  // kernel choice: "sm" = persistent wave-scheduled traversal (k_trace_sm), "v1" = one ray per lane to completion
+  // (k_trace; also used for batches too small to fill the persistent grid or too large for 32-bit ray indices)
+  bool use_sm = n >= 16384 && n < 0xF0000000ull;
+  if (const char *e = getenv("MGPU_TRACE_KERNEL")) {
+    if (!strcmp(e, "v1")) use_sm = false;
+    else if (!strcmp(e, "sm")) use_sm = n < 0xF0000000ull;
+    else return fail(MGPU_ERR_INVALID, "MGPU_TRACE_KERNEL=%s (expected v1|sm)", e);
+  }
   size_t blocks = (n + kBlock - 1) / kBlock;
-  size_t resident = (size_t)s->num_cu * 8; // the waves walk the ray array in grid strides
+  size_t resident = (size_t)s->num_cu * (use_sm ? 4 : 8); // sm: 16 waves per CU; v1: the waves walk the array in grid strides
   if (const char *e = getenv("MGPU_TRACE_BLOCKS_PER_CU")) resident = (size_t)s->num_cu * (size_t)(atoi(e) < 1 ? 1 : atoi(e));
   if (blocks > resident) blocks = resident;
   rc = ensure_overflow(s, blocks * kBlock);
   if (rc) return rc;
+  uint32_t *counter = s->p_counters + (size_t)(s->launch_seq++ % kCounterRing) * kShards;
+  if (use_sm) HIP_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), st));
   if (stats) {
     HIP_TRY(hipMemsetAsync(s->p_stats, 0, sizeof(unsigned long long) * kStatWords, st));
     HIP_TRY(hipEventRecord(s->ev0, st));
   }
-  launch_trace(s->cap, dim3((unsigned)blocks), st, s->d, d_rays, n, d_out, d_hit, s->p_stats);
-  HIP_TRY(hipGetLastError());
+  if (use_sm) {
+    HIP_TRY(launch_trace_sm(s->cap, dim3((unsigned)blocks), st, s->d, d_rays, (uint32_t)n, d_out, d_hit, counter, s->p_stats));
+  } else {
+    launch_trace(s->cap, dim3((unsigned)blocks), st, s->d, d_rays, n, d_out, d_hit, s->p_stats);
+    HIP_TRY(hipGetLastError());
+  }
   if (stats) {
     HIP_TRY(hipEventRecord(s->ev1, st));
     unsigned long long w[kStatWords];

@@ -58,6 +58,9 @@ int pick_stack_cap(int needed_entries);
 // wave-scheduled state-machine renderer (mgpu_render_sm.hip); shmem = stacks (+ scene when lds_scene)
 hipError_t launch_render_sm(int cap, bool lds_scene, int block, dim3 grid, hipStream_t s, size_t shmem, const DScene &sc,
                             const RenderParams &p);
+// k_trace_sm (mgpu_trace_sm.hip): persistent, wave-scheduled batched trace; `counter` = one zeroed device word
+hipError_t launch_trace_sm(int cap, dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, uint32_t n,
+                           MgpuIntersection *out, uint8_t *hit, uint32_t *counter, unsigned long long *stats);
 void launch_accumulate(hipStream_t s, const float *planes, size_t plane_stride, int passes, size_t n_floats, float *image,
                        int32_t *count, bool resume);
 // tile_order[0..n) = tile indices by descending cost (256 log buckets); zeroes cost[]. One workgroup.

@@ -1,0 +1,316 @@
+// mgpu_trace_sm.hip -- k_trace_sm: batched Scene::Trace (scene.cc:253-315 -> BVHAccel::Traverse bvh_accel.cc:773-844 +
+// BuildIntersection :699-769) with the wave-scheduled traversal of k_render_sm.
+//
+// k_trace (mgpu_kernels.hip) walks one ray per lane to completion; on incoherent rays in a large BVH a wave then waits
+// for its slowest lane's chain of dependent HBM loads while 63 lanes idle.  Here the waves are persistent and every lane
+// carries an explicit state
+//
+//     NODE : pop up to 4 nodes, slab test, push children / open a leaf        (bvh_accel.cc:805-834, 550-593)
+//     TRI  : test the open leaf's triangles in leaf order                      (bvh_accel.cc:595-697)
+//     EMIT : write the finished ray's Intersection record and hit flag, take the next ray index from the wave's cursor,
+//            load the ray and arm its traversal                                (bvh_accel.cc:774-802, 699-769, 838)
+//
+// and each trip of the wave loop runs the one body most lanes wait for.  A lane that finishes early emits and re-arms
+// while its neighbours are still walking.  Per-ray operation order is that of BVHAccel::Traverse, so records, hit
+// flags and the node / triangle visit counters are identical to k_trace's and the CPU's (asserted by the tests).
+//
+// Ray indices are handed out in order: a wave reserves kRayChunk consecutive indices with one global atomic and deals
+// them to its lanes as they free up, so neighbouring lanes mostly hold neighbouring rays (coalesced-ish loads, record
+// stores that fill whole cache lines between them).
+#include "mgpu_device.hpp"
+#include "mgpu_kernels.hpp"
+
+namespace mgpu {
+
+namespace {
+enum : int { TS_NODE = 0, TS_TRI = 1, TS_EMIT = 2, TS_IDLE = 3 };
+constexpr uint32_t kRayChunk = 256;
+constexpr int kTraceBlock = 256;
+} // namespace
+
+#ifndef MGPU_EMIT_MIN
+#define MGPU_EMIT_MIN 24
+#endif
+
+template <int CAP, bool OVF>
+__global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const MgpuRay *__restrict__ rays, uint32_t n,
+                                                            MgpuIntersection *__restrict__ out,
+                                                            uint8_t *__restrict__ hit_out, uint32_t *work_counter,
+                                                            unsigned long long *__restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ unsigned long long s_cnt[3];
+  uint32_t *s_stack = reinterpret_cast<uint32_t *>(smem); // [waves][CAP][64]
+  // record staging: per wave 16 records of 23 8-byte pieces + their 16 ray indices
+  unsigned long long *s_stage = reinterpret_cast<unsigned long long *>(smem + (size_t)(kTraceBlock / 64) * CAP * 64 * sizeof(uint32_t));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t slot = (size_t)blockIdx.x * kTraceBlock + threadIdx.x;
+  Stack<CAP, OVF> stk;
+  stk.lds = s_stack + ((size_t)wave * CAP) * 64 + lane;
+  stk.overflow = (OVF && sc.stack_overflow) ? sc.stack_overflow + slot * sc.overflow_cap : nullptr;
+  if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0ull;
+  __syncthreads();
+
+  // wave-uniform cursor over ray indices
+  uint32_t cur_next = 0, cur_end = 0;
+  bool exhausted = false;
+  // per-lane state
+  int st = TS_EMIT;
+  bool have_ray = false;
+  uint32_t rid = 0;
+  V3 org = v3(0, 0, 0), dir = v3(0, 0, 1);
+  double ix = 0, iy = 0, iz = 0;
+  bool sx = false, sy = false, sz = false;
+  int sp = -1;
+  double bt = kDblMax, bu = 0, bv = 0;
+  uint32_t bslot = kNoHit;
+  uint32_t tri_cur = 0, tri_end = 0;
+  uint32_t n_rays = 0, n_nodes = 0, n_tris = 0;
+
+  for (;;) {
+    const unsigned long long mN = __ballot(st == TS_NODE);
+    const unsigned long long mT = __ballot(st == TS_TRI);
+    const unsigned long long mE = __ballot(st == TS_EMIT);
+    const int cN = __popcll(mN), cT = __popcll(mT), cE = __popcll(mE);
+    if ((cN | cT | cE) == 0) break;
+    const bool run_emit = (cE >= MGPU_EMIT_MIN) || (cN == 0 && cT == 0);
+    if (!run_emit && cN >= cT) {
+      // ================================ NODE step ================================
+      if (st == TS_NODE) {
+#pragma unroll 1
+        for (int rep = 0; rep < 4; ++rep) {
+          const uint32_t ni = stk.get(sp);
+          --sp;
+          ++n_nodes;
+          const MgpuNode *nd = sc.nodes + ni;
+          const double2 b0 = *reinterpret_cast<const double2 *>(&nd->bmin[0]);
+          const double2 b1 = *reinterpret_cast<const double2 *>(&nd->bmin[2]);
+          const double2 b2 = *reinterpret_cast<const double2 *>(&nd->bmax[1]);
+          const int4 meta = *reinterpret_cast<const int4 *>(&nd->flag);
+          // IntersectRayAABB, bvh_accel.cc:550-593
+          const double nx = sx ? b1.y : b0.x, fx = sx ? b0.x : b1.y;
+          const double ny = sy ? b2.x : b0.y, fy = sy ? b0.y : b2.x;
+          const double nz = sz ? b2.y : b1.x, fz = sz ? b1.x : b2.y;
+          const double tmin_x = (nx - org.x) * ix, tmax_x = (fx - org.x) * ix;
+          const double tmin_y = (ny - org.y) * iy, tmax_y = (fy - org.y) * iy;
+          double tmin = (tmin_x > tmin_y) ? tmin_x : tmin_y;
+          double tmax = (tmax_x < tmax_y) ? tmax_x : tmax_y;
+          const double tmin_z = (nz - org.z) * iz, tmax_z = (fz - org.z) * iz;
+          tmin = (tmin > tmin_z) ? tmin : tmin_z;
+          tmax = (tmax < tmax_z) ? tmax : tmax_z;
+          const bool hit = (tmax > 0.0) && (tmin <= tmax) && (tmin <= bt);
+          if (hit) {
+            if (meta.x == 0) {
+              const bool nearIsSecond = (meta.y == 0) ? sx : ((meta.y == 1) ? sy : sz); // dirSign[node.axis]
+              const uint32_t c0 = (uint32_t)meta.z, c1 = (uint32_t)meta.w;
+              stk.put(sp + 1, nearIsSecond ? c0 : c1); // far
+              stk.put(sp + 2, nearIsSecond ? c1 : c0); // near: popped first
+              sp += 2;
+            } else if (meta.z != 0) {
+              tri_cur = (uint32_t)meta.w;
+              tri_end = (uint32_t)meta.w + (uint32_t)meta.z;
+              st = TS_TRI;
+            }
+          }
+          if (st != TS_NODE || sp < 0) break;
+        }
+        if (st == TS_NODE && sp < 0) st = TS_EMIT;
+      }
+    } else if (!run_emit) {
+      // ================================ TRI step =================================
+      if (st == TS_TRI) {
+#pragma unroll 1
+        for (int rep = 0; rep < 16; ++rep) {
+          const DTri *tp = sc.tris + tri_cur;
+          const double2 a0 = reinterpret_cast<const double2 *>(tp)[0];
+          const double2 a1 = reinterpret_cast<const double2 *>(tp)[1];
+          const double2 a2 = reinterpret_cast<const double2 *>(tp)[2];
+          const double2 a3 = reinterpret_cast<const double2 *>(tp)[3];
+          const double e2z = tp->e2[2];
+          ++n_tris;
+          // TriangleIsect, bvh_accel.cc:595-638
+          const V3 p0 = v3(a0.x, a0.y, a1.x), e1 = v3(a1.y, a2.x, a2.y), e2 = v3(a3.x, a3.y, e2z);
+          const V3 p = cross(dir, e2);
+          const double det = dot(e1, p);
+          if (!(fabs(det) < kDblEps1024)) {
+            const double invDet = 1.0 / det;
+            const V3 s = org - p0;
+            const V3 q = cross(s, e1);
+            const double u = dot(s, p) * invDet;
+            const double v = dot(q, dir) * invDet;
+            const double t = dot(e2, q) * invDet;
+            const bool rej = (u < 0.0 || u > 1.0) || (v < 0.0 || u + v > 1.0) || (t < 0.0 || t > bt);
+            if (!rej) {
+              bt = t;
+              bu = u;
+              bv = v;
+              bslot = tri_cur;
+            }
+          }
+          ++tri_cur;
+          if (tri_cur == tri_end) break;
+        }
+        if (tri_cur == tri_end) st = (sp < 0) ? TS_EMIT : TS_NODE;
+      }
+    } else {
+      // ================================ EMIT step ================================
+      const bool emit_lane = (st == TS_EMIT);
+      const bool emitting = emit_lane && have_ray;
+      // a miss leaves t = DBL_MAX, u = v = 0, faceID = -1 (bvh_accel.cc:782-786); every other field is zeroed here.
+      // Traverse reports a hit iff isect.t < DBL_MAX (bvh_accel.cc:838): a NaN t (NaN ray) fails that test even though
+      // TestLeafNode accepted a triangle and already wrote faceID / materialID.
+      const bool hit = bt < kDblMax;
+      uint32_t faceID = 0xFFFFFFFFu, materialID = 0, f0 = 0, f1 = 0, f2 = 0;
+      V3 pos = v3(0, 0, 0), gn = v3(0, 0, 0), sn = v3(0, 0, 0);
+      double tc0 = 0.0, tc1 = 0.0;
+      if (emitting) {
+        if (!hit && bslot != kNoHit) {
+          faceID = sc.tris[bslot].face;
+          materialID = sc.tris[bslot].mat;
+        }
+        if (hit) {
+          // BuildIntersection, bvh_accel.cc:699-769
+          const DTri *tp = sc.tris + bslot;
+          const uint32_t face = tp->face;
+          faceID = face;
+          materialID = tp->mat;
+          f0 = sc.faces[3 * (size_t)face + 0];
+          f1 = sc.faces[3 * (size_t)face + 1];
+          f2 = sc.faces[3 * (size_t)face + 2];
+          pos = v3(org.x + bt * dir.x, org.y + bt * dir.y, org.z + bt * dir.z);
+          const V3 e1 = v3(tp->e1[0], tp->e1[1], tp->e1[2]), e2 = v3(tp->e2[0], tp->e2[1], tp->e2[2]);
+          gn = normalized(cross(e1, e2));
+          if (sc.fv_normals) {
+            const double *nn = sc.fv_normals + 9 * (size_t)face;
+            const double w = 1.0 - bu - bv;
+            sn = v3(w * nn[0] + bu * nn[3] + bv * nn[6], w * nn[1] + bu * nn[4] + bv * nn[7],
+                    w * nn[2] + bu * nn[5] + bv * nn[8]);
+          } else {
+            sn = gn;
+          }
+          if (sc.fv_uvs) {
+            const double *uv = sc.fv_uvs + 6 * (size_t)face;
+            const double w = 1.0 - bu - bv;
+            tc0 = w * uv[0] + bu * uv[2] + bv * uv[4];
+            tc1 = w * uv[1] + bu * uv[3] + bv * uv[5];
+          }
+        }
+        hit_out[rid] = hit ? 1 : 0;
+      }
+      // The 184-byte records go out through LDS, 16 at a time: their lanes lay them out in the wave's staging area and
+      // the whole wave stores them as 8-byte pieces, neighbouring lanes writing neighbouring pieces of one record -- a
+      // lane storing its own record would issue 23 store instructions of one isolated 8-byte write per lane each.
+      {
+        const unsigned long long em = __ballot(emitting);
+        const int total = __popcll(em);
+        const int my_rank = (int)__popcll(em & ((1ull << lane) - 1ull));
+        unsigned long long *stage = s_stage + (size_t)wave * (16 * 23 + 16);
+        uint32_t *stage_rid = reinterpret_cast<uint32_t *>(stage + 16 * 23);
+        for (int r0 = 0; r0 < total; r0 += 16) {
+          if (emitting && my_rank >= r0 && my_rank < r0 + 16) {
+            MgpuIntersection *is = reinterpret_cast<MgpuIntersection *>(stage + (size_t)(my_rank - r0) * 23);
+            is->t = bt; is->u = bu; is->v = bv;
+            is->faceID = faceID; is->materialID = materialID; is->f0 = f0; is->f1 = f1; is->f2 = f2; is->pad_ = 0;
+            is->position[0] = pos.x; is->position[1] = pos.y; is->position[2] = pos.z;
+            is->geometricNormal[0] = gn.x; is->geometricNormal[1] = gn.y; is->geometricNormal[2] = gn.z;
+            is->normal[0] = sn.x; is->normal[1] = sn.y; is->normal[2] = sn.z;
+            for (int k = 0; k < 3; ++k) { is->tangent[k] = 0.0; is->binormal[k] = 0.0; }
+            is->texcoord[0] = tc0; is->texcoord[1] = tc1;
+            stage_rid[my_rank - r0] = rid;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const int cnt = (total - r0 < 16) ? (total - r0) : 16;
+          for (int i = lane; i < cnt * 23; i += 64) {
+            const int rec = i / 23, piece = i - rec * 23;
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(out + stage_rid[rec]) + piece;
+            *dst = stage[i];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier(); // the area is rewritten by the next 16
+        }
+      }
+      if (emitting) have_ray = false;
+      // ---- hand-out of ray indices, executed by the whole wave (the cursor is wave-uniform) ----
+      bool want = emit_lane;
+      for (;;) {
+        const unsigned long long wm = __ballot(want);
+        if (!wm || exhausted) break;
+        if (cur_next >= cur_end) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(work_counter, kRayChunk);
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          if (base >= n) { exhausted = true; break; }
+          cur_next = base;
+          cur_end = (n - base < kRayChunk) ? n : base + kRayChunk;
+        }
+        const uint32_t rank = __popcll(wm & ((1ull << lane) - 1ull));
+        const uint32_t avail = cur_end - cur_next;
+        if (want && rank < avail) {
+          rid = cur_next + rank;
+          have_ray = true;
+          want = false;
+        }
+        const uint32_t took = min((uint32_t)__popcll(wm), avail);
+        cur_next += took;
+      }
+      if (emit_lane) {
+        if (have_ray) {
+          // BVHAccel::Traverse prologue, bvh_accel.cc:774-802 (only org / dir of the 88-byte Ray are inputs)
+          const MgpuRay *r = rays + rid;
+          org = v3(r->org[0], r->org[1], r->org[2]);
+          dir = v3(r->dir[0], r->dir[1], r->dir[2]);
+          sx = dir.x < 0.0; sy = dir.y < 0.0; sz = dir.z < 0.0;
+          ix = 1.0 / dir.x; iy = 1.0 / dir.y; iz = 1.0 / dir.z; // no zero guard, as the reference
+          bt = kDblMax; bu = 0.0; bv = 0.0; bslot = kNoHit;
+          sp = 0;
+          stk.put(0, 0u);
+          ++n_rays;
+          st = TS_NODE;
+        } else {
+          st = TS_IDLE;
+        }
+      }
+    }
+  }
+
+  // counters: wave reduction, one LDS atomic per wave, one global atomic per workgroup and word
+  unsigned long long rn = n_rays, nn = n_nodes, tn = n_tris;
+  for (int off = 32; off; off >>= 1) {
+    rn += __shfl_down(rn, off);
+    nn += __shfl_down(nn, off);
+    tn += __shfl_down(tn, off);
+  }
+  if (lane == 0) {
+    atomicAdd(&s_cnt[0], rn);
+    atomicAdd(&s_cnt[1], nn);
+    atomicAdd(&s_cnt[2], tn);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && stats) {
+    atomicAdd(&stats[kStatRays], s_cnt[0]);
+    atomicAdd(&stats[kStatNodes], s_cnt[1]);
+    atomicAdd(&stats[kStatTris], s_cnt[2]);
+    atomicAdd(&stats[kStatTraceCalls], s_cnt[0]);
+  }
+}
+
+template <int CAP, bool OVF>
+static hipError_t launch_one(dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, uint32_t n,
+                             MgpuIntersection *out, uint8_t *hit, uint32_t *counter, unsigned long long *stats) {
+  const size_t shmem = (size_t)(kTraceBlock / 64) * (CAP * 64 * sizeof(uint32_t) + (16 * 23 + 16) * sizeof(unsigned long long));
+  hipLaunchKernelGGL((k_trace_sm<CAP, OVF>), grid, dim3(kTraceBlock), shmem, s, sc, rays, n, out, hit, counter, stats);
+  return hipGetLastError();
+}
+
+hipError_t launch_trace_sm(int cap, dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, uint32_t n,
+                           MgpuIntersection *out, uint8_t *hit, uint32_t *counter, unsigned long long *stats) {
+  const bool ovf = sc.overflow_cap != 0;
+  if (cap == 16 && !ovf) return launch_one<16, false>(grid, s, sc, rays, n, out, hit, counter, stats);
+  if (cap == 24 && !ovf) return launch_one<24, false>(grid, s, sc, rays, n, out, hit, counter, stats);
+  if (cap == 32 && !ovf) return launch_one<32, false>(grid, s, sc, rays, n, out, hit, counter, stats);
+  if (cap == 32 && ovf) return launch_one<32, true>(grid, s, sc, rays, n, out, hit, counter, stats);
+  return hipErrorInvalidConfiguration;
+}
+
+} // namespace mgpu

@@ -45,8 +45,15 @@ def test_loaded_native_library_and_device():
     assert M.lib_path().endswith("libmallie_mgpu.so")
 
 
+@pytest.fixture(params=["v1", "sm"])
+def trace_kernel(request, monkeypatch):
+    """Both batched-trace kernels: k_trace (one ray per lane to completion) and k_trace_sm (persistent, wave-scheduled)."""
+    monkeypatch.setenv("MGPU_TRACE_KERNEL", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("name", ["cornell_obj", "cornell_eson", "teapot_obj"])
-def test_trace_matches_reference_goldens_bit_exact(name):
+def test_trace_matches_reference_goldens_bit_exact(name, trace_kernel):
     t = O.load_golden("trace_" + name)
     sc = gpu_scene(name)
     out, hit, st = sc.trace(t["rays"], want_stats=True)
@@ -64,7 +71,7 @@ def test_trace_matches_reference_goldens_bit_exact(name):
     assert (st["real_rays"], st["nodes"], st["tris"]) == (ost.real_rays, ost.nodes, ost.tris)
 
 
-def test_trace_edge_cases():
+def test_trace_edge_cases(trace_kernel):
     sc = gpu_scene("cornell_obj")
     osc = O.scene_from_golden("cornell_obj")
     out, hit = sc.trace(np.zeros((0, 6)))
@@ -87,7 +94,7 @@ def test_trace_edge_cases():
     assert out["faceID"][0] == 7 and out["t"][0] == 24.591497079797261
 
 
-def test_trace_device_buffers_match_host_call():
+def test_trace_device_buffers_match_host_call(trace_kernel):
     """mgpu_trace_device (rays and records resident in HBM, asynchronous) writes the same bytes as mgpu_trace; sizes
     chosen to cover a ragged last wave (n % 64 != 0, n % 16 != 0) and a single ray."""
     import torch
@@ -111,7 +118,7 @@ def test_trace_device_buffers_match_host_call():
             assert st["real_rays"] == n
 
 
-def test_trace_random_incoherent_vs_oracle_own_bvh():
+def test_trace_random_incoherent_vs_oracle_own_bvh(trace_kernel):
     """Product-built BVH (mgpu_bvh_build) on the device vs oracle-built BVH on the CPU, 200k incoherent rays."""
     g = O.load_golden("teapot_obj")
     rng = np.random.default_rng(11)
@@ -341,7 +348,7 @@ def _deep_scene(n=120, base=8.0):
     return tri.reshape(-1, 3), np.arange(3 * n, dtype="u4").reshape(n, 3)
 
 
-def test_deep_tree_uses_stack_overflow_column():
+def test_deep_tree_uses_stack_overflow_column(trace_kernel):
     verts, faces = _deep_scene()
     nodes, idx, st = M.bvh_build(verts, faces)
     assert st["maxTreeDepth"] > 32

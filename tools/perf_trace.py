@@ -11,6 +11,9 @@ c = O.load_golden("cornell_obj")
 for name in sys.argv[1:] or ["c2"]:
     if name == "c2":
         verts, faces, mats, normals = c["verts"].astype(np.float64), c["faces"], c["matIDs"], c["normals"]
+    elif name == "teapot":
+        g = O.load_golden("teapot_obj")
+        verts, faces, mats, normals = g["verts"].astype(np.float64), g["faces"], g["matIDs"], g["normals"]
     else:
         verts, faces, mats, normals = suzanne_grid(c["verts"], c["faces"], int(name[4:]))
     nodes, idx, _ = M.bvh_build(verts, faces, device=0 if len(faces) > 65536 else None)
@@ -30,7 +33,11 @@ for name in sys.argv[1:] or ["c2"]:
             org = np.broadcast_to(eye, d.shape)
         rays = np.concatenate([org, d], 1)
         sc.trace(rays[:1000])
-        out, hit, st = sc.trace(rays, want_stats=True)
+        best = None
+        for _ in range(3):
+            out, hit, st = sc.trace(rays, want_stats=True)
+            if best is None or st["kernel_ms"] < best["kernel_ms"]: best = st
+        st = best
         nr = len(rays)
         print("%s %s: %d rays, kernel %.3f ms -> %.0f Mrays/s (hit %.0f%%, nodes/ray %.1f tris/ray %.1f), call total %.0f ms; bytes in+out %.0f GB/s" % (
             name, kind, nr, st["kernel_ms"], nr / st["kernel_ms"] / 1e3, 100.0 * hit.mean(), st["nodes"] / nr, st["tris"] / nr, st["total_ms"], nr * (88 + 184 + 1) / st["kernel_ms"] / 1e6), flush=True)
