@@ -13,6 +13,7 @@ Every vector below is an OUTPUT of the reference binary (or an input fed to it):
   teapot_obj.npz    same for teapot.obj
   trace_*.npz       (Ray -> Intersection) batches through Scene::Trace                   (scene.cc:253)
   render_*.npz      Render() images, 1..2 consecutive passes, OMP_NUM_THREADS=1           (render.cc:593)
+  pano_*.npz        RenderPanoramic() images (mono / stereo), OMP_NUM_THREADS=1            (render.cc:710)
 
 Rules: CWD=/root/reference so tinyobj finds the .mtl; one process per render config
 (Render() keeps `static bool initial_pass`); OMP_NUM_THREADS=1.
@@ -155,6 +156,27 @@ def gen_render(tmp, kind, fname, name, W, H, plane, passes, eye, lookat, up=(0, 
     print(name, [float(i[..., 0].mean()) for i in imgs])
 
 
+def gen_pano(tmp, kind, fname, name, W, H, stereo, eye, lookat=(0, 0, 0), up=(0, 1, 0), quat=(0, 0, 0, 0)):
+    """One RenderPanoramic() call (render.cc:710-763; 10 PathTraceEnv samples per pixel, maxPathLength 16)."""
+    prefix = os.path.join(tmp, name)
+    run(["panoramic", kind, fname, 1.0, W, H, int(stereo), *eye, *lookat, *up, *quat, prefix])
+    img = np.fromfile(prefix + ".f32", "<f4").reshape(H, W, 3)
+    count = np.fromfile(prefix + ".count.i32", "<i4").reshape(H, W)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), image=img, count=count, W=W, H=H, stereo=int(stereo),
+                        eye=np.array(eye, "f8"), lookat=np.array(lookat, "f8"), up=np.array(up, "f8"),
+                        quat=np.array(quat, "f8"), maxPathLength=16, samples=10, scene=name.split("_")[1])
+    print(name, float(img[..., 0].mean()), int((img[..., 0] != 0).sum()), "non-zero pixels")
+
+
+def gen_pano_all(tmp):
+    # main_console.cc:104-106 puts the eye on a circle of radius 4 at height 1 (frame 0: (0, 1, 4)) and asks for stereo
+    gen_pano(tmp, "obj", "cornellbox_suzanne.obj", "pano_cornell_stereo_96x64", 96, 64, True, (0.0, 1.0, 4.0))
+    gen_pano(tmp, "obj", "cornellbox_suzanne.obj", "pano_cornell_mono_80x40", 80, 40, False, (0.0, 1.0, 4.0))
+    gen_pano(tmp, "obj", "cornellbox_suzanne.obj", "pano_cornell_stereo_50x37_view2", 50, 37, True, (2.5, 3.0, -1.5),
+             quat=(0.05, -0.1, 0.02, 0.99))
+    gen_pano(tmp, "obj", "teapot.obj", "pano_teapot_mono_64x32", 64, 32, False, (0.0, 60.0, 120.0))
+
+
 def gen_camera(tmp):
     rng = np.random.default_rng(7)
     cfgs = [
@@ -192,7 +214,12 @@ def main():
     if not os.path.exists(DRIVER):
         raise SystemExit("build the reference driver first: make -C oracle ref")
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["pano"]:  # only the RenderPanoramic goldens (keeps the other fixtures' bytes untouched)
+        with tempfile.TemporaryDirectory() as tmp:
+            gen_pano_all(tmp)
+        return
     with tempfile.TemporaryDirectory() as tmp:
+        gen_pano_all(tmp)
         gen_camera(tmp)
         mc = gen_mesh(tmp, "obj", "cornellbox_suzanne.obj", "cornell_obj")
         gen_mesh(tmp, "eson", "cornellbox_suzanne.eson", "cornell_eson")

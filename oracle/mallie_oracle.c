@@ -953,6 +953,153 @@ int mo_render(const mo_scene *s, const double frame[12], int W, int H, int x0, i
   return err;
 }
 
+/* ------------------------------------------------------------------------------------------------ */
+/* RenderPanoramic (render.cc:710-763) = PathTraceEnv (render.cc:518-590) over equirectangular rays    */
+/* ------------------------------------------------------------------------------------------------ */
+/* Camera::GenerateEnvRay (camera.cc:242-257) / Camera::GenerateStereoEnvRay (camera.cc:259-329).  origin = the camera
+ * frame's origin_ (BuildCameraFrame); W, H = the frame size.  Stereo: top half = left eye, bottom half = right eye,
+ * eyes on a circle of radius 0.5 toed in towards a focal distance of 4. */
+void mo_generate_env_ray(const double origin[3], int W, int H, int stereo, double u, double v, double ray[6]) {
+  if (!stereo) {
+    double theta = M_PI * (v / H);
+    double phi = 2.0 * M_PI * (u / W);
+    ray[0] = origin[0]; ray[1] = origin[1]; ray[2] = origin[2];
+    ray[3] = sin(theta) * cos(phi);
+    ray[4] = cos(theta);
+    ray[5] = sin(theta) * sin(phi);
+    return;
+  }
+  const int is_left_side = v < (double)(H >> 1);
+  const double focal_length = 4.0;
+  const double r = 0.5;
+  double theta = M_PI * fmod(2.0 * v / H, 1.0);
+  double phi = 2.0 * M_PI * (u / W);
+  v3 d0 = v3_make(sin(theta) * cos(phi), cos(theta), sin(theta) * sin(phi));
+  v3 parallax = is_left_side ? v3_make(-d0.z, 0.0, d0.x) : v3_make(d0.z, 0.0, -d0.x);
+  parallax = v3_normalized(parallax);
+  parallax = v3_scale(parallax, r);
+  ray[0] = origin[0] + parallax.x;
+  ray[1] = origin[1] + parallax.y;
+  ray[2] = origin[2] + parallax.z;
+  double psi = atan2(r, focal_length);
+  if (is_left_side) psi = -psi;
+  v3 d = v3_make(d0.x * cos(psi) - d0.z * sin(psi), d0.y, d0.x * sin(psi) + d0.z * cos(psi));
+  d = v3_normalized(d);
+  ray[3] = d.x; ray[4] = d.y; ray[5] = d.z;
+}
+
+/* PathTraceEnv, render.cc:518-590: no plane, no material, `throughput` never used; a miss at length L >= 2 adds
+ * 0.5/L and -- as in PathTrace -- does NOT end the path: the loop runs on to maxPathLength with the stale
+ * record, every later ray starting ~1e308 away. */
+static int path_trace_env(const mo_scene *s, const double origin[3], int W, int H, int stereo, int maxPathLength, int px,
+                          int py, uint32_t rng[4], double radiance_out[3], path_counters *pc) {
+  float ju = (float)(mo_xorshift128(rng) - 0.5);
+  float jv = (float)(mo_xorshift128(rng) - 0.5);
+  double ray[6];
+  mo_generate_env_ray(origin, W, H, stereo, (double)((float)px + ju), (double)((float)py + jv), ray);
+  v3 org = v3_load(&ray[0]), dir = v3_load(&ray[3]);
+  isect_t is;
+  memset(&is, 0, sizeof(is));
+  is.t = 1.0e+30;
+  double rad[3] = {0.0, 0.0, 0.0};
+  int escaped = 0;
+  pc->paths++;
+  for (unsigned pathLength = 1;; ++pathLength) {
+    uint64_t nv = 0, nt = 0;
+    int hit = traverse(s, &is, org, dir, &nv, &nt, &pc->max_stack);
+    if (hit < 0) return -3;
+    pc->trace_calls++;
+    if (escaped) {
+      pc->garbage_nodes += nv;
+      if (hit) pc->garbage_hits++;
+    } else {
+      pc->real_rays++;
+      pc->nodes += nv;
+      pc->tris += nt;
+    }
+    if (!hit) {
+      if (pathLength < 2) break; /* kMinPathLength */
+      escaped = 1;
+      double L = (double)pathLength; /* kd / real3(pathLength, pathLength, pathLength), kd = 0.5 */
+      rad[0] += 0.5 / L;
+      rad[1] += 0.5 / L;
+      rad[2] += 0.5 / L;
+    }
+    if (pathLength >= (unsigned)maxPathLength) break;
+    v3 hitP = v3_add(org, v3_scale(dir, is.t));
+    (void)mo_xorshift128(rng); /* `double r = randomreal();` -- drawn, never used (render.cc:563) */
+    v3 n = is.normal;
+    double ndoti = v3_dot(is.normal, v3_neg(dir));
+    if (ndoti < 0.0) n = v3_neg(n);
+    v3 sd = sample_diffuse(n, rng);
+    org = v3_add(hitP, v3_scale(sd, 1.0e-3));
+    dir = sd;
+    is.t = 1.0e+30;
+  }
+  radiance_out[0] = rad[0]; radiance_out[1] = rad[1]; radiance_out[2] = rad[2];
+  return 0;
+}
+
+int mo_render_panoramic(const mo_scene *s, const double origin[3], int W, int H, int x0, int y0, int x1, int y1,
+                        int maxPathLength, int samples, int stereo, int rng_mode, uint32_t stream_state[4],
+                        const uint32_t *rng_states, uint64_t seed, uint32_t pass_base, float *image, int32_t *count,
+                        uint32_t *states_out, mo_stats *stats, int nthreads) {
+  if (!s || !origin || !image || W <= 0 || H <= 0 || samples < 1 || maxPathLength < 1) return -1;
+  if (x0 < 0 || y0 < 0 || x1 > W || y1 > H || x0 > x1 || y0 > y1) return -1;
+  if (rng_mode == MO_RNG_STREAM && !stream_state) return -1;
+  if (rng_mode == MO_RNG_TABLE && !rng_states) return -1;
+  if (rng_mode < 0 || rng_mode > 2) return -1;
+  int err = 0;
+  path_counters total;
+  memset(&total, 0, sizeof(total));
+#ifdef _OPENMP
+  if (nthreads < 1) nthreads = omp_get_max_threads();
+#else
+  nthreads = 1;
+#endif
+  if (rng_mode == MO_RNG_STREAM) nthreads = 1; /* scanline order, one state (OMP_NUM_THREADS=1 in the reference) */
+#pragma omp parallel num_threads(nthreads)
+  {
+    path_counters local;
+    memset(&local, 0, sizeof(local));
+#pragma omp for schedule(dynamic, 1)
+    for (int y = y0; y < y1; y++) {
+      for (int x = x0; x < x1; x++) {
+        size_t px = (size_t)y * W + x;
+        uint32_t own[4];
+        uint32_t *st = own;
+        if (rng_mode == MO_RNG_STREAM) st = stream_state;
+        else if (rng_mode == MO_RNG_TABLE) memcpy(own, &rng_states[px * 4], 16);
+        else mo_hash_state(seed, pass_base, (uint32_t)px, own);
+        if (states_out) memcpy(&states_out[px * 4], st, 16);
+        float acc[3] = {0.0f, 0.0f, 0.0f}; /* memset(image) then `image[...] += radiance[k]`: float += double */
+        for (int i = 0; i < samples; i++) {
+          double rad[3];
+          if (path_trace_env(s, origin, W, H, stereo, maxPathLength, x, y, st, rad, &local)) {
+#pragma omp atomic write
+            err = -3;
+          }
+          for (int c = 0; c < 3; c++) acc[c] = (float)((double)acc[c] + rad[c]);
+        }
+        image[3 * px + 0] = acc[0];
+        image[3 * px + 1] = acc[1];
+        image[3 * px + 2] = acc[2];
+        if (count) count[px] += samples;
+      }
+    }
+#pragma omp critical
+    {
+      total.trace_calls += local.trace_calls; total.real_rays += local.real_rays;
+      total.nodes += local.nodes; total.tris += local.tris;
+      total.garbage_nodes += local.garbage_nodes; total.garbage_hits += local.garbage_hits;
+      total.paths += local.paths;
+      if (local.max_stack > total.max_stack) total.max_stack = local.max_stack;
+    }
+  }
+  if (stats) merge_stats(stats, &total);
+  return err;
+}
+
 /* One eye path with per-iteration records (16 doubles each, layout of mgpu_probe_path in include/mgpu.h, except that
  * field 8 holds the FACE id of a mesh hit rather than the BVH slot).  Only iterations up to and including the first
  * miss are recorded, which is what the device executes. */

@@ -128,6 +128,22 @@ int mo_render(const mo_scene *s, const double frame[12], int W, int H, int x0, i
               const uint32_t *rng_states, uint64_t seed, uint32_t pass_base, float *image, int32_t *count,
               uint32_t *states_out, mo_stats *stats, int nthreads);
 
+/* ---- RenderPanoramic (render.cc:710-763 + PathTraceEnv render.cc:518-590 + camera.cc:242-329) ---------------------- */
+/* Camera::GenerateEnvRay (stereo == 0) / GenerateStereoEnvRay: ray[0..2] = origin, ray[3..5] = direction. */
+void mo_generate_env_ray(const double origin[3], int W, int H, int stereo, double u, double v, double ray[6]);
+/*
+ * One RenderPanoramic() call on the window [x0,x1) x [y0,y1): every pixel receives the sum of `samples` (reference: 10)
+ * PathTraceEnv radiances, added one after the other as `float += double`; count[px] += samples.
+ * A pixel's samples draw from ONE xorshift128 stream (the reference's loop nest is y, x, sample), so the RNG modes are
+ * per PIXEL: MO_RNG_STREAM = one state for the whole scanline-ordered frame (in/out), MO_RNG_TABLE = rng_states[px*4..]
+ * is the state at the pixel's first sample, MO_RNG_HASH = mo_hash_state(seed, pass_base, px).  states_out (W*H*4) receives
+ * every pixel's start state.  maxPathLength: the reference's 16.
+ */
+int mo_render_panoramic(const mo_scene *s, const double origin[3], int W, int H, int x0, int y0, int x1, int y1,
+                        int maxPathLength, int samples, int stereo, int rng_mode, uint32_t stream_state[4],
+                        const uint32_t *rng_states, uint64_t seed, uint32_t pass_base, float *image, int32_t *count,
+                        uint32_t *states_out, mo_stats *stats, int nthreads);
+
 /* Display transforms: mode 0 = HDRToLDR/fclamp of main_console.cc:25-43 (RGB8, linear), mode 1 = Display/fclamp of
  * main_sdl.cc:157-165,420-477 (BGRA8, gamma 2.2); both divide by the per-pixel count first. */
 void mo_tonemap(const float *image, const int32_t *count, size_t npix, int mode, unsigned char *out);

@@ -9,6 +9,7 @@
 // Reference entry points exercised (file:line in /root/reference):
 //   mallie::Scene::Init            scene.cc:66      mallie::Scene::Trace   scene.cc:253
 //   mallie::Render                 render.cc:593    Camera::BuildCameraFrame camera.cc:40
+//   mallie::RenderPanoramic        render.cc:710
 //   BVHAccel::GetNodes/GetIndices  bvh_accel.h:74   Camera::GenerateRay    camera.cc:222
 //
 // Rules learnt in SURVEY.md section 0: one process per (scene, config) because Render() keeps
@@ -200,6 +201,36 @@ int cmd_render(int argc, char **argv) {
   return 0;
 }
 
+// panoramic <kind> <file> <scale> <W> <H> <stereo> <eye[3]> <lookat[3]> <up[3]> <quat[4]> <out_prefix>
+//   one mallie::RenderPanoramic() call (render.cc:710; what main_console.cc:111 runs): <out>.f32 (3*W*H float32) and
+//   <out>.count.i32.  Run with OMP_NUM_THREADS=1 in a fresh process (its own `static bool initial_pass`).
+int cmd_panoramic(int argc, char **argv) {
+  if (argc < 22) die("panoramic kind file scale W H stereo eye[3] lookat[3] up[3] quat[4] out");
+  SceneProbe scene;
+  if (!init_scene(scene, argv[2], argv[3], atof(argv[4]))) die("Scene::Init failed");
+  mallie::RenderConfig config;
+  config.width = atoi(argv[5]);
+  config.height = atoi(argv[6]);
+  const bool stereo = atoi(argv[7]) != 0;
+  for (int k = 0; k < 3; k++) {
+    config.eye[k] = atof(argv[8 + k]);
+    config.lookat[k] = atof(argv[11 + k]);
+    config.up[k] = atof(argv[14 + k]);
+  }
+  for (int k = 0; k < 4; k++) config.quat[k] = atof(argv[17 + k]);
+  std::string out = argv[21];
+  std::vector<float> image(3 * (size_t)config.width * config.height);
+  std::vector<int> count((size_t)config.width * config.height, 0);
+  mallie::RenderPanoramic(scene, config, image, count, config.eye, config.lookat, config.up, config.quat, stereo);
+  FILE *fp = xopen(out + ".f32", "wb");
+  wr(fp, &image[0], sizeof(float) * image.size());
+  fclose(fp);
+  fp = xopen(out + ".count.i32", "wb");
+  wr(fp, &count[0], sizeof(int) * count.size());
+  fclose(fp);
+  return 0;
+}
+
 } // namespace
 
 int main(int argc, char **argv) {
@@ -208,6 +239,7 @@ int main(int argc, char **argv) {
   if (!strcmp(argv[1], "trace")) return cmd_trace(argc, argv);
   if (!strcmp(argv[1], "camera")) return cmd_camera(argc, argv);
   if (!strcmp(argv[1], "render")) return cmd_render(argc, argv);
+  if (!strcmp(argv[1], "panoramic")) return cmd_panoramic(argc, argv);
   die("unknown command");
   return 2;
 }

@@ -65,6 +65,11 @@ def lib():
         L.mo_render.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, u64, u32, vp, vp, vp,
                                 vp, i32]
         L.mo_render.restype = i32
+        L.mo_render_panoramic.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, u64, u32, vp, vp,
+                                          vp, C.POINTER(Stats), i32]
+        L.mo_render_panoramic.restype = i32
+        L.mo_generate_env_ray.argtypes = [vp, i32, i32, i32, C.c_double, C.c_double, vp]
+        L.mo_generate_env_ray.restype = None
         L.mo_tonemap.argtypes = [vp, vp, sz, i32, vp]
         L.mo_probe_path.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, C.POINTER(i32), vp]
         L.mo_probe_path.restype = i32
@@ -171,6 +176,31 @@ class OracleScene:
         if rc:
             raise RuntimeError("mo_render failed: %d" % rc)
         return image, count, st.as_dict(), states_out
+
+
+    def render_panoramic(self, origin, W, H, stereo, maxPathLength=16, samples=10, rng_mode=RNG_HASH, stream_state=None,
+                         rng_states=None, seed=1, pass_base=0, window=None, count=None, want_states=False, nthreads=0):
+        """mo_render_panoramic: one RenderPanoramic() call -> (image, count, stats, per-pixel start states or None)."""
+        origin = _c(origin, "<f8")
+        x0, y0, x1, y1 = window if window is not None else (0, 0, W, H)
+        image = np.zeros((H, W, 3), "<f4")
+        if count is None:
+            count = np.zeros((H, W), "<i4")
+        rng_states = _c(rng_states, "<u4")
+        states_out = np.zeros((H, W, 4), "<u4") if want_states else None
+        st = Stats()
+        rc = lib().mo_render_panoramic(self.h, _p(origin), W, H, x0, y0, x1, y1, maxPathLength, samples, int(stereo),
+                                       rng_mode, _p(stream_state), _p(rng_states), seed, pass_base, _p(image), _p(count),
+                                       _p(states_out), C.byref(st), nthreads)
+        if rc:
+            raise RuntimeError("mo_render_panoramic failed: %d" % rc)
+        return image, count, st.as_dict(), states_out
+
+
+def generate_env_ray(origin, W, H, stereo, u, v):
+    r = np.zeros(6)
+    lib().mo_generate_env_ray(_p(_c(origin, "<f8")), int(W), int(H), int(stereo), float(u), float(v), _p(r))
+    return r
 
 
 def tonemap(image, count, mode):

@@ -111,6 +111,48 @@ def test_render_512_digest():
     assert st["garbage_hits"] == 0
 
 
+PANOS = ["pano_cornell_stereo_96x64", "pano_cornell_mono_80x40", "pano_cornell_stereo_50x37_view2", "pano_teapot_mono_64x32"]
+
+
+def pano_setup(name):
+    r = O.load_golden(name)
+    sc = O.scene_from_golden("teapot_obj" if "teapot" in name else "cornell_obj")
+    W, H = int(r["W"]), int(r["H"])
+    origin = O.camera_frame(r["eye"], r["lookat"], r["up"], r["quat"], 45.0, W, H)[:3]
+    return r, sc, W, H, origin
+
+
+@pytest.mark.parametrize("name", PANOS)
+def test_panoramic_reference_stream_bit_exact(name):
+    """mo_render_panoramic (RenderPanoramic + PathTraceEnv + Generate[Stereo]EnvRay) against the reference's own images."""
+    r, sc, W, H, origin = pano_setup(name)
+    state = np.array(O.REFERENCE_SEED, "<u4")
+    img, count, st, states = sc.render_panoramic(origin, W, H, int(r["stereo"]), 16, 10, O.RNG_STREAM, stream_state=state,
+                                                 want_states=True)
+    assert img.tobytes() == r["image"].tobytes()
+    assert np.array_equal(count, r["count"]) and int(count[0, 0]) == 10
+    assert st["garbage_hits"] == 0
+    assert st["paths"] == 10 * W * H and (st["trace_calls"] - st["paths"]) % 15 == 0  # 1 or 16 Trace() calls per path
+    # per-pixel start states replayed in parallel give the same image (the bridge to the GPU)
+    img2, _, st2, _ = sc.render_panoramic(origin, W, H, int(r["stereo"]), 16, 10, O.RNG_TABLE, rng_states=states, nthreads=4)
+    assert img2.tobytes() == img.tobytes() and st2["real_rays"] == st["real_rays"]
+
+
+def test_env_rays_cover_the_sphere():
+    """GenerateEnvRay: unit directions, v = 0 is +Y, u wraps around Y; stereo eyes sit 0.5 off the origin, left eye in the
+    top half of the frame, toed in (camera.cc:242-329)."""
+    o = np.array([1.0, 2.0, 3.0])
+    r = O.generate_env_ray(o, 64, 32, 0, 0.0, 0.0)
+    assert np.allclose(r[:3], o) and np.allclose(r[3:], (0, 1, 0))
+    r = O.generate_env_ray(o, 64, 32, 0, 16.0, 16.0)  # phi = pi/2, theta = pi/2
+    assert np.allclose(r[3:], (0, 0, 1), atol=1e-15)
+    top = O.generate_env_ray(o, 64, 32, 1, 0.0, 8.0)      # left eye, theta = pi/2, phi = 0: looks along +X
+    bot = O.generate_env_ray(o, 64, 32, 1, 0.0, 24.0)     # right eye, same direction
+    assert np.isclose(np.linalg.norm(top[:3] - o), 0.5) and np.isclose(np.linalg.norm(bot[:3] - o), 0.5)
+    assert np.allclose(top[:3] - o, -(bot[:3] - o))
+    assert np.isclose(np.linalg.norm(top[3:]), 1.0) and top[5] * bot[5] < 0  # toed in: opposite z components
+
+
 def test_table_mode_replays_stream():
     """Start states captured from a reference-stream run, replayed per pixel, give the same image: the bridge that
     lets a parallel (GPU) renderer be compared with the serial reference stream."""
