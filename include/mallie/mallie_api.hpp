@@ -266,6 +266,13 @@ struct RenderConfig {
 void Render(Scene &scene, const RenderConfig &config, std::vector<float> &image, std::vector<int> &count,
             const double eye[3], const double lookat[3], const double up[3], const double quat[4], int step);
 
+// One panoramic frame (render.h:56-60, render.cc:710-763): equirectangular rays, 10 PathTraceEnv samples per pixel with
+// the reference's kMaxPathLength = 16 whatever SetMaxPathLength says; overwrites image, count[px] += 10.  `stereo`: left
+// eye in the top half of the frame, right eye in the bottom half (camera.cc:259-329).  Seeded like Render; with
+// SetRenderRngTable the W*H*4 words are per-PIXEL start states (the pixel's 10 samples share one stream).
+void RenderPanoramic(Scene &scene, const RenderConfig &config, std::vector<float> &image, std::vector<int> &count,
+                     const double eye[3], const double lookat[3], const double up[3], const double quat[4], bool stereo);
+
 // Extensions (see the header comment).
 void SetMaxPathLength(int maxPathLength);          // default 16 (render.cc:52)
 void SetRenderSeed(unsigned long long seed);       // default 1; also restarts the pass counter

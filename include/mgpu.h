@@ -143,6 +143,26 @@ int mgpu_render_strips_device(MgpuScene *scene, const double frame[12], int W, i
                               const float plane[4], int rng_mode, const uint32_t *d_rng_states, uint64_t seed,
                               uint32_t pass_base, float *d_image, int32_t *d_count, void *stream, MgpuStats *stats);
 
+/* -- RenderPanoramic (render.cc:710-763; PathTraceEnv render.cc:518-590; Camera::GenerateEnvRay / GenerateStereoEnvRay
+ *    camera.cc:242-329) -- what the reference's console driver renders (main_console.cc:111) --------------------------- */
+/* One RenderPanoramic() call on the window [x0,x1) x [y0,y1) of a W x H equirectangular frame: every window pixel of
+ * `image_out` (3*W*H float32, full-frame indexing) is overwritten with the sum of `samples` (reference: 10) PathTraceEnv
+ * radiances, added as `float += double` sample after sample; count_out[px] += samples (may be NULL).
+ * origin = the camera frame's origin (mgpu_camera_frame); stereo != 0 selects GenerateStereoEnvRay (left eye in the top
+ * half of the frame); maxPathLength: the reference's kMaxPathLength, 16.
+ * A pixel's samples draw from ONE xorshift128 stream, so the RNG modes are per PIXEL: MGPU_RNG_TABLE reads the state at
+ * the pixel's first sample from rng_states[(y*W + x)*4 ..] (capture them from a reference-stream run to reproduce its
+ * image), MGPU_RNG_HASH uses mgpu_hash_state(seed, pass_base, y*W + x).  MGPU_RNG_STREAM is refused as in mgpu_render. */
+int mgpu_render_panoramic(MgpuScene *scene, const double origin[3], int W, int H, int x0, int y0, int x1, int y1,
+                          int maxPathLength, int samples, int stereo, int rng_mode, const uint32_t *rng_states,
+                          uint64_t seed, uint32_t pass_base, float *image_out, int32_t *count_out, MgpuStats *stats);
+/* The same with device buffers, asynchronous on `stream`: d_image (3 * (x1-x0) * (y1-y0) floats) and d_count are
+ * WINDOW-local, d_rng_states (TABLE mode) covers the full frame.  With stats != NULL the call waits for the kernel. */
+int mgpu_render_panoramic_device(MgpuScene *scene, const double origin[3], int W, int H, int x0, int y0, int x1, int y1,
+                                 int maxPathLength, int samples, int stereo, int rng_mode, const uint32_t *d_rng_states,
+                                 uint64_t seed, uint32_t pass_base, float *d_image, int32_t *d_count, void *stream,
+                                 MgpuStats *stats);
+
 /* Device work counters accumulate over every mgpu_render* call made with stats == NULL (calls with stats != NULL zero
  * them first and return that call's own counts).  mgpu_stats_read synchronises the device and returns the running
  * totals (kernel_ms / total_ms are left 0); reset != 0 zeroes them afterwards. */

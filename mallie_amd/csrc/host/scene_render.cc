@@ -242,6 +242,40 @@ void Render(Scene &scene, const RenderConfig &config, std::vector<float> &image,
   RenderPasses(scene, config, image, count, eye, lookat, up, quat, 1);
 }
 
+// RenderPanoramic, render.cc:710-763 (what main_console.cc:111 calls): 10 PathTraceEnv samples per pixel of an
+// equirectangular frame, maxPathLength 16; overwrites image, count[px] += 10.  Seeding as for Render (see the header).
+void RenderPanoramic(Scene &scene, const RenderConfig &config, std::vector<float> &image, std::vector<int> &count,
+                     const double eye[3], const double lookat[3], const double up[3], const double quat[4], bool stereo) {
+  const int width = config.width, height = config.height;
+  if (width <= 0 || height <= 0) return;
+  if (image.size() < (size_t)3 * width * height || count.size() < (size_t)width * height) {
+    printf("Mallie:err\tmsg:RenderPanoramic: image/count buffers are smaller than %dx%d\n", width, height);
+    return;
+  }
+  double origin[3], corner[3], du[3], dv[3];
+  Camera camera(eye, lookat, up);
+  camera.BuildCameraFrame(origin, corner, du, dv, config.fov, quat, width, height);
+  MgpuScene *dev = scene.DeviceScene();
+  if (!dev) {
+    printf("Mallie:err\tmsg:RenderPanoramic: no device scene (%s)\n", mgpu_last_error());
+    return;
+  }
+  const bool table = gRngTable != NULL;
+  MgpuStats st;
+  const int rc = mgpu_render_panoramic(dev, origin, width, height, 0, 0, width, height, /*kMaxPathLength*/ 16, /*samples*/ 10,
+                                       stereo ? 1 : 0, table ? MGPU_RNG_TABLE : MGPU_RNG_HASH, gRngTable, gSeed,
+                                       gPassCounter, &image[0], &count[0], &st);
+  gRngTable = NULL;
+  if (rc != MGPU_OK) {
+    printf("Mallie:err\tmsg:RenderPanoramic failed: %s\n", mgpu_last_error());
+    return;
+  }
+  gPassCounter += 1;
+  const double sec = st.total_ms / 1000.0;
+  printf("\r[Mallie] Render time: %f sec(s) | %f fps", sec, sec > 0 ? 1.0 / sec : 0.0);
+  fflush(stdout);
+}
+
 } // namespace mallie
 
 extern "C" void mgpu_plane_from_bbox(const double bmin[3], const double bmax[3], float plane[4]) {

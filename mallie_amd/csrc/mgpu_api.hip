@@ -722,6 +722,130 @@ int mgpu_render(MgpuScene *s, const double origin[3], const double corner[3], co
 #undef TRY_R
 }
 
+int mgpu_render_panoramic_device(MgpuScene *s, const double origin[3], int W, int H, int x0, int y0, int x1, int y1,
+                                 int maxPathLength, int samples, int stereo, int rng_mode, const uint32_t *d_rng_states,
+                                 uint64_t seed, uint32_t pass_base, float *d_image, int32_t *d_count, void *stream,
+                                 MgpuStats *stats) {
+  if (!s || !origin || !d_image) return fail(MGPU_ERR_INVALID, "NULL argument");
+  if (W <= 0 || H <= 0 || x0 < 0 || y0 < 0 || x1 > W || y1 > H || x0 > x1 || y0 > y1)
+    return fail(MGPU_ERR_INVALID, "bad window");
+  if (samples < 1 || maxPathLength < 1) return fail(MGPU_ERR_INVALID, "samples and maxPathLength must be >= 1");
+  if (rng_mode == MGPU_RNG_STREAM)
+    return fail(MGPU_ERR_UNSUPPORTED,
+                "the reference's serial RNG stream cannot be reproduced in parallel; capture per-pixel start states "
+                "and use MGPU_RNG_TABLE");
+  if (rng_mode != MGPU_RNG_TABLE && rng_mode != MGPU_RNG_HASH) return fail(MGPU_ERR_INVALID, "bad rng_mode %d", rng_mode);
+  if (rng_mode == MGPU_RNG_TABLE && !d_rng_states) return fail(MGPU_ERR_INVALID, "MGPU_RNG_TABLE needs rng_states");
+  const double t0 = now_ms();
+  int rc = set_device(s);
+  if (rc) return rc;
+  if (stats) memset(stats, 0, sizeof(*stats));
+  const int ww = x1 - x0, wh = y1 - y0;
+  if (ww == 0 || wh == 0) return MGPU_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const uint64_t tiles = (uint64_t)((ww + 7) / 8) * (uint64_t)((wh + 7) / 8);
+  uint64_t blocks = (uint64_t)s->num_cu * 4; // 16 waves per CU
+  const uint64_t max_useful = (tiles * 64 + kBlock - 1) / kBlock;
+  if (blocks > max_useful) blocks = max_useful;
+  if (blocks < 1) blocks = 1;
+  rc = ensure_overflow(s, blocks * kBlock);
+  if (rc) return rc;
+  EnvParams P;
+  memcpy(P.origin, origin, sizeof(P.origin));
+  {
+    // psi = atan2(r, focal_length) with r = 0.5, focal_length = 4.0 (camera.cc:261-262,311): the host's libm, as the reference
+    const double psi = std::atan2(0.5, 4.0);
+    P.cos_psi = std::cos(psi);
+    P.sin_psi = std::sin(psi);
+  }
+  P.W = W; P.H = H; P.x0 = x0; P.y0 = y0; P.win_w = ww; P.win_h = wh;
+  P.maxPathLength = maxPathLength; P.samples = samples; P.stereo = stereo ? 1 : 0;
+  P.rng_mode = rng_mode;
+  P.rng_states = d_rng_states;
+  P.seed = seed;
+  P.pass_base = pass_base;
+  P.image = d_image;
+  P.count = d_count;
+  P.work_counter = s->p_counters + (size_t)(s->launch_seq++ % kCounterRing) * kShards;
+  P.stats = s->p_stats;
+  HIP_TRY(hipMemsetAsync(P.work_counter, 0, sizeof(uint32_t), st));
+  if (stats) {
+    HIP_TRY(hipMemsetAsync(s->p_stats, 0, sizeof(unsigned long long) * kStatWords, st));
+    HIP_TRY(hipEventRecord(s->ev0, st));
+  }
+  HIP_TRY(launch_render_env(s->cap, dim3((unsigned)blocks), st, s->d, P));
+  if (stats) {
+    HIP_TRY(hipEventRecord(s->ev1, st));
+    unsigned long long w[kStatWords];
+    HIP_TRY(hipMemcpyAsync(w, s->p_stats, sizeof(w), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    read_stats(w, stats);
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    stats->kernel_ms = ms;
+    stats->total_ms = now_ms() - t0;
+  }
+  return MGPU_OK;
+}
+
+int mgpu_render_panoramic(MgpuScene *s, const double origin[3], int W, int H, int x0, int y0, int x1, int y1,
+                          int maxPathLength, int samples, int stereo, int rng_mode, const uint32_t *rng_states,
+                          uint64_t seed, uint32_t pass_base, float *image_out, int32_t *count_out, MgpuStats *stats) {
+  if (!s || !origin || !image_out) return fail(MGPU_ERR_INVALID, "NULL argument");
+  if (W <= 0 || H <= 0 || x0 < 0 || y0 < 0 || x1 > W || y1 > H || x0 > x1 || y0 > y1)
+    return fail(MGPU_ERR_INVALID, "bad window");
+  if (samples < 1) return fail(MGPU_ERR_INVALID, "samples must be >= 1");
+  const double t0 = now_ms();
+  int rc = set_device(s);
+  if (rc) return rc;
+  if (stats) memset(stats, 0, sizeof(*stats));
+  const int ww = x1 - x0, wh = y1 - y0;
+  if (ww == 0 || wh == 0) return MGPU_OK;
+  float *d_img = nullptr;
+  uint32_t *d_states = nullptr;
+  auto cleanup = [&]() {
+    if (d_img) (void)hipFree(d_img);
+    if (d_states) (void)hipFree(d_states);
+  };
+#define TRY_R(expr)                                                                                   \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess) {                                                                           \
+      cleanup();                                                                                      \
+      return fail(MGPU_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));                       \
+    }                                                                                                 \
+  } while (0)
+  TRY_R(hipMalloc((void **)&d_img, sizeof(float) * 3 * (size_t)ww * wh));
+  if (rng_mode == MGPU_RNG_TABLE) {
+    if (!rng_states) {
+      cleanup();
+      return fail(MGPU_ERR_INVALID, "MGPU_RNG_TABLE needs rng_states");
+    }
+    const size_t bytes = (size_t)W * H * 16;
+    TRY_R(hipMalloc((void **)&d_states, bytes));
+    TRY_R(hipMemcpy(d_states, rng_states, bytes, hipMemcpyHostToDevice));
+  }
+  MgpuStats local;
+  rc = mgpu_render_panoramic_device(s, origin, W, H, x0, y0, x1, y1, maxPathLength, samples, stereo, rng_mode, d_states,
+                                    seed, pass_base, d_img, nullptr, nullptr, &local);
+  if (rc) {
+    cleanup();
+    return rc;
+  }
+  TRY_R(hipMemcpy2D(image_out + 3 * ((size_t)y0 * W + x0), sizeof(float) * 3 * (size_t)W, d_img,
+                    sizeof(float) * 3 * (size_t)ww, sizeof(float) * 3 * (size_t)ww, (size_t)wh, hipMemcpyDeviceToHost));
+  cleanup();
+  if (count_out)
+    for (int y = y0; y < y1; y++)
+      for (int x = x0; x < x1; x++) count_out[(size_t)y * W + x] += samples;
+  if (stats) {
+    *stats = local;
+    stats->total_ms = now_ms() - t0;
+  }
+  return MGPU_OK;
+#undef TRY_R
+}
+
 int mgpu_stats_read(MgpuScene *s, MgpuStats *out, int reset) {
   if (!s || !out) return fail(MGPU_ERR_INVALID, "NULL argument");
   int rc = set_device(s);

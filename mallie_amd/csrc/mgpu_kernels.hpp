@@ -58,6 +58,23 @@ int pick_stack_cap(int needed_entries);
 // wave-scheduled state-machine renderer (mgpu_render_sm.hip); shmem = stacks (+ scene when lds_scene)
 hipError_t launch_render_sm(int cap, bool lds_scene, int block, dim3 grid, hipStream_t s, size_t shmem, const DScene &sc,
                             const RenderParams &p);
+// k_render_env (mgpu_render_env.hip): RenderPanoramic
+struct EnvParams {
+  double origin[3];        // Camera::origin_ (BuildCameraFrame)
+  double cos_psi, sin_psi; // cos / sin of atan2(0.5, 4.0), the stereo toe-in (camera.cc:311), from the host's libm
+  int W, H;                // full frame: the spherical angles and the RNG states index the full frame
+  int x0, y0, win_w, win_h; // window; image / count are window-local
+  int maxPathLength, samples, stereo;
+  int rng_mode;
+  const uint32_t *rng_states; // device, 4 words per pixel of the full frame, or null
+  unsigned long long seed;
+  uint32_t pass_base;
+  float *image;   // device, 3 * win_w * win_h, overwritten
+  int32_t *count; // device, win_w * win_h, += samples; may be null
+  uint32_t *work_counter; // one zeroed word
+  unsigned long long *stats;
+};
+hipError_t launch_render_env(int cap, dim3 grid, hipStream_t s, const DScene &sc, const EnvParams &p);
 // k_trace_sm (mgpu_trace_sm.hip): persistent, wave-scheduled batched trace; `counter` = one zeroed device word
 hipError_t launch_trace_sm(int cap, dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, uint32_t n,
                            MgpuIntersection *out, uint8_t *hit, uint32_t *counter, unsigned long long *stats);

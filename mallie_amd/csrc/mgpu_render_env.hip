@@ -1,0 +1,351 @@
+// mgpu_render_env.hip -- k_render_env: RenderPanoramic (render.cc:710-763) = 10 PathTraceEnv paths (render.cc:518-590) per
+// pixel over equirectangular rays (Camera::GenerateEnvRay / GenerateStereoEnvRay, camera.cc:242-329).  This is what the
+// reference's console driver renders (main_console.cc:111).
+//
+// Same wave-scheduled traversal as k_render_sm / k_trace_sm (lane states NODE / TRI / SHADE, one body per trip of the
+// wave loop).  What differs from PathTrace:
+//   * no ground plane, no material, no throughput: a path's radiance is 0 or sum_{L = L0..maxPathLength} 0.5 / L, L0 >= 2
+//     being the length at which it first missed (the reference keeps iterating after that miss with a stale record,
+//     SURVEY F4; those rays start ~1e308 away and are evaluated in closed loop here, same additions in the same order);
+//   * a pixel's `samples` paths draw from ONE xorshift128 stream (loop nest y, x, sample), so a lane owns a pixel for all
+//     its samples, replays the draws the reference makes after a miss (3 per remaining iteration) and accumulates
+//     `image[px] += radiance` exactly as written there: float += double, sample after sample;
+//   * primary rays come from sin / cos of the pixel's spherical angles (device sincos: <= 1 ulp from glibc; radiance
+//     depends on hit / miss events only, see DESIGN.md "Numerics").
+#include "mgpu_device.hpp"
+#include "mgpu_kernels.hpp"
+
+namespace mgpu {
+
+namespace {
+enum : int { ES_NODE = 0, ES_TRI = 1, ES_SHADE = 2, ES_IDLE = 3 };
+constexpr int kEnvBlock = 256;
+} // namespace
+
+#ifndef MGPU_ENV_SHADE_MIN
+#define MGPU_ENV_SHADE_MIN 32
+#endif
+
+template <int CAP, bool OVF>
+__global__ __launch_bounds__(kEnvBlock, 4) void k_render_env(DScene sc, EnvParams P_arg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ EnvParams s_P; // launch parameters live in LDS, not in scalar registers (see k_render_sm)
+  __shared__ unsigned long long s_cnt[5];
+  if (threadIdx.x == 0) s_P = P_arg;
+  if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0ull;
+  __syncthreads();
+  const EnvParams &P = s_P;
+  uint32_t *s_stack = reinterpret_cast<uint32_t *>(smem); // [waves][CAP][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t slot = (size_t)blockIdx.x * kEnvBlock + threadIdx.x;
+  Stack<CAP, OVF> stk;
+  stk.lds = s_stack + ((size_t)wave * CAP) * 64 + lane;
+  stk.overflow = (OVF && sc.stack_overflow) ? sc.stack_overflow + slot * sc.overflow_cap : nullptr;
+
+  const uint32_t tiles_x = (uint32_t)(P.win_w + 7) >> 3, tiles_y = (uint32_t)(P.win_h + 7) >> 3;
+  const uint32_t total_tiles = tiles_x * tiles_y;
+  // wave-uniform cursor: the current 8x8 tile and the position inside it
+  uint32_t cur_tile = 0, in_tile = 64;
+  bool exhausted = false;
+
+  // per-lane pixel / path state
+  int st = ES_SHADE;
+  bool have_ray = false, have_pixel = false;
+  uint32_t lx = 0, ly = 0;
+  int sample = 0;
+  float acc = 0.0f;    // the pixel's running sum; R = G = B for this integrator
+  double rad = 0.0;    // the current path's radiance
+  Rng rng{1, 0, 0, 0};
+  V3 org = v3(0, 0, 0), dir = v3(0, 0, 1);
+  int pathLength = 1;
+  // per-lane traversal state
+  double ix = 0, iy = 0, iz = 0;
+  bool sx = false, sy = false, sz = false;
+  int sp = -1;
+  double bt = kDblMax, bu = 0, bv = 0;
+  uint32_t bslot = kNoHit;
+  uint32_t tri_cur = 0, tri_end = 0;
+  uint32_t n_rays = 0, n_nodes = 0, n_tris = 0, trace_calls = 0, paths = 0;
+
+  for (;;) {
+    const unsigned long long mN = __ballot(st == ES_NODE);
+    const unsigned long long mT = __ballot(st == ES_TRI);
+    const unsigned long long mS = __ballot(st == ES_SHADE);
+    const int cN = __popcll(mN), cT = __popcll(mT), cS = __popcll(mS);
+    if ((cN | cT | cS) == 0) break;
+    const bool run_shade = (cS >= MGPU_ENV_SHADE_MIN) || (cN == 0 && cT == 0);
+    if (!run_shade && cN >= cT) {
+      // ================================ NODE step ================================
+      if (st == ES_NODE) {
+#pragma unroll 1
+        for (int rep = 0; rep < 4; ++rep) {
+          const uint32_t ni = stk.get(sp);
+          --sp;
+          ++n_nodes;
+          const MgpuNode *nd = sc.nodes + ni;
+          const double2 b0 = *reinterpret_cast<const double2 *>(&nd->bmin[0]);
+          const double2 b1 = *reinterpret_cast<const double2 *>(&nd->bmin[2]);
+          const double2 b2 = *reinterpret_cast<const double2 *>(&nd->bmax[1]);
+          const int4 meta = *reinterpret_cast<const int4 *>(&nd->flag);
+          // IntersectRayAABB, bvh_accel.cc:550-593
+          const double nx = sx ? b1.y : b0.x, fx = sx ? b0.x : b1.y;
+          const double ny = sy ? b2.x : b0.y, fy = sy ? b0.y : b2.x;
+          const double nz = sz ? b2.y : b1.x, fz = sz ? b1.x : b2.y;
+          const double tmin_x = (nx - org.x) * ix, tmax_x = (fx - org.x) * ix;
+          const double tmin_y = (ny - org.y) * iy, tmax_y = (fy - org.y) * iy;
+          double tmin = (tmin_x > tmin_y) ? tmin_x : tmin_y;
+          double tmax = (tmax_x < tmax_y) ? tmax_x : tmax_y;
+          const double tmin_z = (nz - org.z) * iz, tmax_z = (fz - org.z) * iz;
+          tmin = (tmin > tmin_z) ? tmin : tmin_z;
+          tmax = (tmax < tmax_z) ? tmax : tmax_z;
+          const bool hit = (tmax > 0.0) && (tmin <= tmax) && (tmin <= bt);
+          if (hit) {
+            if (meta.x == 0) {
+              const bool nearIsSecond = (meta.y == 0) ? sx : ((meta.y == 1) ? sy : sz); // dirSign[node.axis]
+              const uint32_t c0 = (uint32_t)meta.z, c1 = (uint32_t)meta.w;
+              stk.put(sp + 1, nearIsSecond ? c0 : c1); // far
+              stk.put(sp + 2, nearIsSecond ? c1 : c0); // near: popped first
+              sp += 2;
+            } else if (meta.z != 0) {
+              tri_cur = (uint32_t)meta.w;
+              tri_end = (uint32_t)meta.w + (uint32_t)meta.z;
+              st = ES_TRI;
+            }
+          }
+          if (st != ES_NODE || sp < 0) break;
+        }
+        if (st == ES_NODE && sp < 0) st = ES_SHADE;
+      }
+    } else if (!run_shade) {
+      // ================================ TRI step =================================
+      if (st == ES_TRI) {
+#pragma unroll 1
+        for (int rep = 0; rep < 16; ++rep) {
+          const DTri *tp = sc.tris + tri_cur;
+          const double2 a0 = reinterpret_cast<const double2 *>(tp)[0];
+          const double2 a1 = reinterpret_cast<const double2 *>(tp)[1];
+          const double2 a2 = reinterpret_cast<const double2 *>(tp)[2];
+          const double2 a3 = reinterpret_cast<const double2 *>(tp)[3];
+          const double e2z = tp->e2[2];
+          ++n_tris;
+          // TriangleIsect, bvh_accel.cc:595-638
+          const V3 p0 = v3(a0.x, a0.y, a1.x), e1 = v3(a1.y, a2.x, a2.y), e2 = v3(a3.x, a3.y, e2z);
+          const V3 p = cross(dir, e2);
+          const double det = dot(e1, p);
+          if (!(fabs(det) < kDblEps1024)) {
+            const double invDet = 1.0 / det;
+            const V3 s = org - p0;
+            const V3 q = cross(s, e1);
+            const double u = dot(s, p) * invDet;
+            const double v = dot(q, dir) * invDet;
+            const double t = dot(e2, q) * invDet;
+            const bool rej = (u < 0.0 || u > 1.0) || (v < 0.0 || u + v > 1.0) || (t < 0.0 || t > bt);
+            if (!rej) {
+              bt = t;
+              bu = u;
+              bv = v;
+              bslot = tri_cur;
+            }
+          }
+          ++tri_cur;
+          if (tri_cur == tri_end) break;
+        }
+        if (tri_cur == tri_end) st = (sp < 0) ? ES_SHADE : ES_NODE;
+      }
+    } else {
+      // ================================ SHADE step ===============================
+      const bool shade_lane = (st == ES_SHADE);
+      bool path_done = false;
+      if (shade_lane) {
+        path_done = !have_ray && !have_pixel ? true : false; // a lane without a pixel asks for one below
+        if (have_ray) {
+          // ---- the rest of one PathTraceEnv loop iteration (render.cc:541-585) ----
+          const bool hit = bt < kDblMax; // bvh_accel.cc:838
+          if (!hit) {
+            path_done = true;
+            if (pathLength < 2) {
+              trace_calls += 1; // eye ray -> background (render.cc:543-546)
+            } else {
+              // first miss at length L0 >= 2: the reference adds 0.5 / L for L = L0 .. maxPathLength, tracing garbage
+              // rays in between and drawing three random numbers per remaining iteration (render.cc:563-574)
+              trace_calls += (uint32_t)P.maxPathLength;
+              for (int L = pathLength;; ++L) {
+                rad += 0.5 / (double)(unsigned)L;
+                if (L >= P.maxPathLength) break;
+                (void)rng_next(rng);
+                (void)rng_next(rng);
+                (void)rng_next(rng);
+              }
+            }
+          } else if (pathLength >= P.maxPathLength) {
+            path_done = true;
+            trace_calls += (uint32_t)P.maxPathLength;
+          } else {
+            V3 n;
+            if (sc.has_fv_normals) { // barycentric lerp, not renormalised (bvh_accel.cc:745-748)
+              const double *nn = sc.slot_normal + 9 * (size_t)bslot;
+              const double w = 1.0 - bu - bv;
+              n = v3(w * nn[0] + bu * nn[3] + bv * nn[6], w * nn[1] + bu * nn[4] + bv * nn[7],
+                     w * nn[2] + bu * nn[5] + bv * nn[8]);
+            } else {
+              const double *gn = sc.slot_normal + 3 * (size_t)bslot;
+              n = v3(gn[0], gn[1], gn[2]);
+            }
+            const V3 hitP = org + scale(dir, bt);
+            (void)rng_next(rng); // `double r = randomreal();` drawn and never used (render.cc:563)
+            const double ndoti = dot(n, neg(dir));
+            if (ndoti < 0.0) n = neg(n);
+            const V3 sd = sample_diffuse(n, rng);
+            org = hitP + scale(sd, 1.0e-3);
+            dir = sd;
+            ++pathLength;
+          }
+          have_ray = false;
+          if (path_done) {
+            // image[...] += radiance (render.cc:749-751): float += double, one sample after the other
+            acc = (float)((double)acc + rad);
+            ++sample;
+            if (sample >= P.samples) {
+              const size_t o = (size_t)ly * (size_t)P.win_w + lx;
+              P.image[3 * o + 0] = acc;
+              P.image[3 * o + 1] = acc;
+              P.image[3 * o + 2] = acc;
+              if (P.count) P.count[o] += P.samples;
+              have_pixel = false;
+            }
+          }
+        }
+      }
+      // ---- pixel hand-out, executed by the whole wave (the cursor is wave-uniform) ----
+      bool want = shade_lane && !have_pixel && !have_ray;
+      for (;;) {
+        const unsigned long long wm = __ballot(want);
+        if (!wm || exhausted) break;
+        if (in_tile >= 64) {
+          uint32_t t = 0;
+          if (lane == 0) t = atomicAdd(P.work_counter, 1u);
+          t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+          if (t >= total_tiles) { exhausted = true; break; }
+          cur_tile = t;
+          in_tile = 0;
+        }
+        if (want) {
+          const uint32_t rank = __popcll(wm & ((1ull << lane) - 1ull));
+          const uint32_t s = in_tile + rank;
+          if (s < 64) {
+            const uint32_t x = (cur_tile % tiles_x) * 8 + (s & 7), y = (cur_tile / tiles_x) * 8 + (s >> 3);
+            if (x < (uint32_t)P.win_w && y < (uint32_t)P.win_h) { // slots of an edge tile outside the window are skipped
+              lx = x; ly = y;
+              have_pixel = true;
+              want = false;
+              // the pixel's stream (render.cc:743-753): all its samples draw from it one after the other
+              const uint32_t gpix = (uint32_t)(P.y0 + (int)y) * (uint32_t)P.W + (uint32_t)(P.x0 + (int)x);
+              uint32_t s4[4];
+              if (P.rng_mode == MGPU_RNG_TABLE) {
+                const uint4 q = reinterpret_cast<const uint4 *>(P.rng_states)[gpix];
+                s4[0] = q.x; s4[1] = q.y; s4[2] = q.z; s4[3] = q.w;
+              } else {
+                hash_state(P.seed, P.pass_base, gpix, s4);
+              }
+              rng = Rng{s4[0], s4[1], s4[2], s4[3]};
+              acc = 0.0f; // memset(image) of render.cc:737
+              sample = 0;
+              path_done = true;
+            }
+          }
+        }
+        in_tile += (uint32_t)__popcll(wm);
+        if (in_tile > 64) in_tile = 64;
+      }
+      // ---- next path / next traversal ----
+      if (shade_lane) {
+        if (!have_pixel) {
+          st = ES_IDLE; // no pixel left for this lane
+        } else {
+          if (path_done) {
+            // PathTraceEnv prologue (render.cc:523-534): jitter, equirectangular ray
+            const float ju = (float)(rng_next(rng) - 0.5);
+            const float jv = (float)(rng_next(rng) - 0.5);
+            const double u = (double)((float)(P.x0 + (int)lx) + ju), v = (double)((float)(P.y0 + (int)ly) + jv);
+            const double kPi = 3.14159265358979323846, k2Pi = 6.283185307179586; // M_PI, 2.0 * M_PI
+            const double phi = k2Pi * (u / (double)P.W);
+            double sin_p, cos_p, sin_t, cos_t;
+            sincos(phi, &sin_p, &cos_p);
+            if (!P.stereo) { // Camera::GenerateEnvRay, camera.cc:242-257
+              const double theta = kPi * (v / (double)P.H);
+              sincos(theta, &sin_t, &cos_t);
+              org = v3(P.origin[0], P.origin[1], P.origin[2]);
+              dir = v3(sin_t * cos_p, cos_t, sin_t * sin_p);
+            } else { // Camera::GenerateStereoEnvRay, camera.cc:259-329
+              const bool left = v < (double)(P.H >> 1);
+              const double theta = kPi * fmod(2.0 * v / (double)P.H, 1.0);
+              sincos(theta, &sin_t, &cos_t);
+              const V3 d0 = v3(sin_t * cos_p, cos_t, sin_t * sin_p);
+              V3 par = left ? v3(-d0.z, 0.0, d0.x) : v3(d0.z, 0.0, -d0.x);
+              par = scale(normalized(par), 0.5);
+              org = v3(P.origin[0] + par.x, P.origin[1] + par.y, P.origin[2] + par.z);
+              // psi = atan2(0.5, 4), negated for the left eye; cos / sin of it come from the host's libm
+              const double cpsi = P.cos_psi, spsi = left ? -P.sin_psi : P.sin_psi;
+              dir = normalized(v3(d0.x * cpsi - d0.z * spsi, d0.y, d0.x * spsi + d0.z * cpsi));
+            }
+            rad = 0.0;
+            pathLength = 1;
+            ++paths;
+          }
+          // arm the traversal of (org, dir): BVHAccel::Traverse prologue, bvh_accel.cc:774-802
+          sx = dir.x < 0.0; sy = dir.y < 0.0; sz = dir.z < 0.0;
+          ix = 1.0 / dir.x; iy = 1.0 / dir.y; iz = 1.0 / dir.z; // no zero guard, as the reference
+          bt = kDblMax; bu = 0.0; bv = 0.0; bslot = kNoHit;
+          sp = 0;
+          stk.put(0, 0u);
+          have_ray = true;
+          ++n_rays;
+          st = ES_NODE;
+        }
+      }
+    }
+  }
+
+  // counters: wave reduction, one LDS atomic per wave, one global atomic per workgroup and word
+  unsigned long long v0 = trace_calls, v1 = n_rays, v2 = n_nodes, v3_ = n_tris, v4 = paths;
+  for (int off = 32; off; off >>= 1) {
+    v0 += __shfl_down(v0, off);
+    v1 += __shfl_down(v1, off);
+    v2 += __shfl_down(v2, off);
+    v3_ += __shfl_down(v3_, off);
+    v4 += __shfl_down(v4, off);
+  }
+  if (lane == 0) {
+    atomicAdd(&s_cnt[0], v0);
+    atomicAdd(&s_cnt[1], v1);
+    atomicAdd(&s_cnt[2], v2);
+    atomicAdd(&s_cnt[3], v3_);
+    atomicAdd(&s_cnt[4], v4);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && P.stats) {
+    atomicAdd(&P.stats[kStatTraceCalls], s_cnt[0]);
+    atomicAdd(&P.stats[kStatRays], s_cnt[1]);
+    atomicAdd(&P.stats[kStatNodes], s_cnt[2]);
+    atomicAdd(&P.stats[kStatTris], s_cnt[3]);
+    atomicAdd(&P.stats[kStatPaths], s_cnt[4]);
+  }
+}
+
+template <int CAP, bool OVF>
+static hipError_t launch_one(dim3 grid, hipStream_t s, const DScene &sc, const EnvParams &p) {
+  const size_t shmem = (size_t)(kEnvBlock / 64) * CAP * 64 * sizeof(uint32_t);
+  hipLaunchKernelGGL((k_render_env<CAP, OVF>), grid, dim3(kEnvBlock), shmem, s, sc, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_render_env(int cap, dim3 grid, hipStream_t s, const DScene &sc, const EnvParams &p) {
+  const bool ovf = sc.overflow_cap != 0;
+  if (cap == 16 && !ovf) return launch_one<16, false>(grid, s, sc, p);
+  if (cap == 24 && !ovf) return launch_one<24, false>(grid, s, sc, p);
+  if (cap == 32 && !ovf) return launch_one<32, false>(grid, s, sc, p);
+  if (cap == 32 && ovf) return launch_one<32, true>(grid, s, sc, p);
+  return hipErrorInvalidConfiguration;
+}
+
+} // namespace mgpu

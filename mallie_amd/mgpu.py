@@ -85,6 +85,12 @@ def load_library():
     L.mgpu_stats_read.restype = i32
     L.mgpu_debug_words.argtypes = [vp, vp]
     L.mgpu_debug_words.restype = i32
+    L.mgpu_render_panoramic.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, u64, u32, vp, vp,
+                                        C.POINTER(Stats)]
+    L.mgpu_render_panoramic.restype = i32
+    L.mgpu_render_panoramic_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, u64, u32, vp, vp,
+                                               vp, C.POINTER(Stats)]
+    L.mgpu_render_panoramic_device.restype = i32
     L.mgpu_trace_device.argtypes = [vp, vp, sz, vp, vp, vp, C.POINTER(Stats)]
     L.mgpu_trace_device.restype = i32
     L.mgpu_debug_tile_order.argtypes = [vp, vp, vp, sz]
@@ -275,6 +281,33 @@ class Scene:
                                           x0, y0, x1, y1, maxPathLength, passes, _p(plane), rng_mode, _p(rng_states),
                                           seed, pass_base, _p(image), _p(count), C.byref(st)), "mgpu_render")
         return image, count, st.as_dict()
+
+    def render_panoramic(self, origin, W, H, stereo, maxPathLength=16, samples=10, rng_mode=RNG_HASH, rng_states=None,
+                         seed=1, pass_base=0, window=None, image=None, count=None):
+        """mgpu_render_panoramic into host buffers -> (image HxWx3 float32, count HxW int32, stats dict)"""
+        origin = _c(origin, "<f8")
+        x0, y0, x1, y1 = window if window is not None else (0, 0, W, H)
+        image = np.zeros((H, W, 3), "<f4") if image is None else image
+        count = np.zeros((H, W), "<i4") if count is None else count
+        rng_states = _c(rng_states, "<u4")
+        st = Stats()
+        _check(load_library().mgpu_render_panoramic(self.h, _p(origin), W, H, x0, y0, x1, y1, maxPathLength, samples,
+                                                    int(stereo), rng_mode, _p(rng_states), seed, pass_base, _p(image),
+                                                    _p(count), C.byref(st)), "mgpu_render_panoramic")
+        return image, count, st.as_dict()
+
+    def render_panoramic_device(self, origin, W, H, stereo, d_image_ptr, maxPathLength=16, samples=10, rng_mode=RNG_HASH,
+                                d_rng_states_ptr=None, seed=1, pass_base=0, window=None, d_count_ptr=None, stream=None,
+                                want_stats=False):
+        """mgpu_render_panoramic_device: window-local device image / count at raw addresses, asynchronous on `stream`."""
+        origin = _c(origin, "<f8")
+        x0, y0, x1, y1 = window if window is not None else (0, 0, W, H)
+        st = Stats()
+        _check(load_library().mgpu_render_panoramic_device(
+            self.h, _p(origin), W, H, x0, y0, x1, y1, maxPathLength, samples, int(stereo), rng_mode,
+            C.c_void_p(d_rng_states_ptr or 0), seed, pass_base, C.c_void_p(d_image_ptr), C.c_void_p(d_count_ptr or 0),
+            C.c_void_p(stream or 0), C.byref(st) if want_stats else None), "mgpu_render_panoramic_device")
+        return st.as_dict() if want_stats else None
 
     def stats_read(self, reset=True):
         """Running device work counters since the last reset (synchronises)."""

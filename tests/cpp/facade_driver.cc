@@ -73,6 +73,22 @@ int main(int argc, char **argv) {
     if (memcmp(&image2[0], &accum[0], 4 * accum.size()) != 0) { fprintf(stderr, "RenderPasses != Render+AccumImage\n"); return 7; }
     return 0;
   }
+  if (!strcmp(argv[1], "panoramic") && argc >= 9) {   // what main_console.cc:95-111 does for one frame
+    mallie::Scene scene;
+    if (!init(scene, argv[2], argv[3], 1.0)) return 3;
+    mallie::RenderConfig config;
+    config.width = atoi(argv[4]); config.height = atoi(argv[5]);
+    const bool stereo = atoi(argv[6]) != 0;
+    mallie::SetRenderSeed(strtoull(argv[7], NULL, 10));
+    std::vector<float> image(3 * (size_t)config.width * config.height);
+    std::vector<int> count((size_t)config.width * config.height, 0);
+    double eye[3] = {0.0, 1.0, 4.0};
+    mallie::RenderPanoramic(scene, config, image, count, eye, config.lookat, config.up, config.quat, stereo);
+    FILE *fp = fopen(argv[8], "wb");
+    wr(fp, &image[0], 4 * image.size()); wr(fp, &count[0], 4 * count.size());
+    fclose(fp);
+    return 0;
+  }
   if (!strcmp(argv[1], "trace") && argc >= 6) {
     mallie::Scene scene;
     if (!init(scene, argv[2], argv[3], 1.0)) return 3;

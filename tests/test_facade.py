@@ -131,6 +131,28 @@ def test_facade_render_and_trace_on_gpu(driver, tmp_path):
 
 
 @pytest.mark.gpu
+def test_facade_render_panoramic_on_gpu(driver, tmp_path):
+    """mallie::RenderPanoramic through the Mallie-named facade (the console driver's call) vs the oracle, same seeding."""
+    obj = str(tmp_path / "cornell_like.obj")
+    _write_cornell_obj(obj)
+    W, H, seed = 96, 48, 7
+    g = O.load_golden("cornell_obj")
+    osc = O.OracleScene(g["verts"].astype(np.float64), g["faces"], np.full(len(g["faces"]), 0xFFFFFFFF, "u4"), g["normals"], None)
+    origin = O.camera_frame((0.0, 1.0, 4.0), (0, 0, 0), width=W, height=H)[:3]
+    for stereo in (0, 1):
+        out = str(tmp_path / ("pano%d.f32" % stereo))
+        r = subprocess.run([driver, "panoramic", "obj", obj, str(W), str(H), str(stereo), str(seed), out],
+                           capture_output=True, text=True, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stdout + r.stderr
+        raw = np.fromfile(out, "<f4")
+        img = raw[: 3 * W * H].reshape(H, W, 3)
+        count = raw[3 * W * H:].view("<i4").reshape(H, W)
+        assert np.all(count == 10)
+        oimg, _, _, _ = osc.render_panoramic(origin, W, H, stereo, 16, 10, O.RNG_HASH, seed=seed)
+        assert img.tobytes() == oimg.tobytes(), "%d pixels differ" % int((img != oimg).any(-1).sum())
+
+
+@pytest.mark.gpu
 def test_facade_build_routes_large_meshes_to_the_device_builder(driver, tmp_path):
     """BVHAccel::Build sends meshes of >= 65536 triangles to mgpu_bvh_build_device; the tree must equal the host
     builder's (and MALLIE_BVH_BUILD=host must give the same file)."""
