@@ -240,45 +240,38 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
       return fail(MGPU_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
     }
   }
-  // slot-ordered triangle records: p0, e1 = p1-p0, e2 = p2-p0 (bvh_accel.cc:606-607), face id, material id
-  std::vector<DTri> tris(nf);
-  const size_t nstride = fv_normals ? 9 : 3;
-  std::vector<double> slotn(nstride * nf);
-  for (size_t slot = 0; slot < nf; slot++) {
-    const uint32_t face = indices[slot];
-    const double *p0 = verts + 3 * (size_t)faces[3 * (size_t)face + 0];
-    const double *p1 = verts + 3 * (size_t)faces[3 * (size_t)face + 1];
-    const double *p2 = verts + 3 * (size_t)faces[3 * (size_t)face + 2];
-    DTri &t = tris[slot];
-    for (int k = 0; k < 3; k++) {
-      t.p0[k] = p0[k];
-      t.e1[k] = p1[k] - p0[k];
-      t.e2[k] = p2[k] - p0[k];
-    }
-    t.face = face;
-    t.mat = matIDs ? matIDs[face] : kNoMaterial;
-    if (fv_normals) {
-      memcpy(&slotn[9 * slot], fv_normals + 9 * (size_t)face, 9 * sizeof(double));
-    } else {
-      // geometric normal of BuildIntersection (bvh_accel.cc:723-729): normalize(cross(p1-p0, p2-p0)), len guard 1e-6
-      const double *a = t.e1, *b = t.e2;
-      double n[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
-      const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-      if (std::fabs(len) > 1.0e-6) {
-        const double inv = 1.0 / len;
-        n[0] *= inv; n[1] *= inv; n[2] *= inv;
-      }
-      memcpy(&slotn[3 * slot], n, sizeof(n));
-    }
-  }
   TRY_OR_FREE(upload(s, &s->p_nodes, nodes, sizeof(MgpuNode) * nn));
-  TRY_OR_FREE(upload(s, &s->p_tris, tris.data(), sizeof(DTri) * nf));
-  TRY_OR_FREE(upload(s, &s->p_slotn, slotn.data(), sizeof(double) * slotn.size()));
   TRY_OR_FREE(upload(s, &s->p_mat, mat_diffuse, sizeof(double) * 3 * nm));
   TRY_OR_FREE(upload(s, &s->p_verts, verts, sizeof(double) * 3 * nv));
   TRY_OR_FREE(upload(s, &s->p_faces, faces, sizeof(uint32_t) * 3 * nf));
   TRY_OR_FREE(upload(s, &s->p_fvn, fv_normals, fv_normals ? sizeof(double) * 9 * nf : 0));
   TRY_OR_FREE(upload(s, &s->p_fvuv, fv_uvs, fv_uvs ? sizeof(double) * 6 * nf : 0));
+  // slot-ordered triangle records (p0, e1 = p1-p0, e2 = p2-p0 of bvh_accel.cc:606-607, face id, material id) and
+  // per-slot shading normals are laid out on the device from the arrays just uploaded (k_scene_layout)
+  {
+    void *d_idx = nullptr, *d_mat = nullptr;
+    TRY_OR_FREE(upload(s, &d_idx, indices, sizeof(uint32_t) * nf));
+    if (matIDs) TRY_OR_FREE(upload(s, &d_mat, matIDs, sizeof(uint32_t) * nf));
+    int lrc = dev_alloc(s, &s->p_tris, sizeof(DTri) * nf);
+    if (!lrc) lrc = dev_alloc(s, &s->p_slotn, sizeof(double) * (fv_normals ? 9 : 3) * nf);
+    hipError_t e = hipSuccess;
+    if (!lrc) {
+      launch_scene_layout(0, (const double *)s->p_verts, (const uint32_t *)s->p_faces, (const uint32_t *)d_idx,
+                          (const uint32_t *)d_mat, (const double *)s->p_fvn, nf, (DTri *)s->p_tris, (double *)s->p_slotn);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    if (d_idx) { (void)hipFree(d_idx); s->device_bytes -= sizeof(uint32_t) * nf; }
+    if (d_mat) { (void)hipFree(d_mat); s->device_bytes -= sizeof(uint32_t) * nf; }
+    if (lrc) {
+      mgpu_scene_destroy(s);
+      return lrc;
+    }
+    if (e != hipSuccess) {
+      mgpu_scene_destroy(s);
+      return fail(MGPU_ERR_HIP, "scene layout kernel: %s", hipGetErrorString(e));
+    }
+  }
   TRY_OR_FREE(dev_alloc(s, (void **)&s->p_counters, sizeof(uint32_t) * kCounterRing * kShards));
   TRY_OR_FREE(dev_alloc(s, (void **)&s->p_stats, sizeof(unsigned long long) * kStatWords));
   {

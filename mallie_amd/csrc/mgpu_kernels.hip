@@ -402,6 +402,52 @@ __global__ __launch_bounds__(kBlock, MGPU_RENDER_MIN_WAVES) void k_render(DScene
 // =====================================================================================================================
 // launchers
 // =====================================================================================================================
+// =====================================================================================================================
+// k_scene_layout: what mgpu_scene_create leaves in HBM for the traversal, one thread per BVH leaf slot.
+//   tris[slot]   = p0, e1 = p1 - p0, e2 = p2 - p0 of face indices[slot] (the operands TriangleIsect forms, bvh_accel.cc:
+//                  606-607), its face id and material id (kNoMaterial without a material array)
+//   slot_normal  = the face's 9 face-varying normal components, or the geometric normal of BuildIntersection
+//                  (bvh_accel.cc:723-729): normalize(cross(p1-p0, p2-p0)) with real3::normalize's 1e-6 guard
+// fp64 subtraction, multiplication, sqrt and division are correctly rounded on the device (profiles/microbench), so the
+// values equal what the host used to compute here.
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void k_scene_layout(const double *__restrict__ verts, const uint32_t *__restrict__ faces,
+                                                       const uint32_t *__restrict__ indices,
+                                                       const uint32_t *__restrict__ matIDs,
+                                                       const double *__restrict__ fv_normals, size_t nf,
+                                                       DTri *__restrict__ tris, double *__restrict__ slot_normal) {
+  const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (slot >= nf) return;
+  const uint32_t face = indices[slot];
+  const double *p0 = verts + 3 * (size_t)faces[3 * (size_t)face + 0];
+  const double *p1 = verts + 3 * (size_t)faces[3 * (size_t)face + 1];
+  const double *p2 = verts + 3 * (size_t)faces[3 * (size_t)face + 2];
+  DTri t;
+  for (int k = 0; k < 3; ++k) {
+    t.p0[k] = p0[k];
+    t.e1[k] = p1[k] - p0[k];
+    t.e2[k] = p2[k] - p0[k];
+  }
+  t.face = face;
+  t.mat = matIDs ? matIDs[face] : kNoMaterial;
+  tris[slot] = t;
+  if (fv_normals) {
+    for (int k = 0; k < 9; ++k) slot_normal[9 * slot + k] = fv_normals[9 * (size_t)face + k];
+  } else {
+    const V3 n = normalized(cross(v3(t.e1[0], t.e1[1], t.e1[2]), v3(t.e2[0], t.e2[1], t.e2[2])));
+    slot_normal[3 * slot + 0] = n.x;
+    slot_normal[3 * slot + 1] = n.y;
+    slot_normal[3 * slot + 2] = n.z;
+  }
+}
+
+void launch_scene_layout(hipStream_t s, const double *verts, const uint32_t *faces, const uint32_t *indices,
+                         const uint32_t *matIDs, const double *fv_normals, size_t nf, DTri *tris, double *slot_normal) {
+  const unsigned blocks = (unsigned)((nf + 255) / 256);
+  hipLaunchKernelGGL(k_scene_layout, dim3(blocks), dim3(256), 0, s, verts, faces, indices, matIDs, fv_normals, nf, tris,
+                     slot_normal);
+}
+
 int pick_stack_cap(int needed_entries) {
   if (needed_entries <= 16) return 16;
   if (needed_entries <= 24) return 24;

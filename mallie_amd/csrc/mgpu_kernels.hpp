@@ -82,6 +82,9 @@ void launch_accumulate(hipStream_t s, const float *planes, size_t plane_stride, 
                        int32_t *count, bool resume);
 // tile_order[0..n) = tile indices by descending cost (256 log buckets); zeroes cost[]. One workgroup.
 void launch_order_tiles(hipStream_t s, uint32_t *cost, uint32_t n_tiles, uint32_t *order);
+// slot-ordered DTri records + per-slot shading normals (9 doubles with face-varying normals, else the geometric normal)
+void launch_scene_layout(hipStream_t s, const double *verts, const uint32_t *faces, const uint32_t *indices,
+                         const uint32_t *matIDs, const double *fv_normals, size_t nf, DTri *tris, double *slot_normal);
 void launch_tonemap(hipStream_t s, const float *image, const int32_t *count, size_t npix, int mode, unsigned char *out);
 constexpr size_t kLdsBudget = 160 * 1024 - 512; // bytes of LDS per CU on gfx950, less the kernels' static cursor words
 
