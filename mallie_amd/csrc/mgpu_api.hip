@@ -250,9 +250,9 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
   // per-slot shading normals are laid out on the device from the arrays just uploaded (k_scene_layout)
   {
     void *d_idx = nullptr, *d_mat = nullptr;
-    TRY_OR_FREE(upload(s, &d_idx, indices, sizeof(uint32_t) * nf));
-    if (matIDs) TRY_OR_FREE(upload(s, &d_mat, matIDs, sizeof(uint32_t) * nf));
-    int lrc = dev_alloc(s, &s->p_tris, sizeof(DTri) * nf);
+    int lrc = upload(s, &d_idx, indices, sizeof(uint32_t) * nf);
+    if (!lrc && matIDs) lrc = upload(s, &d_mat, matIDs, sizeof(uint32_t) * nf);
+    if (!lrc) lrc = dev_alloc(s, &s->p_tris, sizeof(DTri) * nf);
     if (!lrc) lrc = dev_alloc(s, &s->p_slotn, sizeof(double) * (fv_normals ? 9 : 3) * nf);
     hipError_t e = hipSuccess;
     if (!lrc) {
