@@ -182,8 +182,8 @@ public:
   Scene();
   ~Scene();
 
-  // Loads a mesh file, scales it and builds the BVH (scene.cc:66-251). Wavefront .obj and .eson are read by this
-  // library's own readers; .vox is not supported (returns false).
+  // Loads a mesh file, scales it and builds the BVH (scene.cc:66-251). Wavefront .obj, .eson and MagicaVoxel .vox (which
+  // also fills the 256 palette materials) are read by this library's own readers.
   bool Init(const std::string &objFilename, const std::string &esonFilename, const std::string &magicaVoxelFilename,
             const std::string &materialFilename, double sceneScale = 1.0, bool sceneFit = false);
   // Extension: adopt caller-built arrays (copied) instead of reading a file; applies scale/fit like Init.

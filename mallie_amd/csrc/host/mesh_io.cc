@@ -404,4 +404,116 @@ bool LoadESON(Mesh &mesh, const char *filename) {
   return true;
 }
 
+// ---- MagicaVoxel .vox (MeshLoader::LoadMagicaVoxel, mesh_loader.cc:312-400; MagicaVoxelLoader::Load,
+// importers/magicavoxel_loader.cc:60-157) ---------------------------------------------------------------------------
+// The format's default palette (used when the file carries no RGBA chunk), generated instead of tabulated: index 0 is
+// transparent black; 1..215 walk a 6x6x6 colour cube with levels ff, cc, 99, 66, 33, 00 -- bits 16-23 fastest, then
+// bits 8-15, then bits 0-7 -- stopping before its all-zero corner; then four ramps of ten (bits 0-7, 8-15, 16-23, grey)
+// with levels ee dd bb aa 88 77 55 44 22 11.  Alpha (bits 24-31) is ff.  Checked entry by entry against the reference's
+// reader through tests/golden/objload_vox_default.npz.
+static void default_vox_palette(unsigned int pal[256]) {
+  static const unsigned int ramp[10] = {0xee, 0xdd, 0xbb, 0xaa, 0x88, 0x77, 0x55, 0x44, 0x22, 0x11};
+  pal[0] = 0x00000000u;
+  for (unsigned int k = 0; k < 215; k++) {
+    const unsigned int c0 = 0xffu - 0x33u * (k % 6), c1 = 0xffu - 0x33u * ((k / 6) % 6), c2 = 0xffu - 0x33u * (k / 36);
+    pal[1 + k] = 0xff000000u | (c0 << 16) | (c1 << 8) | c2;
+  }
+  for (unsigned int i = 0; i < 10; i++) {
+    pal[216 + i] = 0xff000000u | ramp[i];
+    pal[226 + i] = 0xff000000u | (ramp[i] << 8);
+    pal[236 + i] = 0xff000000u | (ramp[i] << 16);
+    pal[246 + i] = 0xff000000u | (ramp[i] << 16) | (ramp[i] << 8) | ramp[i];
+  }
+}
+
+bool LoadMagicaVoxel(Mesh &mesh, std::vector<Material> &materials, const char *filename) {
+  FILE *fp = fopen(filename, "rb");
+  if (!fp) {
+    fprintf(stderr, "Failed to load file.\n");
+    fprintf(stderr, "Failed to load .vox file.\n");
+    return false;
+  }
+  unsigned char magic[4] = {0, 0, 0, 0};
+  if (fread(magic, 1, 4, fp) != 4 || memcmp(magic, "VOX ", 4) != 0) {
+    fprintf(stderr, "Bad magic number.\n");
+    fprintf(stderr, "Failed to load .vox file.\n");
+    fclose(fp);
+    return false;
+  }
+  int ver = 0;
+  if (fread(&ver, sizeof(int), 1, fp) != 1) ver = 0;
+  int size[3] = {0, 0, 0};
+  std::vector<unsigned char> voxel; // x, y, z, colour index per voxel
+  std::vector<unsigned int> palette;
+  for (;;) { // chunks: id[4], int chunkSize, int childChunkSize, content; a parent's children follow it in the stream
+    unsigned char id[4];
+    int chunkSize = 0, childChunkSize = 0;
+    if (fread(id, 1, 4, fp) != 4) break;
+    if (fread(&chunkSize, sizeof(int), 1, fp) != 1 || fread(&childChunkSize, sizeof(int), 1, fp) != 1) break;
+    if (!memcmp(id, "SIZE", 4)) {
+      if (fread(size, sizeof(int), 3, fp) != 3) break;
+      fseek(fp, chunkSize - 4 * 3, SEEK_CUR);
+    } else if (!memcmp(id, "XYZI", 4)) {
+      int numVoxels = 0;
+      if (fread(&numVoxels, sizeof(int), 1, fp) != 1 || numVoxels < 0) break;
+      voxel.resize((size_t)numVoxels * 4);
+      if (numVoxels && fread(&voxel[0], 1, voxel.size(), fp) != voxel.size()) break;
+    } else if (!memcmp(id, "RGBA", 4)) {
+      palette.resize(256);
+      if (fread(&palette[0], sizeof(unsigned int), 256, fp) != 256) break;
+    } else {
+      fseek(fp, chunkSize, SEEK_CUR); // MAIN and anything unknown: skip the content, read on into the children
+    }
+  }
+  fclose(fp);
+
+  // materials: 256 palette entries, diffuse = byte / 255.0f (float division, then widened)
+  unsigned int pal[256];
+  if (palette.empty()) default_vox_palette(pal);
+  else memcpy(pal, &palette[0], sizeof(pal));
+  materials.clear();
+  for (int i = 0; i < 256; i++) {
+    Material m;
+    m.diffuse[2] = (float)((pal[i] >> 0) & 0xff) / 255.0f;
+    m.diffuse[1] = (float)((pal[i] >> 8) & 0xff) / 255.0f;
+    m.diffuse[0] = (float)((pal[i] >> 16) & 0xff) / 255.0f;
+    materials.push_back(m);
+  }
+
+  // one cube (8 vertices, 12 triangles) per voxel, centred on the grid, MagicaVoxel's Z-up turned into Y-up
+  static const float P[8][3] = {{-1, -1, 1}, {-1, 1, 1}, {1, 1, 1}, {1, -1, 1}, {-1, -1, -1}, {-1, 1, -1}, {1, 1, -1}, {1, -1, -1}};
+  static const int F[6][4] = {{0, 3, 2, 1}, {2, 3, 7, 6}, {0, 4, 7, 3}, {1, 2, 6, 5}, {4, 5, 6, 7}, {0, 1, 5, 4}};
+  const size_t numVoxels = voxel.size() / 4;
+  memset(&mesh, 0, sizeof(mesh));
+  mesh.numFaces = numVoxels * 12;
+  mesh.numVertices = numVoxels * 8;
+  mesh.vertices = new real[mesh.numVertices * 3 + 1];
+  mesh.faces = new unsigned int[mesh.numFaces * 3 + 1];
+  mesh.materialIDs = new unsigned int[mesh.numFaces + 1];
+  const float posOffset[3] = {-0.5f * (float)size[0], -0.5f * (float)size[1], -0.5f * (float)size[2]};
+  size_t voffset = 0, foffset = 0;
+  for (size_t i = 0; i < numVoxels; i++) {
+    const int x = voxel[4 * i + 0], y = voxel[4 * i + 1], z = voxel[4 * i + 2];
+    const int col = (int)voxel[4 * i + 3] - 1; // palette index 0 is "no voxel": it becomes material id -1
+    for (int j = 0; j < 8; j++) { // float arithmetic, stored as double
+      mesh.vertices[3 * (voffset + j) + 0] = posOffset[0] + (float)x + 0.5f * P[j][0];
+      mesh.vertices[3 * (voffset + j) + 2] = posOffset[1] + -((float)y + 0.5f * P[j][1]);
+      mesh.vertices[3 * (voffset + j) + 1] = posOffset[2] + (float)z + 0.5f * P[j][2];
+    }
+    for (int f = 0; f < 6; f++) { // each quad as the triangles (0,1,2) and (0,2,3)
+      mesh.faces[foffset + 6 * f + 0] = (unsigned int)(voffset + F[f][0]);
+      mesh.faces[foffset + 6 * f + 1] = (unsigned int)(voffset + F[f][1]);
+      mesh.faces[foffset + 6 * f + 2] = (unsigned int)(voffset + F[f][2]);
+      mesh.faces[foffset + 6 * f + 3] = (unsigned int)(voffset + F[f][0]);
+      mesh.faces[foffset + 6 * f + 4] = (unsigned int)(voffset + F[f][2]);
+      mesh.faces[foffset + 6 * f + 5] = (unsigned int)(voffset + F[f][3]);
+      mesh.materialIDs[foffset / 3 + 2 * f + 0] = (unsigned int)col;
+      mesh.materialIDs[foffset / 3 + 2 * f + 1] = (unsigned int)col;
+    }
+    voffset += 8;
+    foffset += 3 * 12;
+  }
+  return true; // as the reference: an empty grid loads and then fails in the BVH build
+}
+
 } // namespace mesh_io

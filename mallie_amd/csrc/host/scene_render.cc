@@ -46,7 +46,8 @@ bool Scene::Init(const std::string &objFilename, const std::string &esonFilename
     printf(ok ? "Mallie:info\tmsg:Success to load .eson file [ %s ]\n" : "Mallie:err\tmsg:Failed to load .eson file [ %s ]\n",
            esonFilename.c_str());
   } else if (!magicaVoxelFilename.empty()) {
-    printf("Mallie:err\tmsg:Failed to load .vox file [ %s ] (MagicaVoxel input is not supported by the MI355X path)\n",
+    ok = mesh_io::LoadMagicaVoxel(mesh_, materials_, magicaVoxelFilename.c_str());
+    printf(ok ? "Mallie:info\tmsg:Success to load .vox file [ %s ]\n" : "Mallie:err\tmsg:Failed to load .vox file [ %s ]\n",
            magicaVoxelFilename.c_str());
   }
   if (!ok) {

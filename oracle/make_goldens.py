@@ -82,6 +82,8 @@ def gen_mesh(tmp, kind, fname, name, cwd=None):
     # vertex coordinates came through float32 (tinyobj / ESON store float): keep them compact when lossless
     if np.array_equal(m["verts"], m["verts"].astype(np.float32).astype(np.float64)):
         m["verts"] = m["verts"].astype(np.float32)
+    if kind == "vox":  # Scene::GetMaterial(0..255).diffuse as the reference's reader filled materials_
+        m["materials"] = np.fromfile(prefix + ".mat", "<f8").reshape(256, 3)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **m)
     print(name, "verts", m["verts"].shape, "faces", m["faces"].shape, "nodes", m["nodes"].shape,
           "normals", m["normals"].shape)
@@ -214,6 +216,12 @@ def main():
     if not os.path.exists(DRIVER):
         raise SystemExit("build the reference driver first: make -C oracle ref")
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["vox"]:  # only the MagicaVoxel reader goldens (authored inputs: tests/golden/objs/make_vox.py)
+        with tempfile.TemporaryDirectory() as tmp:
+            objs = os.path.join(OUT, "objs")
+            gen_mesh(tmp, "vox", "tiny.vox", "objload_vox_default", cwd=objs)
+            gen_mesh(tmp, "vox", "tiny_rgba.vox", "objload_vox_rgba", cwd=objs)
+        return
     if sys.argv[1:] == ["pano"]:  # only the RenderPanoramic goldens (keeps the other fixtures' bytes untouched)
         with tempfile.TemporaryDirectory() as tmp:
             gen_pano_all(tmp)
@@ -228,6 +236,8 @@ def main():
         objs = os.path.join(OUT, "objs")
         gen_mesh(tmp, "obj", "quirks.obj", "objload_quirks", cwd=objs)
         gen_mesh(tmp, "obj", "nomtl.obj", "objload_nomtl", cwd=objs)
+        gen_mesh(tmp, "vox", "tiny.vox", "objload_vox_default", cwd=objs)
+        gen_mesh(tmp, "vox", "tiny_rgba.vox", "objload_vox_rgba", cwd=objs)
         rng = np.random.default_rng(20260929)
         gen_trace(tmp, "obj", "cornellbox_suzanne.obj", "trace_cornell_obj",
                   make_rays(rng, mc, 1500, 1500, 700, 300, np.array([0.0, 0.0, 20.0])))

@@ -54,7 +54,8 @@ bool init_scene(SceneProbe &scene, const char *kind, const char *file, double sc
   std::string obj, eson, vox, mat;
   if (!strcmp(kind, "obj")) obj = file;
   else if (!strcmp(kind, "eson")) eson = file;
-  else die("kind must be obj|eson");
+  else if (!strcmp(kind, "vox")) vox = file;
+  else die("kind must be obj|eson|vox");
   return scene.Init(obj, eson, vox, mat, scale, false);
 }
 
@@ -88,6 +89,15 @@ int cmd_mesh(int argc, char **argv) {
     wr(fp, &nn, 8); wr(fp, &nodes[0], sizeof(BVHNode) * nn);
     wr(fp, &ni, 8); wr(fp, &idx[0], sizeof(unsigned) * ni);
     fclose(fp);
+    { // Scene::GetMaterial(0..255) (scene.h:58-65): the 256 palette materials of a .vox scene, the default otherwise
+      FILE *fm = xopen(out + ".mat", "wb");
+      for (int i = 0; i < 256; i++) {
+        const Material &mt = scene.GetMaterial(i);
+        double d[3] = {mt.diffuse[0], mt.diffuse[1], mt.diffuse[2]};
+        wr(fm, d, 24);
+      }
+      fclose(fm);
+    }
     BVHBuildStatistics st = scene.accel().GetStatistics();
     fprintf(stderr, "\nBVH nodes=%llu leaves=%d branches=%d depth=%d sizeof(BVHNode)=%zu\n",
             (unsigned long long)nn, st.numLeafNodes, st.numBranchNodes, st.maxTreeDepth, sizeof(BVHNode));

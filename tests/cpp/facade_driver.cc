@@ -3,9 +3,9 @@
 // libmallie_mgpu.so, the way main_console.cc (main_console.cc:57-79) uses the reference's own objects.
 // It doubles as the harness of tests/test_facade.py.
 //
-//   facade_driver mesh   <obj|eson> <file> <scale> <out_prefix>          (CPU only: loader + BVH build)
-//   facade_driver render <obj|eson> <file> <W> <H> <plane> <passes> <maxPathLength> <seed> <out.f32>   (GPU)
-//   facade_driver trace  <obj|eson> <file> <rays.bin> <out.bin>                                          (GPU)
+//   facade_driver mesh   <obj|eson|vox> <file> <scale> <out_prefix>          (CPU only: loader + BVH build)
+//   facade_driver render <obj|eson|vox> <file> <W> <H> <plane> <passes> <maxPathLength> <seed> <out.f32>   (GPU)
+//   facade_driver trace  <obj|eson|vox> <file> <rays.bin> <out.bin>                                          (GPU)
 #include <string>
 #include <vector>
 #include <cstdio>
@@ -20,7 +20,7 @@
 
 static bool init(mallie::Scene &scene, const char *kind, const char *file, double scale) {
   std::string obj, eson, vox, mat;
-  if (!strcmp(kind, "obj")) obj = file; else eson = file;
+  if (!strcmp(kind, "obj")) obj = file; else if (!strcmp(kind, "vox")) vox = file; else eson = file;
   return scene.Init(obj, eson, vox, mat, scale, false);
 }
 
@@ -41,6 +41,15 @@ int main(int argc, char **argv) {
     if (hn) wr(fp, m.facevarying_normals, 72 * nf);
     if (hu) wr(fp, m.facevarying_uvs, 48 * nf);
     fclose(fp);
+    { // Scene::GetMaterial(0..255): the palette materials of a .vox scene, the default material otherwise
+      FILE *fm = fopen((out + ".mat").c_str(), "wb");
+      for (int i = 0; i < 256; i++) {
+        const Material &mt = scene.GetMaterial(i);
+        double d[3] = {mt.diffuse[0], mt.diffuse[1], mt.diffuse[2]};
+        wr(fm, d, 24);
+      }
+      fclose(fm);
+    }
     // BVHAccel::Dump writes the reference's binary layout (bvh_accel.cc:484-512)
     if (!scene.GetAccel().Dump((out + ".bvh").c_str())) return 4;
     // and Load must read it back

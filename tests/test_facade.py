@@ -64,6 +64,23 @@ def test_obj_reader_reproduces_reference_loader(driver, tmp_path, obj, golden):
     check_against_golden(read_mesh(prefix), golden)
 
 
+@pytest.mark.parametrize("vox,golden", [("tiny.vox", "objload_vox_default"), ("tiny_rgba.vox", "objload_vox_rgba")])
+def test_vox_reader_reproduces_reference_loader(driver, tmp_path, vox, golden):
+    """MagicaVoxel input (MeshLoader::LoadMagicaVoxel): cube mesh, material ids (colour index 0 -> -1), BVH and all 256
+    palette materials -- the generated default palette included -- equal what the reference makes of the same file."""
+    objs = os.path.join(ROOT, "tests", "golden", "objs")
+    prefix = str(tmp_path / "m")
+    r = subprocess.run([driver, "mesh", "vox", vox, "1.0", prefix], cwd=objs, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Mallie:info\tmsg:Success to load .vox file" in r.stdout
+    check_against_golden(read_mesh(prefix), golden)
+    g = O.load_golden(golden)
+    mats = np.fromfile(prefix + ".mat", "<f8").reshape(256, 3)
+    assert mats.tobytes() == g["materials"].tobytes()
+    if "default" in golden:
+        assert 0xFFFFFFFF in g["matIDs"] and tuple(g["materials"][0]) == (0.0, 0.0, 0.0)  # palette entry 0, voxel index 0
+
+
 @pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference's scene files (build container only)")
 @pytest.mark.parametrize("kind,fname,golden", [("obj", "cornellbox_suzanne.obj", "cornell_obj"),
                                               ("eson", "cornellbox_suzanne.eson", "cornell_eson"),
@@ -128,6 +145,26 @@ def test_facade_render_and_trace_on_gpu(driver, tmp_path):
     h = ref["hit"] == 1
     for f in ("faceID", "t", "u", "v", "normal"):
         assert rec[f][h].tobytes() == ref[f][h].tobytes(), f
+
+
+@pytest.mark.gpu
+def test_facade_renders_a_vox_scene_with_its_palette(driver, tmp_path):
+    """Scene::Init(.vox) -> mallie::Render on the GPU: the palette materials colour the paths (R, G, B differ) and the
+    image equals the oracle's for the same arrays, materials and seeding."""
+    vox = os.path.join(ROOT, "tests", "golden", "objs", "tiny_rgba.vox")
+    W, H, passes, mpl, seed = 80, 64, 2, 6, 3
+    out = str(tmp_path / "img.f32")
+    r = subprocess.run([driver, "render", "vox", vox, str(W), str(H), "1", str(passes), str(mpl), str(seed), out],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    img = np.fromfile(out, "<f4")[: 3 * W * H].reshape(H, W, 3)
+    g = O.load_golden("objload_vox_rgba")
+    osc = O.OracleScene(g["verts"].astype(np.float64), g["faces"], g["matIDs"], None, None, g["nodes"], g["indices"],
+                        mat_diffuse=g["materials"])
+    frame = O.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    oimg, _, _, _ = osc.render(frame, W, H, mpl, passes, osc.plane(), O.RNG_HASH, seed=seed)
+    assert img.tobytes() == oimg.tobytes(), "%d pixels differ" % int((img != oimg).any(-1).sum())
+    assert not np.array_equal(img[..., 0], img[..., 2])
 
 
 @pytest.mark.gpu
