@@ -48,6 +48,19 @@ def hbm_traffic(kernel_prefix):
     return None
 
 
+def valu_counters(kernel_prefix):
+    """SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU per launch of the dominant kernel from the same committed PMC passes."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            d = json.load(f)
+        for k, v in d.get("sq_per_launch", {}).items():
+            if kernel_prefix in k:
+                return v
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def load_scene_arrays():
     g = np.load(os.path.join(ROOT, "tests", "golden", "cornell_obj.npz"))
     return g["verts"].astype(np.float64), g["faces"], g["matIDs"], g["normals"]
@@ -184,6 +197,14 @@ def main():
                                  "(SQ_ACTIVE_INST_VALU 89%% of SIMD cycles, profiles/). HBM-resident scenes: DESIGN.md 7."
                                  % (round(traffic / (kernel_avg_ms * 1e-3) / 1e9, 1) if traffic else "n/a")},
         }
+        sqc = valu_counters("k_render_sm") if world == 1 else None
+        if sqc and kernel_avg_ms > 0:
+            # what actually bounds the kernel: VALU issue.  SQ_ACTIVE_INST_VALU counts 4-cycle issue slots; 256 CUs x 4 SIMDs
+            # at the 2.4 GHz peak clock (measured under this load: 2.35-2.39 GHz, profiles/microbench/RESULTS.md)
+            out["roofline"]["valu"] = {
+                "insts_per_launch": sqc.get("SQ_INSTS_VALU"), "insts_per_ray": round(sqc.get("SQ_INSTS_VALU", 0) * 64.0 / max(st["real_rays"] / max(launches, 1), 1), 1),
+                "issue_busy_frac": round(sqc.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / (kernel_avg_ms * 1e-3 * 2.4e9 * 1024), 3),
+                "note": "from the committed rocprofv3 PMC pass (profiles/); wave-instructions x 64 lanes per real ray"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frame, plane, mpl)
         print(json.dumps(out), flush=True)

@@ -55,7 +55,8 @@ for k in sorted(sq):
         for c, v in sorted(sq[k].items()):
             lines.append("    %-24s %.4g" % (c, v))
 open(os.path.join(here, "%s_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
-json.dump({"tag": tag, "bytes_per_launch": traffic,
+sq_out = {k.split("(")[0].replace("void ", ""): {c: v for c, v in d.items()} for k, d in sq.items() if k.startswith(("void mgpu", "mgpu"))}
+json.dump({"tag": tag, "bytes_per_launch": traffic, "sq_per_launch": sq_out,
            "method": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024, separate rocprofv3 --pmc passes (see %s_summary.txt)" % tag},
           open(os.path.join(here, "hbm_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
