@@ -737,13 +737,23 @@ int mgpu_render_panoramic_device(MgpuScene *s, const double origin[3], int W, in
   if (ww == 0 || wh == 0) return MGPU_OK;
   hipStream_t st = (hipStream_t)stream;
   const uint64_t tiles = (uint64_t)((ww + 7) / 8) * (uint64_t)((wh + 7) / 8);
-  uint64_t blocks = (uint64_t)s->num_cu * 4; // 16 waves per CU
-  const uint64_t max_useful = (tiles * 64 + kBlock - 1) / kBlock;
+  // scene placement as for mgpu_render: BVH in LDS (one 1024-thread workgroup per CU) when it fits beside the stacks
+  const size_t scene_lds = sizeof(MgpuNode) * s->nn + sizeof(DTri) * s->nf;
+  bool lds_scene = s->cap <= 24 && s->stack_need <= s->cap &&
+                   (size_t)16 * s->cap * 64 * sizeof(uint32_t) + scene_lds <= kLdsBudget;
+  if (const char *e = getenv("MGPU_RENDER_KERNEL")) {
+    if (!strcmp(e, "sm")) lds_scene = false;
+  }
+  const int block = lds_scene ? 1024 : kBlock;
+  uint64_t blocks = (uint64_t)s->num_cu * (lds_scene ? 1 : 4); // 16 waves per CU
+  const uint64_t max_useful = (tiles * 64 + block - 1) / block;
   if (blocks > max_useful) blocks = max_useful;
   if (blocks < 1) blocks = 1;
-  rc = ensure_overflow(s, blocks * kBlock);
+  rc = ensure_overflow(s, blocks * block);
   if (rc) return rc;
   EnvParams P;
+  P.lds_nodes_bytes = (uint32_t)(sizeof(MgpuNode) * s->nn);
+  P.lds_tris_bytes = (uint32_t)(sizeof(DTri) * s->nf);
   memcpy(P.origin, origin, sizeof(P.origin));
   {
     // psi = atan2(r, focal_length) with r = 0.5, focal_length = 4.0 (camera.cc:261-262,311): the host's libm, as the reference
@@ -766,7 +776,7 @@ int mgpu_render_panoramic_device(MgpuScene *s, const double origin[3], int W, in
     HIP_TRY(hipMemsetAsync(s->p_stats, 0, sizeof(unsigned long long) * kStatWords, st));
     HIP_TRY(hipEventRecord(s->ev0, st));
   }
-  HIP_TRY(launch_render_env(s->cap, dim3((unsigned)blocks), st, s->d, P));
+  HIP_TRY(launch_render_env(s->cap, lds_scene, dim3((unsigned)blocks), st, s->d, P));
   if (stats) {
     HIP_TRY(hipEventRecord(s->ev1, st));
     unsigned long long w[kStatWords];

@@ -73,8 +73,9 @@ struct EnvParams {
   int32_t *count; // device, win_w * win_h, += samples; may be null
   uint32_t *work_counter; // one zeroed word
   unsigned long long *stats;
+  uint32_t lds_nodes_bytes, lds_tris_bytes; // LDS_SCENE variant: bytes of nodes / triangles staged into LDS
 };
-hipError_t launch_render_env(int cap, dim3 grid, hipStream_t s, const DScene &sc, const EnvParams &p);
+hipError_t launch_render_env(int cap, bool lds_scene, dim3 grid, hipStream_t s, const DScene &sc, const EnvParams &p);
 // k_trace_sm (mgpu_trace_sm.hip): persistent, wave-scheduled batched trace; `counter` = one zeroed device word
 hipError_t launch_trace_sm(int cap, dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, uint32_t n,
                            MgpuIntersection *out, uint8_t *hit, uint32_t *counter, unsigned long long *stats);

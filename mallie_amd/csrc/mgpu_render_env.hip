@@ -3,7 +3,8 @@
 // reference's console driver renders (main_console.cc:111).
 //
 // Same wave-scheduled traversal as k_render_sm / k_trace_sm (lane states NODE / TRI / SHADE, one body per trip of the
-// wave loop).  What differs from PathTrace:
+// wave loop), with the same two scene placements: BVH staged in LDS (1024-thread workgroup per CU) when it fits, else
+// read through L1/L2 (256-thread workgroups).  What differs from PathTrace:
 //   * no ground plane, no material, no throughput: a path's radiance is 0 or sum_{L = L0..maxPathLength} 0.5 / L, L0 >= 2
 //     being the length at which it first missed (the reference keeps iterating after that miss with a stale record,
 //     SURVEY F4; those rays start ~1e308 away and are evaluated in closed loop here, same additions in the same order);
@@ -26,8 +27,8 @@ constexpr int kEnvBlock = 256;
 #define MGPU_ENV_SHADE_MIN 32
 #endif
 
-template <int CAP, bool OVF>
-__global__ __launch_bounds__(kEnvBlock, 4) void k_render_env(DScene sc, EnvParams P_arg) {
+template <int CAP, bool OVF, bool LDS_SCENE, int BLOCK>
+__global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_arg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ EnvParams s_P; // launch parameters live in LDS, not in scalar registers (see k_render_sm)
   __shared__ unsigned long long s_cnt[5];
@@ -37,10 +38,22 @@ __global__ __launch_bounds__(kEnvBlock, 4) void k_render_env(DScene sc, EnvParam
   const EnvParams &P = s_P;
   uint32_t *s_stack = reinterpret_cast<uint32_t *>(smem); // [waves][CAP][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t slot = (size_t)blockIdx.x * kEnvBlock + threadIdx.x;
+  const size_t slot = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   Stack<CAP, OVF> stk;
   stk.lds = s_stack + ((size_t)wave * CAP) * 64 + lane;
   stk.overflow = (OVF && sc.stack_overflow) ? sc.stack_overflow + slot * sc.overflow_cap : nullptr;
+  // LDS_SCENE: nodes + triangles staged once per workgroup next to the stacks (as k_render_sm does)
+  const unsigned char *lds_nodes = smem + (size_t)(BLOCK / 64) * CAP * 64 * sizeof(uint32_t);
+  const unsigned char *lds_tris = lds_nodes + (size_t)P.lds_nodes_bytes;
+  if (LDS_SCENE) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(sc.nodes);
+    uint4 *dst = reinterpret_cast<uint4 *>(const_cast<unsigned char *>(lds_nodes));
+    for (uint32_t i = threadIdx.x; i < (P.lds_nodes_bytes >> 4); i += BLOCK) dst[i] = src[i];
+    const uint4 *src2 = reinterpret_cast<const uint4 *>(sc.tris);
+    uint4 *dst2 = reinterpret_cast<uint4 *>(const_cast<unsigned char *>(lds_tris));
+    for (uint32_t i = threadIdx.x; i < (P.lds_tris_bytes >> 4); i += BLOCK) dst2[i] = src2[i];
+    __syncthreads();
+  }
 
   const uint32_t tiles_x = (uint32_t)(P.win_w + 7) >> 3, tiles_y = (uint32_t)(P.win_h + 7) >> 3;
   const uint32_t total_tiles = tiles_x * tiles_y;
@@ -82,11 +95,21 @@ __global__ __launch_bounds__(kEnvBlock, 4) void k_render_env(DScene sc, EnvParam
           const uint32_t ni = stk.get(sp);
           --sp;
           ++n_nodes;
-          const MgpuNode *nd = sc.nodes + ni;
-          const double2 b0 = *reinterpret_cast<const double2 *>(&nd->bmin[0]);
-          const double2 b1 = *reinterpret_cast<const double2 *>(&nd->bmin[2]);
-          const double2 b2 = *reinterpret_cast<const double2 *>(&nd->bmax[1]);
-          const int4 meta = *reinterpret_cast<const int4 *>(&nd->flag);
+          double2 b0, b1, b2;
+          int4 meta;
+          if (LDS_SCENE) {
+            const unsigned char *nd = lds_nodes + (size_t)ni * 64;
+            b0 = *reinterpret_cast<const double2 *>(nd);
+            b1 = *reinterpret_cast<const double2 *>(nd + 16);
+            b2 = *reinterpret_cast<const double2 *>(nd + 32);
+            meta = *reinterpret_cast<const int4 *>(nd + 48);
+          } else {
+            const MgpuNode *nd = sc.nodes + ni;
+            b0 = *reinterpret_cast<const double2 *>(&nd->bmin[0]);
+            b1 = *reinterpret_cast<const double2 *>(&nd->bmin[2]);
+            b2 = *reinterpret_cast<const double2 *>(&nd->bmax[1]);
+            meta = *reinterpret_cast<const int4 *>(&nd->flag);
+          }
           // IntersectRayAABB, bvh_accel.cc:550-593
           const double nx = sx ? b1.y : b0.x, fx = sx ? b0.x : b1.y;
           const double ny = sy ? b2.x : b0.y, fy = sy ? b0.y : b2.x;
@@ -121,12 +144,23 @@ __global__ __launch_bounds__(kEnvBlock, 4) void k_render_env(DScene sc, EnvParam
       if (st == ES_TRI) {
 #pragma unroll 1
         for (int rep = 0; rep < 16; ++rep) {
-          const DTri *tp = sc.tris + tri_cur;
-          const double2 a0 = reinterpret_cast<const double2 *>(tp)[0];
-          const double2 a1 = reinterpret_cast<const double2 *>(tp)[1];
-          const double2 a2 = reinterpret_cast<const double2 *>(tp)[2];
-          const double2 a3 = reinterpret_cast<const double2 *>(tp)[3];
-          const double e2z = tp->e2[2];
+          double2 a0, a1, a2, a3;
+          double e2z;
+          if (LDS_SCENE) {
+            const unsigned char *tp = lds_tris + (size_t)tri_cur * 80;
+            a0 = *reinterpret_cast<const double2 *>(tp);
+            a1 = *reinterpret_cast<const double2 *>(tp + 16);
+            a2 = *reinterpret_cast<const double2 *>(tp + 32);
+            a3 = *reinterpret_cast<const double2 *>(tp + 48);
+            e2z = *reinterpret_cast<const double *>(tp + 64);
+          } else {
+            const DTri *tp = sc.tris + tri_cur;
+            a0 = reinterpret_cast<const double2 *>(tp)[0];
+            a1 = reinterpret_cast<const double2 *>(tp)[1];
+            a2 = reinterpret_cast<const double2 *>(tp)[2];
+            a3 = reinterpret_cast<const double2 *>(tp)[3];
+            e2z = tp->e2[2];
+          }
           ++n_tris;
           // TriangleIsect, bvh_accel.cc:595-638
           const V3 p0 = v3(a0.x, a0.y, a1.x), e1 = v3(a1.y, a2.x, a2.y), e2 = v3(a3.x, a3.y, e2z);
@@ -332,19 +366,34 @@ __global__ __launch_bounds__(kEnvBlock, 4) void k_render_env(DScene sc, EnvParam
   }
 }
 
-template <int CAP, bool OVF>
+template <int CAP, bool OVF, bool LDS_SCENE, int BLOCK>
 static hipError_t launch_one(dim3 grid, hipStream_t s, const DScene &sc, const EnvParams &p) {
-  const size_t shmem = (size_t)(kEnvBlock / 64) * CAP * 64 * sizeof(uint32_t);
-  hipLaunchKernelGGL((k_render_env<CAP, OVF>), grid, dim3(kEnvBlock), shmem, s, sc, p);
+  size_t shmem = (size_t)(BLOCK / 64) * CAP * 64 * sizeof(uint32_t);
+  if (LDS_SCENE) {
+    shmem += (size_t)p.lds_nodes_bytes + (size_t)p.lds_tris_bytes;
+    static bool attr_done = false; // one device per process in practice; the attribute is per function
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render_env<CAP, OVF, LDS_SCENE, BLOCK>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+      if (e != hipSuccess) return e;
+      attr_done = true;
+    }
+  }
+  hipLaunchKernelGGL((k_render_env<CAP, OVF, LDS_SCENE, BLOCK>), grid, dim3(BLOCK), shmem, s, sc, p);
   return hipGetLastError();
 }
 
-hipError_t launch_render_env(int cap, dim3 grid, hipStream_t s, const DScene &sc, const EnvParams &p) {
+hipError_t launch_render_env(int cap, bool lds_scene, dim3 grid, hipStream_t s, const DScene &sc, const EnvParams &p) {
   const bool ovf = sc.overflow_cap != 0;
-  if (cap == 16 && !ovf) return launch_one<16, false>(grid, s, sc, p);
-  if (cap == 24 && !ovf) return launch_one<24, false>(grid, s, sc, p);
-  if (cap == 32 && !ovf) return launch_one<32, false>(grid, s, sc, p);
-  if (cap == 32 && ovf) return launch_one<32, true>(grid, s, sc, p);
+  if (lds_scene && !ovf) {
+    if (cap == 16) return launch_one<16, false, true, 1024>(grid, s, sc, p);
+    if (cap == 24) return launch_one<24, false, true, 1024>(grid, s, sc, p);
+    return hipErrorInvalidConfiguration;
+  }
+  if (cap == 16 && !ovf) return launch_one<16, false, false, kEnvBlock>(grid, s, sc, p);
+  if (cap == 24 && !ovf) return launch_one<24, false, false, kEnvBlock>(grid, s, sc, p);
+  if (cap == 32 && !ovf) return launch_one<32, false, false, kEnvBlock>(grid, s, sc, p);
+  if (cap == 32 && ovf) return launch_one<32, true, false, kEnvBlock>(grid, s, sc, p);
   return hipErrorInvalidConfiguration;
 }
 
