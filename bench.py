@@ -66,7 +66,7 @@ def load_scene_arrays():
     return g["verts"].astype(np.float64), g["faces"], g["matIDs"], g["normals"]
 
 
-def cpu_baseline(frame, plane, mpl):
+def cpu_baseline(frame, plane, mpl, gpu_frame=None):
     """The oracle (this repo's CPU restatement, pinned bit-exact to the reference) timed on the host cores on a bounded
     sample of the same workload: the same 1920x1080 frame, same path length and seeding, `spp_sample` passes."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -80,15 +80,19 @@ def cpu_baseline(frame, plane, mpl):
     # wall time or 4 frames, whichever comes first
     osc.render(frame, W, H, mpl, 1, plane, O.RNG_HASH, seed=WORKLOAD["seed"], window=(0, 512, W, 576), nthreads=cores)
     spp_sample, dt, rays = 0, 0.0, 0
+    same = None
     while dt < 10.0 and spp_sample < 4 * WORKLOAD["spp"]:
         t0 = time.perf_counter()
-        _, _, st, _ = osc.render(frame, W, H, mpl, WORKLOAD["spp"], plane, O.RNG_HASH, seed=WORKLOAD["seed"],
-                                 pass_base=spp_sample, nthreads=cores)
+        img, _, st, _ = osc.render(frame, W, H, mpl, WORKLOAD["spp"], plane, O.RNG_HASH, seed=WORKLOAD["seed"],
+                                   pass_base=spp_sample, nthreads=cores)
         dt += time.perf_counter() - t0
+        if spp_sample == 0 and gpu_frame is not None:
+            # the first sample frame IS the benchmarked frame (same seed, passes 0..15): the checker's image against the GPU's
+            same = bool(img.tobytes() == gpu_frame.tobytes())
         rays += st["real_rays"]
         spp_sample += WORKLOAD["spp"]
     st = dict(real_rays=rays)
-    return dict(value=round(st["real_rays"] / dt / 1e6, 3), unit="Mrays/s", cores=cores, kind="port",
+    return dict(gpu_frame_byte_equal=same, value=round(st["real_rays"] / dt / 1e6, 3), unit="Mrays/s", cores=cores, kind="port",
                 sample="%dx%d frames of the workload, %d passes in total (%d spp each), maxPathLength %d, OpenMP %d "
                               "threads, %.1f s wall, %.0f ms/pass" % (W, H, spp_sample, WORKLOAD["spp"], mpl, cores, dt,
                                                                       1e3 * dt / spp_sample))
@@ -206,7 +210,8 @@ def main():
                 "issue_busy_frac": round(sqc.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / (kernel_avg_ms * 1e-3 * 2.4e9 * 1024), 3),
                 "note": "from the committed rocprofv3 PMC pass (profiles/); wave-instructions x 64 lanes per real ray"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frame, plane, mpl)
+            gpu_frame = fr.frame_buffer.detach().cpu().numpy()  # the last timed frame (pass_base 0), after the timed region
+            out["cpu_baseline"] = cpu_baseline(frame, plane, mpl, gpu_frame)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier(device_ids=[local_rank])
