@@ -488,6 +488,34 @@ def test_panoramic_full_size_properties():
     assert 0.3 < (img[..., 0] > 0).mean() < 1.0  # inside the Cornell box most directions hit something and bounce out
 
 
+def test_cost_ordered_hand_out_is_a_permutation_and_changes_nothing(monkeypatch):
+    """The second launch of a layout hands tiles out by the first one's cost (mgpu_debug_tile_order): the order is a
+    permutation with the expensive tiles first, and the image equals the image-order launch's bit for bit."""
+    import torch
+    sc = gpu_scene("cornell_obj")
+    W, H, mpl, passes = 512, 384, 5, 4
+    frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    plane = sc.plane()
+    imgs = []
+    for i in range(3):
+        buf = torch.full((H, W, 3), float("nan"), dtype=torch.float32, device="cuda")
+        sc.render_strips_device(frame, W, H, buf.data_ptr(), H, maxPathLength=mpl, passes=passes, plane=plane, seed=5)
+        imgs.append(buf.cpu().numpy())
+    nt = (W // 8) * (H // 8)
+    cost, order = sc.tile_order(nt)
+    assert np.array_equal(np.sort(order), np.arange(nt))
+    assert cost.min() >= 64 * 17  # 64 paths of at least one ray (1 node + 16) each, recorded for pass 0
+    c = cost[order].astype(np.float64)  # this launch's costs along the order derived from the previous launch's
+    assert c[: nt // 8].mean() > 3 * c[-nt // 8:].mean()
+    monkeypatch.setenv("MGPU_TILE_ORDER", "0")
+    buf = torch.full((H, W, 3), float("nan"), dtype=torch.float32, device="cuda")
+    sc.render_strips_device(frame, W, H, buf.data_ptr(), H, maxPathLength=mpl, passes=passes, plane=plane, seed=5)
+    ref = buf.cpu().numpy()
+    assert not np.isnan(ref).any()
+    for im in imgs:
+        assert im.tobytes() == ref.tobytes()
+
+
 def test_tonemap_matches_driver_transforms():
     """1/count + fclamp of the console driver (exact) and of the SDL driver (gamma 2.2 through powf: the device's powf
     may differ from glibc's in the last ulp, which can move a value across an integer boundary -> at most 1 LSB)."""
