@@ -518,12 +518,15 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   // Passes are rendered `group` at a time so that the per-pass planes stay below a fixed budget (1 GiB unless
   // MGPU_PLANES_MAX_MB says otherwise); k_accumulate carries the running float sum from one group to the next, so the
   // additions and their order are those of a single launch.
+  if (tiles >= ((uint64_t)1 << 28)) return fail(MGPU_ERR_INVALID, "window too large: %llu tiles", (unsigned long long)tiles);
   int group = passes;
   if (kern != 0 && passes > 1) {
     size_t budget = (size_t)1 << 30;
     if (const char *e = getenv("MGPU_PLANES_MAX_MB")) budget = (size_t)(atoll(e) < 1 ? 1 : atoll(e)) << 20;
     const size_t fit = budget / (n_floats * sizeof(float));
     if ((size_t)group > fit) group = fit < 1 ? 1 : (int)fit;
+    // the work cursor addresses (tile, pass) items with 28 bits per XCD part
+    while (group > 1 && tiles * (uint64_t)group >= ((uint64_t)1 << 28)) group = (group + 1) / 2;
     const size_t need = n_floats * (size_t)group;
     if (need > s->planes_floats) {
       if (s->p_planes) {
