@@ -140,6 +140,61 @@ def test_trace_random_incoherent_vs_oracle_own_bvh(trace_kernel):
     assert (st["nodes"], st["tris"]) == (ost.nodes, ost.tris)
 
 
+def _soup(rng, nt, dup_frac=0.2, degenerate=2):
+    """Random triangle soup on a coarse coordinate lattice (many exactly shared edges / vertices), with exact duplicate
+    triangles (equal-t ties: the later one in leaf order must win, bvh_accel.cc:624) and zero-area triangles."""
+    nv = max(3, nt)
+    verts = rng.integers(-8, 9, (nv, 3)).astype(np.float64) * 0.5
+    faces = rng.integers(0, nv, (nt, 3)).astype(np.uint32)
+    ndup = int(nt * dup_frac)
+    if ndup:
+        faces[rng.integers(0, nt, ndup)] = faces[rng.integers(0, nt, ndup)]
+    for k in range(min(degenerate, nt)):
+        faces[k, 2] = faces[k, 1]  # zero area
+    return verts, faces
+
+
+@pytest.mark.parametrize("seed,nt", [(1, 1), (2, 2), (3, 17), (4, 64), (5, 300), (6, 1500)])
+def test_random_soups_with_exact_ties_trace_and_render(seed, nt, trace_kernel):
+    """Own BVH on both sides (product builder vs oracle builder must agree first), lattice-aligned and axis-parallel
+    rays so that hits on shared edges and duplicate triangles are common; then a small render with materials."""
+    rng = np.random.default_rng(seed)
+    verts, faces = _soup(rng, nt)
+    mats = rng.integers(0, 4, nt).astype("u4")
+    diffuse = rng.random((3, 3))  # material id 3 is out of range -> default 0.5
+    nodes, idx, _ = M.bvh_build(verts, faces)
+    onodes, oidx, _ = O.bvh_build(verts, faces)
+    assert np.array_equal(idx, oidx) and len(nodes) == len(onodes)
+    for f in ("bmin", "bmax", "flag", "data"):
+        assert np.array_equal(nodes[f], onodes[f]), f
+    sc = M.Scene(verts, faces, mats, None, None, nodes, idx, mat_diffuse=diffuse)
+    osc = O.OracleScene(verts, faces, mats, None, None, onodes, oidx, mat_diffuse=diffuse)
+    n = 20000
+    org = rng.integers(-10, 11, (n, 3)).astype(np.float64) * 0.5
+    tgt = rng.integers(-8, 9, (n, 3)).astype(np.float64) * 0.5 + rng.choice([0.0, 0.0, 0.25], (n, 3))
+    d = tgt - org
+    d[np.all(d == 0, axis=1)] = (0.0, 0.0, 1.0)
+    axis = rng.random(n) < 0.3
+    keep = rng.integers(0, 3, n)
+    d[axis] = np.where(np.arange(3)[None, :] == keep[axis, None], np.sign(d[axis]) + (d[axis] == 0), 0.0)
+    rays = np.hstack([org, d])
+    out, hit, st = sc.trace(rays, want_stats=True)
+    ost = O.Stats()
+    ref = osc.trace(rays, ost)
+    assert np.array_equal(hit, ref["hit"].astype("u1"))
+    h = ref["hit"] == 1
+    for f in ("t", "u", "v", "faceID", "materialID", "normal", "position"):
+        assert out[f][h].tobytes() == ref[f][h].tobytes(), f
+    assert (st["nodes"], st["tris"]) == (ost.nodes, ost.tris)
+    if trace_kernel == "sm":  # the render does not depend on the trace kernel: once is enough
+        W, H = 72, 56
+        frame = M.camera_frame((1.0, 2.0, 14.0), (0, 0, 0), width=W, height=H)
+        img, _, rst = sc.render(frame, W, H, 6, 3, osc.plane(), M.RNG_HASH, seed=seed)
+        oimg, _, orst, _ = osc.render(frame, W, H, 6, 3, osc.plane(), O.RNG_HASH, seed=seed)
+        assert_images_match(img, oimg, "soup %d" % nt)
+        assert (rst["trace_calls"], rst["paths"]) == (orst["trace_calls"], orst["paths"])
+
+
 RENDERS = ["render_cornell_obj_64_plane_2pass", "render_cornell_obj_64_noplane", "render_cornell_obj_128x96_plane",
            "render_cornell_eson_48_plane", "render_cornell_obj_40x56_view2", "render_teapot_obj_64x48_plane"]
 
