@@ -26,11 +26,13 @@ class FrameRenderer:
     """
 
     def __init__(self, scene, frame, W, H, maxPathLength, passes, plane=None, seed=1, rank=0, world=1, device=None,
-                 strip_h=STRIP_H, render_local=None):
+                 strip_h=STRIP_H, render_local=None, tonemap_local=None):
         """render_local(rows, out, pass_base): optional replacement for the device renderer -- fills out[:len(rows)]
         (float32, len(rows) x W x 3) for the given frame rows.  Used by the CPU (gloo) tests of the partition/gather
         logic, where `device` is torch.device("cpu"); the product path leaves it None and renders through the C ABI."""
         self.render_local = render_local
+        self.tonemap_local = tonemap_local  # (float strips, passes, mode, out u8) -> None; CPU tests only
+        self._ldr = {}                      # per display mode: local / gathered / assembled 8-bit buffers
         self.scene, self.frame = scene, np.ascontiguousarray(frame, "<f8")
         self.W, self.H, self.mpl, self.passes = W, H, maxPathLength, passes
         self.plane = None if plane is None else np.ascontiguousarray(plane, "<f4")
@@ -79,3 +81,56 @@ class FrameRenderer:
                 torch.index_select(self.slab.view(self.world * self.max_rows, self.W, 3), 0, self.perm,
                                    out=self.frame_buffer)
         return self.frame_buffer
+
+    # ---- display frame: only 8-bit pixels leave the GPUs ------------------------------------------
+    def _ldr_buffers(self, mode):
+        if mode in self._ldr:
+            return self._ldr[mode]
+        ch = 3 if mode == mgpu.TONEMAP_LINEAR_RGB8 else 4
+        b = dict(ch=ch, local=torch.zeros((self.max_rows, self.W, ch), dtype=torch.uint8, device=self.device),
+                 count=torch.full((self.max_rows, self.W), self.passes, dtype=torch.int32, device=self.device))
+        if self.world > 1 and self.rank == 0:
+            b["slab"] = torch.empty((self.world, self.max_rows, self.W, ch), dtype=torch.uint8, device=self.device)
+            b["gathered"] = list(b["slab"].unbind(0))
+            b["frame"] = torch.empty((self.H, self.W, ch), dtype=torch.uint8, device=self.device)
+        elif self.world == 1:
+            b["frame"] = b["local"]
+        self._ldr[mode] = b
+        return b
+
+    def render_ldr(self, mode=None, pass_base=0):
+        """Renders the frame and returns it DISPLAY-READY on rank 0 (None elsewhere): every rank divides its strips by the
+        pass count and applies the driver's transform itself (mode TONEMAP_LINEAR_RGB8: HDRToLDR of main_console.cc:25-43,
+        H x W x 3; TONEMAP_GAMMA22_BGRA8: Display of main_sdl.cc:420-477, H x W x 4), and the one gather moves 8-bit
+        pixels -- a quarter (RGB8) or a third (BGRA8) of the float traffic.  Pixel for pixel the result equals the
+        transform applied to the gathered float frame: it is per-pixel and count = passes everywhere."""
+        import torch.distributed as dist
+        mode = mgpu.TONEMAP_LINEAR_RGB8 if mode is None else mode
+        b = self._ldr_buffers(mode)
+        # 1. float strips into self.local, exactly as render() does, but without the float gather
+        if self.render_local is not None:
+            if self.n_rows:
+                self.render_local(self.rows, self.local, pass_base)
+        elif self.n_rows:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            self.scene.render_strips_device(self.frame, self.W, self.H, self.local.data_ptr(), self.n_rows,
+                                            y_first=self.rank * self.strip_h, strip_h=self.strip_h,
+                                            y_period=self.strip_h * self.world, maxPathLength=self.mpl,
+                                            passes=self.passes, plane=self.plane, rng_mode=mgpu.RNG_HASH, seed=self.seed,
+                                            pass_base=pass_base, stream=stream)
+        # 2. per-rank display transform of the local strips
+        if self.n_rows:
+            if self.tonemap_local is not None:
+                self.tonemap_local(self.local[: self.n_rows], self.passes, mode, b["local"][: self.n_rows])
+            else:
+                stream = torch.cuda.current_stream(self.device).cuda_stream
+                mgpu.tonemap_device(self.local.data_ptr(), b["count"].data_ptr(), self.n_rows * self.W, mode,
+                                    b["local"].data_ptr(), device=self.device.index or 0, stream=stream)
+        # 3. one gather of 8-bit strips, re-interleaved on rank 0
+        if self.world > 1:
+            dist.gather(b["local"], b["gathered"] if self.rank == 0 else None, dst=0)
+            if self.rank == 0:
+                torch.index_select(b["slab"].view(self.world * self.max_rows, self.W, b["ch"]), 0, self.perm, out=b["frame"])
+                return b["frame"]
+            return None
+        return b["frame"]

@@ -543,6 +543,23 @@ def test_panoramic_full_size_properties():
     assert 0.3 < (img[..., 0] > 0).mean() < 1.0  # inside the Cornell box most directions hit something and bounce out
 
 
+def test_frame_renderer_display_frame_single_gpu():
+    """FrameRenderer.render_ldr on one GPU: k_render_sm + k_tonemap on the local strips == the oracle's display
+    transform of the oracle's float frame (the multi-rank gather of the 8-bit strips is covered by the gloo tests)."""
+    import torch
+    from mallie_amd.frame import FrameRenderer
+    sc, osc = gpu_scene("cornell_obj"), O.scene_from_golden("cornell_obj")
+    W, H, mpl, passes = 200, 120, 5, 4
+    frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    fr = FrameRenderer(sc, frame, W, H, mpl, passes, sc.plane(), 9, 0, 1, torch.device("cuda", 0))
+    oimg, _, _, _ = osc.render(frame, W, H, mpl, passes, osc.plane(), O.RNG_HASH, seed=9)
+    cnt = np.full((H, W), passes, "<i4")
+    for mode in (M.TONEMAP_LINEAR_RGB8, M.TONEMAP_GAMMA22_BGRA8):
+        ldr = fr.render_ldr(mode)
+        torch.cuda.synchronize()
+        assert ldr.cpu().numpy().tobytes() == O.tonemap(oimg, cnt, mode).tobytes()
+
+
 def test_cost_ordered_hand_out_is_a_permutation_and_changes_nothing(monkeypatch):
     """The second launch of a layout hands tiles out by the first one's cost (mgpu_debug_tile_order): the order is a
     permutation with the expensive tiles first, and the image equals the image-order launch's bit for bit."""

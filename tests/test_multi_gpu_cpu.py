@@ -57,6 +57,17 @@ def _worker(rank, world, port, result_path):
             np.save(result_path, out.numpy())
         else:
             assert out is None
+        # display path: per-rank tonemap (the oracle's mo_tonemap standing in for k_tonemap), 8-bit gather
+        def tonemap_local(strips, passes, mode, out_u8):
+            cnt = np.full(strips.shape[:2], passes, "<i4")
+            out_u8.copy_(torch.from_numpy(O.tonemap(strips.numpy(), cnt, mode).reshape(out_u8.shape)))
+        fr.tonemap_local = tonemap_local
+        for mode in (0, 1):
+            ldr = fr.render_ldr(mode, pass_base=2)
+            if rank == 0:
+                np.save(result_path + ".ldr%d.npy" % mode, ldr.numpy())
+            else:
+                assert ldr is None
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -71,6 +82,12 @@ def test_strip_partition_gather_reassemble(world, tmp_path):
     frame = O.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
     ref, _, _, _ = osc.render(frame, W, H, MPL, PASSES, osc.plane(), O.RNG_HASH, seed=SEED, pass_base=2)
     assert got.tobytes() == ref.tobytes()
+    # display frames gathered as 8-bit strips == the driver's transform of the whole float frame
+    cnt = np.full((H, W), PASSES, "<i4")
+    for mode, ch in ((0, 3), (1, 4)):
+        ldr = np.load(path + ".ldr%d.npy" % mode)
+        assert ldr.shape == (H, W, ch) and ldr.dtype == np.uint8
+        assert ldr.tobytes() == O.tonemap(ref, cnt, mode).tobytes()
 
 
 def test_strip_rows_cover_frame_exactly_once():
