@@ -71,6 +71,8 @@ struct MgpuScene {
   size_t t_used = 0;            // events used since the last mgpu_timing_read
   float *p_planes = nullptr;   // per-pass radiance planes of k_render_sm (grow-only)
   size_t planes_floats = 0;
+  void *p_host_img = nullptr;       // mgpu_render: device landing buffer of the host-buffer entry point (grow-only)
+  size_t host_img_bytes = 0;
   uint32_t *p_tile_cost = nullptr;  // per 8x8 tile: cost of the last launch's pass 0 (k_render_sm), feeds k_order_tiles
   uint32_t *p_tile_order = nullptr; // hand-out order of the current launch
   size_t tile_cap = 0;
@@ -308,7 +310,7 @@ int mgpu_scene_destroy(MgpuScene *s) {
   (void)hipSetDevice(s->device);
   (void)hipDeviceSynchronize();
   void *ptrs[] = {s->p_nodes, s->p_tris, s->p_slotn, s->p_mat, s->p_verts, s->p_faces, s->p_fvn, s->p_fvuv,
-                  s->p_overflow, s->p_counters, s->p_stats, s->p_planes, s->p_wave_log, s->p_tile_cost, s->p_tile_order};
+                  s->p_overflow, s->p_counters, s->p_stats, s->p_planes, s->p_wave_log, s->p_tile_cost, s->p_tile_order, s->p_host_img};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -673,10 +675,23 @@ int mgpu_render(MgpuScene *s, const double origin[3], const double corner[3], co
   memcpy(frame + 3, corner, 24);
   memcpy(frame + 6, du, 24);
   memcpy(frame + 9, dv, 24);
-  float *d_img = nullptr;
+  // the frame's landing buffer on the device is kept with the scene (grow-only): a progressive renderer calls this once
+  // per pass with the same size, and hipMalloc + hipFree cost ~0.2 ms of a 7 ms frame
+  const size_t img_bytes = sizeof(float) * 3 * (size_t)ww * wh;
+  if (img_bytes > s->host_img_bytes) {
+    if (s->p_host_img) {
+      (void)hipFree(s->p_host_img);
+      s->device_bytes -= s->host_img_bytes;
+      s->p_host_img = nullptr;
+      s->host_img_bytes = 0;
+    }
+    rc = dev_alloc(s, (void **)&s->p_host_img, img_bytes);
+    if (rc) return rc;
+    s->host_img_bytes = img_bytes;
+  }
+  float *d_img = (float *)s->p_host_img;
   uint32_t *d_states = nullptr;
   auto cleanup = [&]() {
-    if (d_img) (void)hipFree(d_img);
     if (d_states) (void)hipFree(d_states);
   };
 #define TRY_R(expr)                                                                                   \
@@ -687,7 +702,6 @@ int mgpu_render(MgpuScene *s, const double origin[3], const double corner[3], co
       return fail(MGPU_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));                       \
     }                                                                                                 \
   } while (0)
-  TRY_R(hipMalloc((void **)&d_img, sizeof(float) * 3 * (size_t)ww * wh));
   if (rng_mode == MGPU_RNG_TABLE) {
     if (!rng_states) {
       cleanup();
