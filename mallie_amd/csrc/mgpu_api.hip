@@ -71,6 +71,8 @@ struct MgpuScene {
   size_t t_used = 0;            // events used since the last mgpu_timing_read
   float *p_planes = nullptr;   // per-pass radiance planes of k_render_sm (grow-only)
   size_t planes_floats = 0;
+  void *p_trace = nullptr;          // mgpu_trace: device staging of the host-buffer entry point (grow-only)
+  size_t trace_cap = 0;             // rays it holds
   void *p_host_img = nullptr;       // mgpu_render: device landing buffer of the host-buffer entry point (grow-only)
   size_t host_img_bytes = 0;
   uint32_t *p_tile_cost = nullptr;  // per 8x8 tile: cost of the last launch's pass 0 (k_render_sm), feeds k_order_tiles
@@ -310,7 +312,7 @@ int mgpu_scene_destroy(MgpuScene *s) {
   (void)hipSetDevice(s->device);
   (void)hipDeviceSynchronize();
   void *ptrs[] = {s->p_nodes, s->p_tris, s->p_slotn, s->p_mat, s->p_verts, s->p_faces, s->p_fvn, s->p_fvuv,
-                  s->p_overflow, s->p_counters, s->p_stats, s->p_planes, s->p_wave_log, s->p_tile_cost, s->p_tile_order, s->p_host_img};
+                  s->p_overflow, s->p_counters, s->p_stats, s->p_planes, s->p_wave_log, s->p_tile_cost, s->p_tile_order, s->p_host_img, s->p_trace};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -387,14 +389,25 @@ int mgpu_trace(MgpuScene *s, const MgpuRay *rays, size_t n, MgpuIntersection *ou
   if (rc) return rc;
   if (stats) memset(stats, 0, sizeof(*stats));
   if (n == 0) return MGPU_OK;
-  MgpuRay *d_rays = nullptr;
-  MgpuIntersection *d_out = nullptr;
-  uint8_t *d_hit = nullptr;
-  auto cleanup = [&]() {
-    if (d_rays) (void)hipFree(d_rays);
-    if (d_out) (void)hipFree(d_out);
-    if (d_hit) (void)hipFree(d_hit);
-  };
+  // device staging of the host-buffer entry point, kept with the scene (grow-only): Scene::Trace / BVHAccel::Traverse
+  // come through here one ray at a time, and three hipMalloc + hipFree pairs cost more than the trace itself
+  const size_t per_ray = sizeof(MgpuRay) + sizeof(MgpuIntersection) + 16; // + hit byte, padded
+  if (n > s->trace_cap) {
+    if (s->p_trace) {
+      (void)hipFree(s->p_trace);
+      s->device_bytes -= s->trace_cap * per_ray;
+      s->p_trace = nullptr;
+      s->trace_cap = 0;
+    }
+    const size_t cap = n < 4096 ? 4096 : n;
+    rc = dev_alloc(s, (void **)&s->p_trace, cap * per_ray);
+    if (rc) return rc;
+    s->trace_cap = cap;
+  }
+  MgpuIntersection *d_out = (MgpuIntersection *)s->p_trace; // 16-byte aligned (hipMalloc), records first
+  MgpuRay *d_rays = (MgpuRay *)((unsigned char *)s->p_trace + s->trace_cap * sizeof(MgpuIntersection));
+  uint8_t *d_hit = (uint8_t *)s->p_trace + s->trace_cap * (sizeof(MgpuIntersection) + sizeof(MgpuRay));
+  auto cleanup = [&]() {};
 #define TRY_T(expr)                                                                                   \
   do {                                                                                                \
     hipError_t e_ = (expr);                                                                           \
@@ -403,12 +416,11 @@ int mgpu_trace(MgpuScene *s, const MgpuRay *rays, size_t n, MgpuIntersection *ou
       return fail(MGPU_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));                       \
     }                                                                                                 \
   } while (0)
-  TRY_T(hipMalloc((void **)&d_rays, sizeof(MgpuRay) * n));
-  TRY_T(hipMalloc((void **)&d_out, sizeof(MgpuIntersection) * n));
-  TRY_T(hipMalloc((void **)&d_hit, n));
   TRY_T(hipMemcpy(d_rays, rays, sizeof(MgpuRay) * n, hipMemcpyHostToDevice));
   MgpuStats dev_stats;
-  rc = mgpu_trace_device(s, d_rays, n, d_out, d_hit, nullptr, &dev_stats); // waits for the kernel
+  // counters and kernel time only when asked for (they cost two events, a memset and a read-back per call); the
+  // device-to-host copies below wait for the kernel either way
+  rc = mgpu_trace_device(s, d_rays, n, d_out, d_hit, nullptr, stats ? &dev_stats : nullptr);
   if (rc) {
     cleanup();
     return rc;
