@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <vector>
 
 #include "mgpu_kernels.hpp"
@@ -71,6 +72,8 @@ struct MgpuScene {
   size_t t_used = 0;            // events used since the last mgpu_timing_read
   float *p_planes = nullptr;   // per-pass radiance planes of k_render_sm (grow-only)
   size_t planes_floats = 0;
+  std::mutex host_mutex;            // serialises the host-buffer entry points (they share the staging below); the
+                                    // reference calls Scene::Trace from all its OpenMP threads at once
   void *p_trace = nullptr;          // mgpu_trace: device staging of the host-buffer entry point (grow-only)
   size_t trace_cap = 0;             // rays it holds
   void *p_host_img = nullptr;       // mgpu_render: device landing buffer of the host-buffer entry point (grow-only)
@@ -384,6 +387,7 @@ int mgpu_trace_device(MgpuScene *s, const MgpuRay *d_rays, size_t n, MgpuInterse
 int mgpu_trace(MgpuScene *s, const MgpuRay *rays, size_t n, MgpuIntersection *out, uint8_t *hit, MgpuStats *stats) {
   if (!s) return fail(MGPU_ERR_INVALID, "scene is NULL");
   if (n && (!rays || !out || !hit)) return fail(MGPU_ERR_INVALID, "rays/out/hit must be non-NULL");
+  std::lock_guard<std::mutex> host_lock(s->host_mutex);
   const double t0 = now_ms();
   int rc = set_device(s);
   if (rc) return rc;
@@ -676,6 +680,7 @@ int mgpu_render(MgpuScene *s, const double origin[3], const double corner[3], co
   if (W <= 0 || H <= 0 || x0 < 0 || y0 < 0 || x1 > W || y1 > H || x0 > x1 || y0 > y1)
     return fail(MGPU_ERR_INVALID, "bad window");
   if (passes < 1) return fail(MGPU_ERR_INVALID, "passes must be >= 1");
+  std::lock_guard<std::mutex> host_lock(s->host_mutex);
   const double t0 = now_ms();
   int rc = set_device(s);
   if (rc) return rc;
@@ -827,6 +832,7 @@ int mgpu_render_panoramic(MgpuScene *s, const double origin[3], int W, int H, in
   if (W <= 0 || H <= 0 || x0 < 0 || y0 < 0 || x1 > W || y1 > H || x0 > x1 || y0 > y1)
     return fail(MGPU_ERR_INVALID, "bad window");
   if (samples < 1) return fail(MGPU_ERR_INVALID, "samples must be >= 1");
+  std::lock_guard<std::mutex> host_lock(s->host_mutex);
   const double t0 = now_ms();
   int rc = set_device(s);
   if (rc) return rc;

@@ -7,6 +7,7 @@
 //   facade_driver render <obj|eson|vox> <file> <W> <H> <plane> <passes> <maxPathLength> <seed> <out.f32>   (GPU)
 //   facade_driver trace  <obj|eson|vox> <file> <rays.bin> <out.bin>                                          (GPU)
 #include <string>
+#include <thread>
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -96,6 +97,36 @@ int main(int argc, char **argv) {
     FILE *fp = fopen(argv[8], "wb");
     wr(fp, &image[0], 4 * image.size()); wr(fp, &count[0], 4 * count.size());
     fclose(fp);
+    return 0;
+  }
+  if (!strcmp(argv[1], "trace_mt") && argc >= 6) { // Scene::Trace from 4 host threads at once, as the reference's OpenMP loop does
+    mallie::Scene scene;
+    if (!init(scene, argv[2], argv[3], 1.0)) return 3;
+    FILE *fi = fopen(argv[4], "rb");
+    fseek(fi, 0, SEEK_END); size_t n = ftell(fi) / 48; rewind(fi);
+    std::vector<double> rays(6 * n);
+    if (fread(&rays[0], 48, n, fi) != n) return 4;
+    fclose(fi);
+    std::vector<Intersection> rec(n);
+    std::vector<uint32_t> hits(n, 0);
+    memset(&rec[0], 0, sizeof(Intersection) * n);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < 4; t++)
+      pool.push_back(std::thread([&, t]() {
+        for (size_t i = t; i < n; i += 4) {
+          Ray ray;
+          ray.org = real3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
+          ray.dir = real3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+          hits[i] = scene.Trace(rec[i], ray) ? 1 : 0;
+        }
+      }));
+    for (size_t t = 0; t < pool.size(); t++) pool[t].join();
+    FILE *fo = fopen(argv[5], "wb");
+    for (size_t i = 0; i < n; i++) {
+      wr(fo, &hits[i], 4); wr(fo, &rec[i].faceID, 4); wr(fo, &rec[i].t, 8); wr(fo, &rec[i].u, 8); wr(fo, &rec[i].v, 8);
+      wr(fo, &rec[i].normal, 24);
+    }
+    fclose(fo);
     return 0;
   }
   if (!strcmp(argv[1], "trace") && argc >= 6) {

@@ -19,7 +19,7 @@ REF = "/root/reference"
 def driver(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("facade") / "facade_driver")
     libdir = os.path.dirname(M.lib_path())
-    cmd = ["g++", "-O1", "-std=c++11", "-I", os.path.join(ROOT, "include", "mallie"),
+    cmd = ["g++", "-O1", "-std=c++11", "-pthread", "-I", os.path.join(ROOT, "include", "mallie"),
            os.path.join(ROOT, "tests", "cpp", "facade_driver.cc"), "-L", libdir, "-lmallie_mgpu",
            "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -145,6 +145,11 @@ def test_facade_render_and_trace_on_gpu(driver, tmp_path):
     h = ref["hit"] == 1
     for f in ("faceID", "t", "u", "v", "normal"):
         assert rec[f][h].tobytes() == ref[f][h].tobytes(), f
+    # the same rays from four host threads at once (the reference calls Scene::Trace from every OpenMP thread)
+    op2 = str(tmp_path / "hits_mt.bin")
+    r = subprocess.run([driver, "trace_mt", "obj", obj, rp, op2], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert open(op2, "rb").read() == open(op, "rb").read()
 
 
 @pytest.mark.gpu
