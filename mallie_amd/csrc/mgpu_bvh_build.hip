@@ -30,7 +30,7 @@
 
 namespace {
 
-constexpr int kBB = 1024;              // threads per workgroup (one workgroup per node)
+constexpr int kBBMax = 1024;           // threads per workgroup at the top of the tree (one workgroup per node; 256 / 64 further down)
 constexpr double kPad = 2.220446049250313e-16 * 1024;
 constexpr int kMaxBins = 256;          // LDS histogram capacity per (min|max, axis)
 
@@ -82,6 +82,7 @@ __device__ __forceinline__ double box_area(const double lo[3], const double hi[3
 }
 
 // workgroup-wide exclusive scan of one flag per thread; returns this thread's rank and the total
+template <int kBB>
 __device__ __forceinline__ uint32_t block_scan(uint32_t flag, uint32_t *s_wave, uint32_t &total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long m = __ballot(flag != 0);
@@ -99,6 +100,7 @@ __device__ __forceinline__ uint32_t block_scan(uint32_t flag, uint32_t *s_wave, 
   return base + in_wave;
 }
 
+template <int kBB>
 __global__ __launch_bounds__(kBB) void k_build_level(BNode *__restrict__ nodes, uint32_t level_begin, uint32_t level_count,
                                                      const TriRec *__restrict__ rec, uint32_t *__restrict__ idx,
                                                      uint32_t *__restrict__ lpos, uint32_t *__restrict__ rpos,
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(kBB) void k_build_level(BNode *__restrict__ nodes, 
       const uint32_t i = base + tid;
       const uint32_t bad = (i < mid && !(rec[idx[i]].csum[axis] < pos3)) ? 1u : 0u;
       uint32_t tot;
-      const uint32_t k = block_scan(bad, s_wave, tot);
+      const uint32_t k = block_scan<kBB>(bad, s_wave, tot);
       if (bad) lpos[l + carry + k] = i;
       carry += tot;
     }
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(kBB) void k_build_level(BNode *__restrict__ nodes, 
       const uint32_t i = in ? (r - 1 - o) : 0;
       const uint32_t good = (in && (rec[idx[i]].csum[axis] < pos3)) ? 1u : 0u;
       uint32_t tot;
-      const uint32_t k = block_scan(good, s_wave, tot);
+      const uint32_t k = block_scan<kBB>(good, s_wave, tot);
       if (good) rpos[l + carry + k] = i;
       carry += tot;
     }
@@ -387,9 +389,17 @@ extern "C" int mgpu_bvh_build_device(const double *verts, size_t nv, const uint3
       return MGPU_ERR_INVALID;
     }
     B_TRY(hipMemsetAsync(d_cnt.p, 0, sizeof(uint32_t), 0));
-    hipLaunchKernelGGL(k_build_level, dim3(count), dim3(kBB), 0, 0, d_nodes.as<BNode>(), begin, count, d_rec.as<TriRec>(),
-                       d_idx.as<uint32_t>(), d_lpos.as<uint32_t>(), d_rpos.as<uint32_t>(), d_cnt.as<uint32_t>(),
-                       begin + count, (uint32_t)max_nodes, opt);
+    // workgroup size by the level's average node size: one 1024-thread group per node wastes 1000 threads on the
+    // hundreds of thousands of 16..100-triangle nodes near the leaves (10 M triangles: levels 14-24 took 106 of 283 ms)
+    const size_t avg = nf / count;
+#define LAUNCH_LEVEL(BB)                                                                                              \
+  hipLaunchKernelGGL(k_build_level<BB>, dim3(count), dim3(BB), 0, 0, d_nodes.as<BNode>(), begin, count,                  \
+                     d_rec.as<TriRec>(), d_idx.as<uint32_t>(), d_lpos.as<uint32_t>(), d_rpos.as<uint32_t>(),             \
+                     d_cnt.as<uint32_t>(), begin + count, (uint32_t)max_nodes, opt)
+    if (avg >= 4096) LAUNCH_LEVEL(1024);
+    else if (avg >= 256) LAUNCH_LEVEL(256);
+    else LAUNCH_LEVEL(64);
+#undef LAUNCH_LEVEL
     B_TRY(hipGetLastError());
     uint32_t next = 0;
     B_TRY(hipMemcpy(&next, d_cnt.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
