@@ -143,7 +143,7 @@ public:
   ~BVHAccel();
 
   // Binned-SAH build that reproduces the reference tree node for node (bvh_accel.cc:321-482).  Meshes of >= 65536
-  // triangles are built on the GPU when one is present (same bytes, ~15x faster); MALLIE_BVH_BUILD=host|device overrides.
+  // triangles are built on the GPU when one is present (same bytes, ~30x faster); MALLIE_BVH_BUILD=host|device overrides.
   bool Build(const Mesh *mesh, const BVHBuildOptions &options);
   // Extension: the host (CPU) builder only, whatever the size.
   bool BuildOnHost(const Mesh *mesh, const BVHBuildOptions &options);

@@ -641,3 +641,16 @@ def test_device_bvh_build_is_byte_identical():
     a, b = M.bvh_build(verts, faces, device=0), M.bvh_build(verts, faces)
     assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1])
     assert a[2]["maxTreeDepth"] == 23 and a[2]["device_ms"] > 0
+    # the multi-workgroup top levels (nodes of >= 65 536 triangles on average) on awkward inputs: a 400 000-triangle mesh
+    # whose first 300 000 triangles are one and the same (failed partitions -> median splits of huge nodes), whose sizes
+    # are not multiples of anything, and non-default options; and the same kernel switched off must agree too
+    nf = 400003
+    verts = rng.normal(size=(100001, 3)).round(4)
+    faces = rng.integers(0, len(verts), (nf, 3)).astype("u4")
+    faces[:300000] = faces[0]
+    b = M.bvh_build(verts, faces)
+    a = M.bvh_build(verts, faces, device=0)
+    assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) and {k: a[2][k] for k in b[2]} == b[2]
+    a = M.bvh_build(verts, faces, 0.1, 7, 40, 100, device=0)
+    b = M.bvh_build(verts, faces, 0.1, 7, 40, 100)
+    assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1])
