@@ -560,6 +560,32 @@ def test_frame_renderer_display_frame_single_gpu():
         assert ldr.cpu().numpy().tobytes() == O.tonemap(oimg, cnt, mode).tobytes()
 
 
+@pytest.mark.parametrize("strip_h,parts", [(5, 3), (8, 2), (13, 4), (1, 2)])
+def test_odd_strip_layouts_reassemble_to_the_full_frame(strip_h, parts):
+    """mgpu_render_strips_device with strips that are not multiples of the 8-row work tiles, a frame height that is not a
+    multiple of the strip, and a column window: the parts put back together equal the oracle's full-frame render."""
+    import torch
+    from mallie_amd.frame import strip_rows
+    sc, osc = gpu_scene("cornell_obj"), O.scene_from_golden("cornell_obj")
+    W, H, mpl, passes = 90, 61, 5, 3
+    x0, x1 = 7, 83
+    frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    plane = sc.plane()
+    oimg, _, _, _ = osc.render(frame, W, H, mpl, passes, osc.plane(), O.RNG_HASH, seed=21, pass_base=1)
+    got = np.full((H, W, 3), np.nan, "<f4")
+    for part in range(parts):
+        rows = strip_rows(H, parts, part, strip_h)
+        if len(rows) == 0:
+            continue
+        buf = torch.full((len(rows), x1 - x0, 3), float("nan"), dtype=torch.float32, device="cuda")
+        sc.render_strips_device(frame, W, H, buf.data_ptr(), len(rows), x0=x0, x1=x1, y_first=part * strip_h,
+                                strip_h=strip_h, y_period=strip_h * parts, maxPathLength=mpl, passes=passes, plane=plane,
+                                seed=21, pass_base=1)
+        got[rows, x0:x1] = buf.cpu().numpy()
+    assert got[:, x0:x1].tobytes() == np.ascontiguousarray(oimg[:, x0:x1]).tobytes()
+    assert np.isnan(got[:, :x0]).all() and np.isnan(got[:, x1:]).all()
+
+
 def test_cost_ordered_hand_out_is_a_permutation_and_changes_nothing(monkeypatch):
     """The second launch of a layout hands tiles out by the first one's cost (mgpu_debug_tile_order): the order is a
     permutation with the expensive tiles first, and the image equals the image-order launch's bit for bit."""
