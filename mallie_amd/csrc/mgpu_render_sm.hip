@@ -38,7 +38,7 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 
 
 #ifndef MGPU_SHADE_MIN
-#define MGPU_SHADE_MIN 32
+#define MGPU_SHADE_MIN 36
 #endif
 
 // 4 waves per SIMD (<= 128 VGPRs; the compiler then keeps ~40 cold path-state dwords in scratch, touched only by
@@ -52,7 +52,7 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 #define MGPU_WG_CHUNK_HBM 8
 #endif
 #ifndef MGPU_NODES_PER_STEP
-#define MGPU_NODES_PER_STEP 4
+#define MGPU_NODES_PER_STEP 6
 #endif
 #ifndef MGPU_TRIS_PER_STEP
 #define MGPU_TRIS_PER_STEP 16
