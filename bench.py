@@ -4,7 +4,8 @@
 Workload (configs[1]): cornellbox_suzanne, 1920x1080, 16 spp, 4 bounces (maxPathLength 5), plane on,
 eye (0,0,20) -> (0,0,0), per-(pixel,pass) seeding, seed 1.  One "step" = one whole frame: 16 passes of Render()
 semantics accumulated on the device in one persistent-kernel launch per GPU (+ one RCCL gather of the row strips to
-rank 0 when N > 1).  The scene (mesh arrays from tests/golden, BVH built by this library's host builder) is resident
+rank 0 when N > 1; there three frames are kept in flight on three streams so that the gather and the drain of one
+launch overlap the next frames, see --frames-in-flight and DESIGN.md 6).  The scene (mesh arrays from tests/golden, BVH built by this library's host builder) is resident
 in HBM before the timed region; the frame stays in HBM.
 
 "rays" = BVH traversals actually performed ("real" rays: primary + bounce rays up to and including a path's first
@@ -104,6 +105,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frames enqueued concurrently (own stream and buffers each); default 1 on one GPU -- kernel time "
+                         "then is what rocprofv3 shows -- and 3 on N > 1, where the RCCL gather and the end of a launch "
+                         "overlap the next frames' rendering")
     args = ap.parse_args()
 
     import torch
@@ -134,7 +139,8 @@ def main():
     scene = M.Scene(verts, faces, mats, normals, None, device=local_rank)  # BVH: this library's host builder
     frame = M.camera_frame(WORKLOAD["eye"], WORKLOAD["lookat"], width=W, height=H)
     plane = scene.plane() if WORKLOAD["plane"] else None
-    fr = FrameRenderer(scene, frame, W, H, mpl, spp, plane, WORKLOAD["seed"], rank, world, dev)
+    fif = args.frames_in_flight if args.frames_in_flight > 0 else (1 if world == 1 else 3)
+    fr = FrameRenderer(scene, frame, W, H, mpl, spp, plane, WORKLOAD["seed"], rank, world, dev, frames_in_flight=fif)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -187,6 +193,7 @@ def main():
                                    "seeding, seed 1; 1 step = 1 frame",
                        "parallelism": "replicated scene, interleaved 8-row strips x%d, 1 RCCL gather/frame" % world
                                       if world > 1 else "single GPU, persistent-threads kernel",
+                       "frames_in_flight": fif,
                        "rays_per_frame": int(rays / args.steps), "trace_calls_per_frame": int(trace_calls / args.steps),
                        "nodes_per_ray": round(nodes / rays, 3), "tris_per_ray": round(tris / rays, 3),
                        "mtrace_calls_per_s": round(trace_calls / elapsed / 1e6, 2)},

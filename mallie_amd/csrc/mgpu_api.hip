@@ -47,6 +47,24 @@ constexpr int kCounterRing = 64;
 
 } // namespace
 
+// Scratch one render launch owns while it runs.  A slot is bound to the stream that used it last; a launch on another
+// stream takes an unused slot or re-binds the least recently used one after waiting (on the device) for its last launch.
+constexpr int kRenderSlots = 4;
+struct RenderSlot {
+  hipStream_t stream = nullptr;
+  bool used = false;
+  unsigned long long last_use = 0;
+  hipEvent_t done = nullptr;        // recorded after the slot's last launch
+  float *p_planes = nullptr;        // per-pass radiance planes of k_render_sm (grow-only)
+  size_t planes_floats = 0;
+  uint32_t *p_tile_cost = nullptr;  // per 8x8 tile: cost of the last launch's pass 0 (k_render_sm), feeds k_order_tiles
+  uint32_t *p_tile_order = nullptr; // hand-out order of the current launch
+  size_t tile_cap = 0;
+  long long tile_key[6] = {-1, -1, -1, -1, -1, -1}; // window/strip layout the costs belong to
+  void *p_overflow = nullptr;       // HBM stack overflow columns (deep trees only)
+  size_t overflow_lanes = 0;
+};
+
 struct MgpuScene {
   int device = 0;
   size_t nv = 0, nf = 0, nn = 0, nm = 0;
@@ -70,18 +88,17 @@ struct MgpuScene {
   bool timing_on = false;
   std::vector<hipEvent_t> t_ev; // pairs: start, stop
   size_t t_used = 0;            // events used since the last mgpu_timing_read
-  float *p_planes = nullptr;   // per-pass radiance planes of k_render_sm (grow-only)
-  size_t planes_floats = 0;
+  // Launch scratch of the render entry point, one set per stream in use so that frames on different streams overlap
+  // (the end of one launch fills with the next frame's work; mallie_amd/frame.py keeps two frames in flight).
+  RenderSlot slot[kRenderSlots];
+  unsigned long long slot_clock = 0; // use counter for least-recently-used re-binding
   std::mutex host_mutex;            // serialises the host-buffer entry points (they share the staging below); the
                                     // reference calls Scene::Trace from all its OpenMP threads at once
   void *p_trace = nullptr;          // mgpu_trace: device staging of the host-buffer entry point (grow-only)
   size_t trace_cap = 0;             // rays it holds
   void *p_host_img = nullptr;       // mgpu_render: device landing buffer of the host-buffer entry point (grow-only)
   size_t host_img_bytes = 0;
-  uint32_t *p_tile_cost = nullptr;  // per 8x8 tile: cost of the last launch's pass 0 (k_render_sm), feeds k_order_tiles
-  uint32_t *p_tile_order = nullptr; // hand-out order of the current launch
-  size_t tile_cap = 0;
-  long long tile_key[6] = {-1, -1, -1, -1, -1, -1}; // window/strip layout the costs belong to
+  int last_slot = 0;                // slot of the last render launch (mgpu_debug_tile_order)
   unsigned long long *p_wave_log = nullptr; // 4 words x 16384 waves, diagnostic
   double *probe_buf = nullptr; // set only for the duration of mgpu_probe_path
   uint32_t probe_pixel = 0, probe_pass = 0;
@@ -158,6 +175,53 @@ int ensure_overflow(MgpuScene *s, size_t lanes) {
   }
   s->d.stack_overflow = (uint32_t *)s->p_overflow;
   s->d.overflow_cap = (uint32_t)extra;
+  return MGPU_OK;
+}
+
+// The slot a render launch on `st` uses (see RenderSlot).  Launches on one stream always find their own slot again, so
+// the cost order of a repeated frame survives; the event wait makes re-binding safe without a host synchronisation.
+int acquire_slot(MgpuScene *s, hipStream_t st, RenderSlot **out) {
+  RenderSlot *pick = nullptr;
+  for (RenderSlot &r : s->slot)
+    if (r.used && r.stream == st) pick = &r;
+  if (!pick)
+    for (RenderSlot &r : s->slot)
+      if (!r.used) { pick = &r; break; }
+  if (!pick) {
+    pick = &s->slot[0];
+    for (RenderSlot &r : s->slot)
+      if (r.last_use < pick->last_use) pick = &r;
+    HIP_TRY(hipStreamWaitEvent(st, pick->done, 0));
+  }
+  if (!pick->done) HIP_TRY(hipEventCreateWithFlags(&pick->done, hipEventDisableTiming));
+  pick->used = true;
+  pick->stream = st;
+  pick->last_use = ++s->slot_clock;
+  s->last_slot = (int)(pick - s->slot);
+  *out = pick;
+  return MGPU_OK;
+}
+
+// Per-slot overflow columns for `lanes` hardware lanes; fills the launch's own copy of the scene descriptor.
+int slot_overflow(MgpuScene *s, RenderSlot &r, size_t lanes, DScene &d) {
+  const int extra = s->stack_need - s->cap;
+  d.stack_overflow = nullptr;
+  d.overflow_cap = 0;
+  if (extra <= 0) return MGPU_OK;
+  if (lanes > r.overflow_lanes) {
+    if (r.p_overflow) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(r.p_overflow));
+      s->device_bytes -= r.overflow_lanes * (size_t)extra * sizeof(uint32_t);
+      r.p_overflow = nullptr;
+      r.overflow_lanes = 0;
+    }
+    int rc = dev_alloc(s, &r.p_overflow, lanes * (size_t)extra * sizeof(uint32_t));
+    if (rc) return rc;
+    r.overflow_lanes = lanes;
+  }
+  d.stack_overflow = (uint32_t *)r.p_overflow;
+  d.overflow_cap = (uint32_t)extra;
   return MGPU_OK;
 }
 
@@ -315,9 +379,15 @@ int mgpu_scene_destroy(MgpuScene *s) {
   (void)hipSetDevice(s->device);
   (void)hipDeviceSynchronize();
   void *ptrs[] = {s->p_nodes, s->p_tris, s->p_slotn, s->p_mat, s->p_verts, s->p_faces, s->p_fvn, s->p_fvuv,
-                  s->p_overflow, s->p_counters, s->p_stats, s->p_planes, s->p_wave_log, s->p_tile_cost, s->p_tile_order, s->p_host_img, s->p_trace};
+                  s->p_overflow, s->p_counters, s->p_stats, s->p_wave_log, s->p_host_img, s->p_trace};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
+  for (RenderSlot &r : s->slot) {
+    void *rp[] = {r.p_planes, r.p_tile_cost, r.p_tile_order, r.p_overflow};
+    for (void *p : rp)
+      if (p) (void)hipFree(p);
+    if (r.done) (void)hipEventDestroy(r.done);
+  }
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   for (hipEvent_t e : s->t_ev) (void)hipEventDestroy(e);
@@ -503,7 +573,12 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   const uint64_t max_useful = (tiles * 64 + block - 1) / block;
   if (blocks > max_useful) blocks = max_useful;
   if (blocks < 1) blocks = 1;
-  rc = ensure_overflow(s, blocks * block);
+  RenderSlot *slot = nullptr;
+  rc = acquire_slot(s, st, &slot);
+  if (rc) return rc;
+  RenderSlot &R = *slot;
+  DScene dsc = s->d; // this launch's scene descriptor: the overflow columns are the slot's
+  rc = slot_overflow(s, R, blocks * block, dsc);
   if (rc) return rc;
 
   RenderParams P;
@@ -546,26 +621,26 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
     // the work cursor addresses (tile, pass) items with 28 bits per XCD part
     while (group > 1 && tiles * (uint64_t)group >= ((uint64_t)1 << 28)) group = (group + 1) / 2;
     const size_t need = n_floats * (size_t)group;
-    if (need > s->planes_floats) {
-      if (s->p_planes) {
+    if (need > R.planes_floats) {
+      if (R.p_planes) {
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipFree(s->p_planes));
-        s->device_bytes -= s->planes_floats * sizeof(float);
-        s->p_planes = nullptr;
-        s->planes_floats = 0;
+        HIP_TRY(hipFree(R.p_planes));
+        s->device_bytes -= R.planes_floats * sizeof(float);
+        R.p_planes = nullptr;
+        R.planes_floats = 0;
       }
-      rc = dev_alloc(s, (void **)&s->p_planes, need * sizeof(float));
+      rc = dev_alloc(s, (void **)&R.p_planes, need * sizeof(float));
       if (rc) return rc;
-      s->planes_floats = need;
+      R.planes_floats = need;
     }
-    P.out = s->p_planes;
+    P.out = R.p_planes;
     P.pass_stride = n_floats;
   }
   P.stats = s->p_stats;
   P.lds_nodes_bytes = (uint32_t)(sizeof(MgpuNode) * s->nn);
   P.lds_tris_bytes = (uint32_t)(sizeof(DTri) * s->nf);
   if (!s->p_wave_log && getenv("MGPU_WAVE_LOG")) {
-    rc = dev_alloc(s, (void **)&s->p_wave_log, sizeof(unsigned long long) * 4 * 16384);
+    rc = dev_alloc(s, (void **)&s->p_wave_log, sizeof(unsigned long long) * 8 * 16384);
     if (rc) return rc;
   }
   P.wave_log = s->p_wave_log;
@@ -580,27 +655,27 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   bool use_order = kern != 0 && tiles >= 2 * blocks;
   if (const char *e = getenv("MGPU_TILE_ORDER")) use_order = use_order && atoi(e) != 0;
   if (use_order) {
-    if (tiles > s->tile_cap) {
+    if (tiles > R.tile_cap) {
       HIP_TRY(hipDeviceSynchronize());
-      if (s->p_tile_cost) { HIP_TRY(hipFree(s->p_tile_cost)); s->p_tile_cost = nullptr; }
-      if (s->p_tile_order) { HIP_TRY(hipFree(s->p_tile_order)); s->p_tile_order = nullptr; }
-      s->device_bytes -= 2 * s->tile_cap * sizeof(uint32_t);
-      s->tile_cap = 0;
-      rc = dev_alloc(s, (void **)&s->p_tile_cost, tiles * sizeof(uint32_t));
+      if (R.p_tile_cost) { HIP_TRY(hipFree(R.p_tile_cost)); R.p_tile_cost = nullptr; }
+      if (R.p_tile_order) { HIP_TRY(hipFree(R.p_tile_order)); R.p_tile_order = nullptr; }
+      s->device_bytes -= 2 * R.tile_cap * sizeof(uint32_t);
+      R.tile_cap = 0;
+      rc = dev_alloc(s, (void **)&R.p_tile_cost, tiles * sizeof(uint32_t));
       if (rc) return rc;
-      rc = dev_alloc(s, (void **)&s->p_tile_order, tiles * sizeof(uint32_t));
+      rc = dev_alloc(s, (void **)&R.p_tile_order, tiles * sizeof(uint32_t));
       if (rc) return rc;
-      s->tile_cap = tiles;
-      s->tile_key[0] = -1;
+      R.tile_cap = tiles;
+      R.tile_key[0] = -1;
     }
     const long long key[6] = {win_w, n_rows, x0, y_first, strip_h, y_period};
-    if (memcmp(key, s->tile_key, sizeof(key)) != 0) {
-      HIP_TRY(hipMemsetAsync(s->p_tile_cost, 0, tiles * sizeof(uint32_t), st)); // all-zero costs = image order
-      memcpy(s->tile_key, key, sizeof(key));
+    if (memcmp(key, R.tile_key, sizeof(key)) != 0) {
+      HIP_TRY(hipMemsetAsync(R.p_tile_cost, 0, tiles * sizeof(uint32_t), st)); // all-zero costs = image order
+      memcpy(R.tile_key, key, sizeof(key));
     }
-    P.tile_order = s->p_tile_order;
-    P.tile_cost = s->p_tile_cost;
-    launch_order_tiles(st, s->p_tile_cost, (uint32_t)tiles, s->p_tile_order); // outside the kernel-time bracket
+    P.tile_order = R.p_tile_order;
+    P.tile_cost = R.p_tile_cost;
+    launch_order_tiles(st, R.p_tile_cost, (uint32_t)tiles, R.p_tile_order); // outside the kernel-time bracket
     HIP_TRY(hipGetLastError());
   }
   if (stats) {
@@ -624,7 +699,7 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   }
   for (int g0 = 0; g0 < passes; g0 += group) {
     if (use_order && g0 > 0) {
-      launch_order_tiles(st, s->p_tile_cost, (uint32_t)tiles, s->p_tile_order);
+      launch_order_tiles(st, R.p_tile_cost, (uint32_t)tiles, R.p_tile_order);
       HIP_TRY(hipGetLastError());
     }
     const int g = passes - g0 < group ? passes - g0 : group;
@@ -635,13 +710,13 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
     P.work_counter = s->p_counters + (size_t)(s->launch_seq++ % kCounterRing) * kShards;
     HIP_TRY(hipMemsetAsync(P.work_counter, 0, sizeof(uint32_t) * kShards, st));
     if (kern == 0) {
-      launch_render(s->cap, dim3((unsigned)blocks), st, s->d, P);
+      launch_render(s->cap, dim3((unsigned)blocks), st, dsc, P);
       HIP_TRY(hipGetLastError());
     } else {
-      HIP_TRY(launch_render_sm(s->cap, kern == 2, block, dim3((unsigned)blocks), st, shmem, s->d, P));
+      HIP_TRY(launch_render_sm(s->cap, kern == 2, block, dim3((unsigned)blocks), st, shmem, dsc, P));
     }
     if (g0 + g < passes) { // not the last group: fold it into the image now, the planes are reused
-      launch_accumulate(st, s->p_planes, n_floats, g, n_floats, d_image, d_count, g0 > 0);
+      launch_accumulate(st, R.p_planes, n_floats, g, n_floats, d_image, d_count, g0 > 0);
       HIP_TRY(hipGetLastError());
     }
   }
@@ -652,13 +727,14 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   if (kern != 0) {
     if (passes > 1) {
       const int last = passes - ((passes - 1) / group) * group;
-      launch_accumulate(st, s->p_planes, n_floats, last, n_floats, d_image, d_count, passes > group);
+      launch_accumulate(st, R.p_planes, n_floats, last, n_floats, d_image, d_count, passes > group);
       HIP_TRY(hipGetLastError());
     } else if (d_count) {
       launch_accumulate(st, nullptr, 0, 1, n_floats, d_image, d_count, false); // single pass: only count[px] += 1
       HIP_TRY(hipGetLastError());
     }
   }
+  HIP_TRY(hipEventRecord(R.done, st));
   if (stats) {
     unsigned long long w[kStatWords];
     HIP_TRY(hipMemcpyAsync(w, s->p_stats, sizeof(w), hipMemcpyDeviceToHost, st));
@@ -908,19 +984,25 @@ int mgpu_debug_words(MgpuScene *s, unsigned long long *out32) {
 
 int mgpu_debug_tile_order(MgpuScene *s, uint32_t *cost_out, uint32_t *order_out, size_t n_tiles) {
   if (!s) return fail(MGPU_ERR_INVALID, "NULL argument");
-  if (!s->p_tile_cost || n_tiles > s->tile_cap) return fail(MGPU_ERR_INVALID, "no tile order for %zu tiles", n_tiles);
+  const RenderSlot &R = s->slot[s->last_slot];
+  if (!R.p_tile_cost || n_tiles > R.tile_cap) return fail(MGPU_ERR_INVALID, "no tile order for %zu tiles", n_tiles);
   int rc = set_device(s);
   if (rc) return rc;
   HIP_TRY(hipDeviceSynchronize());
-  if (cost_out) HIP_TRY(hipMemcpy(cost_out, s->p_tile_cost, sizeof(uint32_t) * n_tiles, hipMemcpyDeviceToHost));
-  if (order_out) HIP_TRY(hipMemcpy(order_out, s->p_tile_order, sizeof(uint32_t) * n_tiles, hipMemcpyDeviceToHost));
+  if (cost_out) HIP_TRY(hipMemcpy(cost_out, R.p_tile_cost, sizeof(uint32_t) * n_tiles, hipMemcpyDeviceToHost));
+  if (order_out) HIP_TRY(hipMemcpy(order_out, R.p_tile_order, sizeof(uint32_t) * n_tiles, hipMemcpyDeviceToHost));
   return MGPU_OK;
 }
 
 int mgpu_debug_wave_log(MgpuScene *s, unsigned long long *out, size_t n_waves) {
   if (!s || !out || !s->p_wave_log || n_waves > 16384) return fail(MGPU_ERR_INVALID, "no wave log");
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out, s->p_wave_log, sizeof(unsigned long long) * 4 * n_waves, hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> tmp(8 * 16384);
+  HIP_TRY(hipMemcpy(tmp.data(), s->p_wave_log, sizeof(unsigned long long) * 8 * 16384, hipMemcpyDeviceToHost));
+  for (size_t w = 0; w < n_waves; ++w) {
+    memcpy(out + 8 * w, tmp.data() + 4 * w, 4 * sizeof(unsigned long long));
+    memcpy(out + 8 * w + 4, tmp.data() + 4 * 16384 + 4 * w, 4 * sizeof(unsigned long long));
+  }
   return MGPU_OK;
 }
 

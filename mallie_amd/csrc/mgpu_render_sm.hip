@@ -162,6 +162,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
 
 #ifdef MGPU_UTIL
   const unsigned long long cyc_loop0 = clock64();
+  const unsigned long long wall_loop0 = wall_clock64(); // 100 MHz, one base for the whole device (clock64 has many)
+  unsigned long long cyc_dry = 0; // when this wave first found the work cursor exhausted
+  bool dry_mark = false;
+  uint32_t dry_rays = 0, dry_steps = 0, dry_active = 0, dry_plen = 0, dry_inpath = 0, steps_n = 0, steps_t = 0, steps_s = 0;
 #endif
   for (;;) {
     const unsigned long long mN = __ballot(st == ST_NODE);
@@ -169,6 +173,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
     const unsigned long long mS = __ballot(st == ST_SHADE);
     const int cN = __popcll(mN), cT = __popcll(mT), cS = __popcll(mS);
     if ((cN | cT | cS) == 0) break;
+#ifdef MGPU_UTIL
+    if (cyc_dry) ++dry_steps;
+#endif
 
     // Scheduling rule: SHADE is by far the most expensive body (fp64 sqrt/div/acos/sin/cos), so it runs only when at
     // least MGPU_SHADE_MIN lanes wait for it or nothing else is runnable; otherwise the fuller of NODE / TRI runs.
@@ -229,6 +236,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
         }
         if (st == ST_NODE && sp < 0) st = ST_SHADE;
       }
+#ifdef MGPU_UTIL
+      if (cyc_dry) ++steps_n;
+#endif
       MGPU_TOCK(cyc_node);
     } else if (!run_shade) {
       // ================================ TRI step =================================
@@ -281,6 +291,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
         }
         if (tri_cur == tri_end) st = (sp < 0) ? ST_SHADE : ST_NODE;
       }
+#ifdef MGPU_UTIL
+      if (cyc_dry) ++steps_t;
+#endif
       MGPU_TOCK(cyc_tri);
     } else {
       MGPU_TICK();
@@ -426,7 +439,14 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
             // the workgroup's reservation is used up: one wave refills it, the others come back and retry
             uint32_t flag = 0;
             if (lane == 0) flag = __hip_atomic_load(&wg_dry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (__builtin_amdgcn_readfirstlane((int)flag)) { exhausted = true; break; }
+            if (__builtin_amdgcn_readfirstlane((int)flag)) {
+              exhausted = true;
+#ifdef MGPU_UTIL
+              cyc_dry = wall_clock64();
+              dry_mark = true;
+#endif
+              break;
+            }
             uint32_t won = 0;
             if (lane == 0) won = (atomicCAS(&wg_lock, 0u, 1u) == 0u) ? 1u : 0u;
             if (!__builtin_amdgcn_readfirstlane((int)won)) {
@@ -535,6 +555,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
       }
 #ifdef MGPU_UTIL
       cyc_sub[5] += clock64() - cyc_s;
+      if (dry_mark) { // lane-level snapshot right after the hand-out that found the cursor dry
+        dry_mark = false;
+        dry_rays = n_rays;
+        dry_active = (st != ST_IDLE) ? 1u : 0u;
+        dry_plen = (st != ST_IDLE) ? (uint32_t)pathLength : 0u;
+      }
+      if (cyc_dry) ++steps_s;
 #endif
       MGPU_TOCK(cyc_shade);
     }
@@ -559,11 +586,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
 #ifdef MGPU_UTIL
   {
     unsigned long long a = u_node, b = u_tri, cc = u_shade, d = u_shade_lanes;
+    unsigned long long e_rays = n_rays - dry_rays, e_act = dry_active, e_plen = dry_plen;
     for (int off = 32; off; off >>= 1) {
       a += __shfl_down(a, off);
       b += __shfl_down(b, off);
       cc += __shfl_down(cc, off);
       d += __shfl_down(d, off);
+      e_rays += __shfl_down(e_rays, off);
+      e_act += __shfl_down(e_act, off);
+      e_plen += __shfl_down(e_plen, off);
     }
     if (lane == 0) {
       atomicAdd(&P.stats[kUtilNodeSteps], a);
@@ -583,10 +614,16 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
         if (wid < 16384) {
           unsigned xcc;
           asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-          P.wave_log[4 * wid + 0] = cyc_loop0;
-          P.wave_log[4 * wid + 1] = clock64();
-          P.wave_log[4 * wid + 2] = v1;
-          P.wave_log[4 * wid + 3] = xcc & 0xf;
+          P.wave_log[4 * wid + 0] = wall_loop0;
+          P.wave_log[4 * wid + 1] = wall_clock64();
+          P.wave_log[4 * wid + 2] = cyc_dry;
+          P.wave_log[4 * wid + 3] = (xcc & 0xf) | (v1 << 8);
+          // after-dry record, second half of the log: rays traced, lanes alive and their pathLength sum at dry, steps by kind
+          unsigned long long *w2 = P.wave_log + 4 * 16384 + 4 * wid;
+          w2[0] = e_rays;
+          w2[1] = e_act | (e_plen << 16);
+          w2[2] = (unsigned long long)steps_n | ((unsigned long long)steps_t << 20) | ((unsigned long long)steps_s << 40);
+          w2[3] = dry_steps;
         }
       }
     }

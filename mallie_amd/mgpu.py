@@ -327,7 +327,7 @@ class Scene:
         return cost, order
 
     def wave_log(self, n_waves):
-        w = np.zeros((n_waves, 4), "<u8")
+        w = np.zeros((n_waves, 8), "<u8")
         _check(load_library().mgpu_debug_wave_log(self.h, _p(w), n_waves), "mgpu_debug_wave_log")
         return w
 

@@ -560,6 +560,53 @@ def test_frame_renderer_display_frame_single_gpu():
         assert ldr.cpu().numpy().tobytes() == O.tonemap(oimg, cnt, mode).tobytes()
 
 
+def test_frames_in_flight_on_several_streams():
+    """Frames enqueued on different streams overlap on the device (mgpu_render_strips_device keeps one scratch set per
+    stream; a seventh stream re-binds the least recently used set behind an event).  Every frame must equal the oracle's
+    render of its pass_base -- on the LDS-resident cornell box and on the deep tree, whose traversal stacks spill into
+    per-launch HBM columns."""
+    import torch
+    from mallie_amd.frame import FrameRenderer
+    sc, osc = gpu_scene("cornell_obj"), O.scene_from_golden("cornell_obj")
+    W, H, mpl, passes = 256, 144, 5, 4
+    frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    fr = FrameRenderer(sc, frame, W, H, mpl, passes, sc.plane(), 9, 0, 1, torch.device("cuda", 0), frames_in_flight=3)
+    refs = [osc.render(frame, W, H, mpl, passes, osc.plane(), O.RNG_HASH, seed=9, pass_base=4 * k)[0] for k in range(3)]
+    one = FrameRenderer(sc, frame, W, H, mpl, passes, sc.plane(), 9, 0, 1, torch.device("cuda", 0))
+    for k in range(3):  # one frame at a time first: the oracle's frames
+        seq = one.render(pass_base=4 * k)
+        torch.cuda.synchronize()
+        assert_images_match(seq.cpu().numpy(), refs[k], "frame %d" % k)
+        refs[k] = seq.cpu().numpy()
+    for rep in range(3):  # later repetitions run with the cost order of the earlier ones, still three at a time
+        outs = [fr.render(pass_base=4 * k) for k in range(3)]
+        fr.wait()
+        torch.cuda.synchronize()
+        for k in range(3):
+            assert outs[k].cpu().numpy().tobytes() == refs[k].tobytes(), (rep, k)
+    # more streams than scratch sets, deep tree (overflow columns), no synchronisation in between
+    verts, faces = _deep_scene()
+    nodes, idx, _ = M.bvh_build(verts, faces)
+    dsc = M.Scene(verts, faces, None, None, None, nodes, idx)
+    dosc = O.OracleScene(verts, faces, None, None, None, nodes, idx)
+    W, H = 48, 40
+    frame = M.camera_frame((-20.0, 0.5, 0.5), (8.0 ** 3, 100.0, 100.0), width=W, height=H)
+    streams = [torch.cuda.Stream() for _ in range(7)]
+    bufs = [torch.full((H, W, 3), float("nan"), dtype=torch.float32, device="cuda") for _ in streams]
+    torch.cuda.synchronize()
+    for k, (stm, buf) in enumerate(zip(streams, bufs)):
+        dsc.render_strips_device(frame, W, H, buf.data_ptr(), H, maxPathLength=4, passes=2, plane=None, seed=2,
+                                 pass_base=k % 2, stream=stm.cuda_stream)
+    torch.cuda.synchronize()
+    orefs = []
+    for b in (0, 1):
+        img, _, _ = dsc.render(frame, W, H, 4, 2, None, M.RNG_HASH, seed=2, pass_base=b)
+        assert_images_match(img, dosc.render(frame, W, H, 4, 2, None, O.RNG_HASH, seed=2, pass_base=b)[0], "deep %d" % b)
+        orefs.append(img)
+    for k, buf in enumerate(bufs):
+        assert buf.cpu().numpy().tobytes() == orefs[k % 2].tobytes(), k
+
+
 @pytest.mark.parametrize("strip_h,parts", [(5, 3), (8, 2), (13, 4), (1, 2)])
 def test_odd_strip_layouts_reassemble_to_the_full_frame(strip_h, parts):
     """mgpu_render_strips_device with strips that are not multiples of the 8-row work tiles, a frame height that is not a

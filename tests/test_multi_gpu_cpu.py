@@ -73,6 +73,41 @@ def _worker(rank, world, port, result_path):
         dist.destroy_process_group()
 
 
+def _worker_inflight(rank, world, port, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        osc = O.scene_from_golden("cornell_obj")
+        frame = O.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+        plane = osc.plane()
+        fr = FrameRenderer(None, frame, W, H, MPL, PASSES, plane, SEED, rank, world, torch.device("cpu"),
+                           render_local=_oracle_local(osc, frame, plane), frames_in_flight=2)
+        outs = [fr.render(pass_base=b) for b in (0, 3, 6)]  # three frames over two rotating buffer sets
+        fr.wait()
+        if rank == 0:
+            assert outs[0] is outs[2] and outs[0] is not outs[1]  # frame 2 reuses (and overwrote) frame 0's buffers
+            np.save(result_path, np.stack([outs[1].numpy(), outs[2].numpy()]))
+        else:
+            assert all(o is None for o in outs)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_frames_in_flight_rotate_buffers(tmp_path):
+    """bench.py's N>1 configuration: consecutive frames alternate between two buffer sets (on a GPU: two streams), every
+    rank issues its gathers in frame order.  Frames 1 and 2 (pass_base 3 and 6) must equal single-process renders."""
+    path = str(tmp_path / "frames.npy")
+    mp.spawn(_worker_inflight, args=(2, _free_port(), path), nprocs=2, join=True)
+    got = np.load(path)
+    osc = O.scene_from_golden("cornell_obj")
+    frame = O.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    for k, base in enumerate((3, 6)):
+        ref, _, _, _ = osc.render(frame, W, H, MPL, PASSES, osc.plane(), O.RNG_HASH, seed=SEED, pass_base=base)
+        assert got[k].tobytes() == ref.tobytes()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_strip_partition_gather_reassemble(world, tmp_path):
     path = str(tmp_path / "frame.npy")
