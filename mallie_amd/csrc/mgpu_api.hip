@@ -69,6 +69,7 @@ struct MgpuScene {
   int device = 0;
   size_t nv = 0, nf = 0, nn = 0, nm = 0;
   int tree_depth = 0;  // deepest node level (root = 0)
+  bool boxes_ordered = false; // bmin <= bmax in every reachable node (lets the kernels take the min/max slab test)
   int stack_need = 1;  // entries a traversal can ever hold = tree_depth + 1
   int cap = 16;        // LDS stack entries per lane of the instantiated kernels
   double bmin[3], bmax[3];
@@ -123,7 +124,7 @@ int upload(MgpuScene *s, void **p, const void *src, size_t bytes) {
 }
 
 // Validates the tree (child / leaf ranges in bounds, no cycles through an explicit visit budget) and returns its depth.
-int tree_depth(const MgpuNode *nodes, size_t nn, size_t nf, int *depth_out) {
+int tree_depth(const MgpuNode *nodes, size_t nn, size_t nf, int *depth_out, bool *boxes_ordered) {
   struct Item { uint32_t node; int depth; };
   std::vector<Item> stack;
   stack.push_back({0u, 0});
@@ -135,6 +136,8 @@ int tree_depth(const MgpuNode *nodes, size_t nn, size_t nf, int *depth_out) {
     if (++visited > nn) return fail(MGPU_ERR_INVALID, "BVH is not a tree (more than %zu node visits)", nn);
     const MgpuNode &n = nodes[it.node];
     if (it.depth > depth) depth = it.depth;
+    for (int k = 0; k < 3; k++) // false for NaNs too; an empty builder box (bmin = +max, bmax = -max) also lands here
+      if (!(n.bmin[k] <= n.bmax[k])) *boxes_ordered = false;
     if (n.flag == 0) {
       if (n.axis < 0 || n.axis > 2) return fail(MGPU_ERR_INVALID, "node %u: bad axis %d", it.node, n.axis);
       for (int k = 0; k < 2; k++) {
@@ -147,7 +150,7 @@ int tree_depth(const MgpuNode *nodes, size_t nn, size_t nf, int *depth_out) {
     }
   }
   *depth_out = depth;
-  return MGPU_OK;
+  return MGPU_OK; // *boxes_ordered was initialised by the caller
 }
 
 int set_device(const MgpuScene *s) {
@@ -282,7 +285,8 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
   for (size_t i = 0; i < nf; i++)
     if (indices[i] >= nf) return fail(MGPU_ERR_INVALID, "indices[%zu] = %u >= %zu faces", i, indices[i], nf);
   int depth = 0;
-  int rc = tree_depth(nodes, nn, nf, &depth);
+  bool boxes_ordered = true;
+  int rc = tree_depth(nodes, nn, nf, &depth, &boxes_ordered);
   if (rc) return rc;
   if (depth + 1 > 512) return fail(MGPU_ERR_STACK, "tree depth %d needs more than the reference's 512 stack entries", depth);
 
@@ -291,6 +295,7 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
   s->device = device;
   s->nv = nv; s->nf = nf; s->nn = nn; s->nm = nm;
   s->tree_depth = depth;
+  s->boxes_ordered = boxes_ordered;
   s->stack_need = depth + 1;
   s->cap = pick_stack_cap(s->stack_need);
   for (int k = 0; k < 3; k++) { s->bmin[k] = nodes[0].bmin[k]; s->bmax[k] = nodes[0].bmax[k]; }
@@ -369,6 +374,9 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
   s->d.fv_uvs = (const double *)s->p_fvuv;
   s->d.stack_overflow = nullptr;
   s->d.overflow_cap = 0;
+  s->d.boxes_ordered = s->boxes_ordered ? 1 : 0;
+  if (const char *e = getenv("MGPU_PLAIN_SLABS")) // 0: literal slab test only (A/B measurements, tests)
+    if (atoi(e) == 0) s->d.boxes_ordered = 0;
   *out = s;
   return MGPU_OK;
 #undef TRY_OR_FREE

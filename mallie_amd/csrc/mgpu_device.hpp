@@ -49,6 +49,9 @@ struct DScene {
   // traversal stack overflow area (entries beyond the LDS part), per hardware lane slot
   uint32_t *stack_overflow;
   uint32_t overflow_cap; // entries per lane
+  // every reachable node has bmin <= bmax on all axes (checked at scene creation): rays without infinities may then
+  // take the min/max form of the slab test, see slab_hit
+  int boxes_ordered;
 };
 
 struct Hit {
@@ -87,6 +90,47 @@ __device__ __forceinline__ V3 normalized(V3 a) {
     a.z *= inv;
   }
   return a;
+}
+
+// ---- slab test ----------------------------------------------------------------------------------------------------
+// IntersectRayAABB (bvh_accel.cc:550-593) of the box {b0 = (min.x, min.y), b1 = (min.z, max.x), b2 = (max.y, max.z)}
+// (the node's first 48 bytes as three 16-byte loads) against a ray with inverse direction (ix, iy, iz) and direction
+// signs (sx, sy, sz), current best t `bt`.
+// kPlain = false is the literal form: near / far plane picked by the direction sign, `(a > b) ? a : b` selects (they
+// keep the SECOND operand when a NaN is involved, which v_max_f64 would not).
+// kPlain = true is for rays with ray_is_plain() in a tree with DScene::boxes_ordered: no product can be a NaN, and
+// with bmin <= bmax and a finite non-zero inverse the near plane's product is the smaller of the two (rounding is
+// monotonic), so the selects collapse to v_min_f64 / v_max_f64.  The values equal the literal form's up to the sign
+// of a zero, which none of the three comparisons can see: 25 instead of 39 VALU instructions per box.
+template <bool kPlain>
+__device__ __forceinline__ bool slab_hit(double2 b0, double2 b1, double2 b2, V3 org, double ix, double iy, double iz,
+                                         bool sx, bool sy, bool sz, double bt) {
+  double tmin, tmax;
+  if (kPlain) {
+    const double lx = (b0.x - org.x) * ix, hx = (b1.y - org.x) * ix;
+    const double ly = (b0.y - org.y) * iy, hy = (b2.x - org.y) * iy;
+    const double lz = (b1.x - org.z) * iz, hz = (b2.y - org.z) * iz;
+    tmin = __builtin_fmax(__builtin_fmax(__builtin_fmin(lx, hx), __builtin_fmin(ly, hy)), __builtin_fmin(lz, hz));
+    tmax = __builtin_fmin(__builtin_fmin(__builtin_fmax(lx, hx), __builtin_fmax(ly, hy)), __builtin_fmax(lz, hz));
+  } else {
+    const double nx = sx ? b1.y : b0.x, fx = sx ? b0.x : b1.y;
+    const double ny = sy ? b2.x : b0.y, fy = sy ? b0.y : b2.x;
+    const double nz = sz ? b2.y : b1.x, fz = sz ? b1.x : b2.y;
+    const double tmin_x = (nx - org.x) * ix, tmax_x = (fx - org.x) * ix;
+    const double tmin_y = (ny - org.y) * iy, tmax_y = (fy - org.y) * iy;
+    tmin = (tmin_x > tmin_y) ? tmin_x : tmin_y;
+    tmax = (tmax_x < tmax_y) ? tmax_x : tmax_y;
+    const double tmin_z = (nz - org.z) * iz, tmax_z = (fz - org.z) * iz;
+    tmin = (tmin > tmin_z) ? tmin : tmin_z;
+    tmax = (tmax < tmax_z) ? tmax : tmax_z;
+  }
+  return (tmax > 0.0) && (tmin <= tmax) && (tmin <= bt);
+}
+// 1/d finite and non-zero on every axis and a finite origin: (b - o) * inv is then never NaN (an overflowed difference
+// gives +-inf), and sign(inv) is the direction sign the literal form selects by.
+__device__ __forceinline__ bool ray_is_plain(V3 org, double ix, double iy, double iz) {
+  return __builtin_isfinite(ix) && ix != 0.0 && __builtin_isfinite(iy) && iy != 0.0 && __builtin_isfinite(iz) && iz != 0.0 &&
+         __builtin_isfinite(org.x) && __builtin_isfinite(org.y) && __builtin_isfinite(org.z);
 }
 
 // ---- RNG ----------------------------------------------------------------------------------------------------------

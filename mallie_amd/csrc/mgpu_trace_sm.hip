@@ -17,6 +17,7 @@
 // Ray indices are handed out in order: a wave reserves kRayChunk consecutive indices with one global atomic and deals
 // them to its lanes as they free up, so neighbouring lanes mostly hold neighbouring rays (coalesced-ish loads, record
 // stores that fill whole cache lines between them).
+#include <type_traits>
 #include "mgpu_device.hpp"
 #include "mgpu_kernels.hpp"
 
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
   V3 org = v3(0, 0, 0), dir = v3(0, 0, 1);
   double ix = 0, iy = 0, iz = 0;
   bool sx = false, sy = false, sz = false;
+  bool ray_plain = false; // the ray may take the min/max form of the slab test (mgpu_device.hpp, slab_hit)
   int sp = -1;
   double bt = kDblMax, bu = 0, bv = 0;
   uint32_t bslot = kNoHit;
@@ -75,44 +77,40 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
     const bool run_emit = (cE >= MGPU_EMIT_MIN) || (cN == 0 && cT == 0);
     if (!run_emit && cN >= cT) {
       // ================================ NODE step ================================
+      const bool all_plain = __ballot(st == TS_NODE && !ray_plain) == 0ull; // wave-uniform
       if (st == TS_NODE) {
+        // slab_hit<true> (min/max form) when every lane's ray qualifies, the literal form for this step otherwise
+        auto node_pops = [&](auto plain_tag) {
+          constexpr bool kPlain = decltype(plain_tag)::value;
 #pragma unroll 1
-        for (int rep = 0; rep < 4; ++rep) {
-          const uint32_t ni = stk.get(sp);
-          --sp;
-          ++n_nodes;
-          const MgpuNode *nd = sc.nodes + ni;
-          const double2 b0 = *reinterpret_cast<const double2 *>(&nd->bmin[0]);
-          const double2 b1 = *reinterpret_cast<const double2 *>(&nd->bmin[2]);
-          const double2 b2 = *reinterpret_cast<const double2 *>(&nd->bmax[1]);
-          const int4 meta = *reinterpret_cast<const int4 *>(&nd->flag);
-          // IntersectRayAABB, bvh_accel.cc:550-593
-          const double nx = sx ? b1.y : b0.x, fx = sx ? b0.x : b1.y;
-          const double ny = sy ? b2.x : b0.y, fy = sy ? b0.y : b2.x;
-          const double nz = sz ? b2.y : b1.x, fz = sz ? b1.x : b2.y;
-          const double tmin_x = (nx - org.x) * ix, tmax_x = (fx - org.x) * ix;
-          const double tmin_y = (ny - org.y) * iy, tmax_y = (fy - org.y) * iy;
-          double tmin = (tmin_x > tmin_y) ? tmin_x : tmin_y;
-          double tmax = (tmax_x < tmax_y) ? tmax_x : tmax_y;
-          const double tmin_z = (nz - org.z) * iz, tmax_z = (fz - org.z) * iz;
-          tmin = (tmin > tmin_z) ? tmin : tmin_z;
-          tmax = (tmax < tmax_z) ? tmax : tmax_z;
-          const bool hit = (tmax > 0.0) && (tmin <= tmax) && (tmin <= bt);
-          if (hit) {
-            if (meta.x == 0) {
-              const bool nearIsSecond = (meta.y == 0) ? sx : ((meta.y == 1) ? sy : sz); // dirSign[node.axis]
-              const uint32_t c0 = (uint32_t)meta.z, c1 = (uint32_t)meta.w;
-              stk.put(sp + 1, nearIsSecond ? c0 : c1); // far
-              stk.put(sp + 2, nearIsSecond ? c1 : c0); // near: popped first
-              sp += 2;
-            } else if (meta.z != 0) {
-              tri_cur = (uint32_t)meta.w;
-              tri_end = (uint32_t)meta.w + (uint32_t)meta.z;
-              st = TS_TRI;
+          for (int rep = 0; rep < 4; ++rep) {
+            const uint32_t ni = stk.get(sp);
+            --sp;
+            ++n_nodes;
+            const MgpuNode *nd = sc.nodes + ni;
+            const double2 b0 = *reinterpret_cast<const double2 *>(&nd->bmin[0]);
+            const double2 b1 = *reinterpret_cast<const double2 *>(&nd->bmin[2]);
+            const double2 b2 = *reinterpret_cast<const double2 *>(&nd->bmax[1]);
+            const int4 meta = *reinterpret_cast<const int4 *>(&nd->flag);
+            const bool hit = slab_hit<kPlain>(b0, b1, b2, org, ix, iy, iz, sx, sy, sz, bt); // IntersectRayAABB
+            if (hit) {
+              if (meta.x == 0) {
+                const bool nearIsSecond = (meta.y == 0) ? sx : ((meta.y == 1) ? sy : sz); // dirSign[node.axis]
+                const uint32_t c0 = (uint32_t)meta.z, c1 = (uint32_t)meta.w;
+                stk.put(sp + 1, nearIsSecond ? c0 : c1); // far
+                stk.put(sp + 2, nearIsSecond ? c1 : c0); // near: popped first
+                sp += 2;
+              } else if (meta.z != 0) {
+                tri_cur = (uint32_t)meta.w;
+                tri_end = (uint32_t)meta.w + (uint32_t)meta.z;
+                st = TS_TRI;
+              }
             }
+            if (st != TS_NODE || sp < 0) break;
           }
-          if (st != TS_NODE || sp < 0) break;
-        }
+        };
+        if (all_plain) node_pops(std::true_type{});
+        else node_pops(std::false_type{});
         if (st == TS_NODE && sp < 0) st = TS_EMIT;
       }
     } else if (!run_emit) {
@@ -262,6 +260,7 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
           dir = v3(r->dir[0], r->dir[1], r->dir[2]);
           sx = dir.x < 0.0; sy = dir.y < 0.0; sz = dir.z < 0.0;
           ix = 1.0 / dir.x; iy = 1.0 / dir.y; iz = 1.0 / dir.z; // no zero guard, as the reference
+          ray_plain = sc.boxes_ordered && ray_is_plain(org, ix, iy, iz);
           bt = kDblMax; bu = 0.0; bv = 0.0; bslot = kNoHit;
           sp = 0;
           stk.put(0, 0u);

@@ -140,6 +140,59 @@ def test_trace_random_incoherent_vs_oracle_own_bvh(trace_kernel):
     assert (st["nodes"], st["tris"]) == (ost.nodes, ost.tris)
 
 
+def test_slab_test_forms_axis_parallel_rays_and_disordered_boxes(trace_kernel):
+    """The kernels take the min/max form of IntersectRayAABB only for rays whose inverse direction is finite and
+    non-zero, in trees whose boxes all have bmin <= bmax (mgpu_device.hpp, slab_hit); everything else must go through the
+    literal form with its NaN-keeping selects.  (a) 100k rays of which two thirds have one or two direction components
+    exactly zero (1/0 = inf, 0 * inf = NaN when the origin lies on a box plane -- origins are snapped to node planes),
+    mixed lane by lane with ordinary rays; (b) the same scene with some boxes turned inside out or given a NaN bound, which
+    the reference traverses literally."""
+    g = O.load_golden("cornell_obj")
+    rng = np.random.default_rng(31)
+    nodes = g["nodes"].copy()
+    planes = np.concatenate([nodes["bmin"].ravel(), nodes["bmax"].ravel()])
+    n = 100000
+    lo, hi = nodes["bmin"][0], nodes["bmax"][0]
+    o = lo + (hi - lo) * (rng.random((n, 3)) * 1.2 - 0.1)
+    snap = rng.random((n, 3)) < 0.3
+    o[snap] = planes[rng.integers(0, len(planes), snap.sum())]  # coordinates exactly on node planes
+    d = rng.normal(size=(n, 3))
+    kind = rng.integers(0, 3, n)
+    for i, k in enumerate(kind):  # 0: ordinary, 1: one zero component, 2: two zero components
+        if k:
+            d[i, rng.permutation(3)[:k]] = 0.0 * rng.choice([-1.0, 1.0])  # +0 and -0
+    rays = np.hstack([o, d])
+    for variant in ("ordered", "disordered"):
+        nd = nodes.copy()
+        if variant == "disordered":
+            pick = 1 + rng.choice(len(nd) - 1, 12, replace=False)  # not the root: its box places the ground plane
+            for j, ni in enumerate(pick):
+                ax = j % 3
+                if j < 9:
+                    nd["bmin"][ni, ax], nd["bmax"][ni, ax] = nd["bmax"][ni, ax], nd["bmin"][ni, ax]
+                else:
+                    nd["bmax"][ni, ax] = np.nan
+        uv = O.golden_uvs(g)
+        nrm = g["normals"] if g["has_normals"] else None
+        sc = M.Scene(g["verts"], g["faces"], g["matIDs"], nrm, uv, nd, g["indices"])
+        osc = O.OracleScene(g["verts"], g["faces"], g["matIDs"], nrm, uv, nd, g["indices"])
+        out, hit, st = sc.trace(rays, want_stats=True)
+        ost = O.Stats()
+        ref = osc.trace(rays, ost)
+        assert np.array_equal(hit, ref["hit"].astype("u1")), variant
+        h = ref["hit"] == 1
+        assert h.sum() > 1000
+        for f in ("t", "u", "v", "faceID", "normal"):
+            assert out[f][h].tobytes() == ref[f][h].tobytes(), (variant, f)
+        assert (st["nodes"], st["tris"]) == (ost.nodes, ost.tris), variant
+        # and through the renderer (k_render_sm): same images as the oracle on the same tree
+        W, H = 96, 64
+        frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+        img, _, _ = sc.render(frame, W, H, 5, 2, sc.plane(), M.RNG_HASH, seed=4)
+        oimg, _, _, _ = osc.render(frame, W, H, 5, 2, osc.plane(), O.RNG_HASH, seed=4)
+        assert_images_match(img, oimg, variant)
+
+
 def _soup(rng, nt, dup_frac=0.2, degenerate=2):
     """Random triangle soup on a coarse coordinate lattice (many exactly shared edges / vertices), with exact duplicate
     triangles (equal-t ties: the later one in leaf order must win, bvh_accel.cc:624) and zero-area triangles."""
