@@ -80,6 +80,32 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {
   return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 __device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// ---- IEEE sqrt / reciprocal without the range handling ----------------------------------------------------------
+// hipcc expands fp64 sqrt into 18 and 1.0 / x into 11 instructions; 8 resp. 4 of them scale operands near the ends of
+// the exponent range and patch 0 / inf / NaN.  These are the same sequences without those steps: bit-identical results
+// for operands well inside the range (checked on 2 x 10^10 operands, profiles/microbench/exact_cores.hip), garbage
+// outside it -- every caller guards the range and falls back to the plain operator.
+__device__ __forceinline__ double sqrt_core(double x) { // 2^-500 < x < 2^500
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+}
+__device__ __forceinline__ double rcp_core(double x) { // 2^-500 < |x| < 2^500
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  return __builtin_fma(y, e, y);
+}
+
 // real3::normalize, common.h:46-56
 __device__ __forceinline__ V3 normalized(V3 a) {
   double len = sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
@@ -90,6 +116,34 @@ __device__ __forceinline__ V3 normalized(V3 a) {
     a.z *= inv;
   }
   return a;
+}
+
+// normalized() as a wave executes it: the short sequences when every active lane's squared length is well inside their
+// range and above the reference's 1e-6 guard on the length (then the guard passes and the values are the literal
+// form's), the literal form for all lanes otherwise.  19 instead of 30 instructions.
+__device__ __forceinline__ V3 normalized_w(V3 a) {
+  const double d2 = a.x * a.x + a.y * a.y + a.z * a.z;
+  const bool ok = d2 > 1.0e-11 && d2 < 1.0e+100;
+  if (__builtin_expect(__ballot(!ok) != 0ull, 0)) return normalized(a);
+  const double inv = rcp_core(sqrt_core(d2));
+  return v3(a.x * inv, a.y * inv, a.z * inv);
+}
+// invDir of BVHAccel::Traverse (bvh_accel.cc:774-802: 1.0 / dir, no zero guard) as a wave executes it.  Returns whether
+// all three inverses of this lane came out with 2^-400 < |1/d| < 2^400 -- which implies that the operands were inside
+// rcp_core's range, and is the inverse-direction half of ray_is_plain.  One lane outside sends the wave through the
+// plain operator.
+__device__ __forceinline__ bool inverse_dir_w(V3 dir, double &ix, double &iy, double &iz) {
+  ix = rcp_core(dir.x);
+  iy = rcp_core(dir.y);
+  iz = rcp_core(dir.z);
+  const double lo = 0x1p-400, hi = 0x1p+400;
+  const bool ok = fabs(ix) > lo && fabs(ix) < hi && fabs(iy) > lo && fabs(iy) < hi && fabs(iz) > lo && fabs(iz) < hi;
+  if (__builtin_expect(__ballot(!ok) != 0ull, 0)) {
+    ix = 1.0 / dir.x;
+    iy = 1.0 / dir.y;
+    iz = 1.0 / dir.z;
+  }
+  return ok;
 }
 
 // ---- slab test ----------------------------------------------------------------------------------------------------
@@ -128,6 +182,9 @@ __device__ __forceinline__ bool slab_hit(double2 b0, double2 b1, double2 b2, V3 
 }
 // 1/d finite and non-zero on every axis and a finite origin: (b - o) * inv is then never NaN (an overflowed difference
 // gives +-inf), and sign(inv) is the direction sign the literal form selects by.
+__device__ __forceinline__ bool origin_is_finite(V3 org) {
+  return __builtin_isfinite(org.x) && __builtin_isfinite(org.y) && __builtin_isfinite(org.z);
+}
 __device__ __forceinline__ bool ray_is_plain(V3 org, double ix, double iy, double iz) {
   return __builtin_isfinite(ix) && ix != 0.0 && __builtin_isfinite(iy) && iy != 0.0 && __builtin_isfinite(iz) && iz != 0.0 &&
          __builtin_isfinite(org.x) && __builtin_isfinite(org.y) && __builtin_isfinite(org.z);
@@ -287,7 +344,7 @@ __device__ __forceinline__ void traverse(const DScene &sc, const Stack<CAP, OVF>
 // `unit_n` = normalized((double)pl[0..2]) computed once on the host (the same IEEE sqrt / division).
 __device__ __forceinline__ bool plane_hit(const float pl[4], const double unit_n[3], V3 org, V3 dir, double &t_io, V3 &normal) {
   V3 n = v3((double)pl[0], (double)pl[1], (double)pl[2]);
-  const V3 v = normalized(dir);
+  const V3 v = normalized_w(dir);
   const float vn = (float)dot(v, n);
   if (fabsf(vn) > 1.1920929e-07f * 1024.0f) {
     const float on_d = (float)(dot(org, n) + (double)pl[3]);
@@ -320,10 +377,11 @@ __device__ __forceinline__ V3 sample_diffuse(V3 n, Rng &rng) {
   t.x = use_z ? -n.y : (use_y ? -n.z : 0.0);
   t.y = use_z ? n.x : (use_y ? 0.0 : -n.z);
   t.z = use_z ? 0.0 : (use_y ? n.x : n.y);
-  t = normalized(t);
-  const V3 b = normalized(cross(t, n));
+  t = normalized_w(t);
+  const V3 b = normalized_w(cross(t, n));
   // theta = acos(sqrt(1 - u1)), phi = 2*pi*u2 (render.cc:325-326); only sin/cos of the two angles are ever used.
-  const double x = sqrt(1.0 - rng_next(rng)); // = cos(theta) before the reference's acos -> cos round trip
+  // = cos(theta) before the reference's acos -> cos round trip; the argument is 1 - k / 2^32 >= 2^-32
+  const double x = sqrt_core(1.0 - rng_next(rng));
   const double u2 = rng_next(rng);
   double sin_theta, cos_theta, sin_phi, cos_phi;
 #if MGPU_SAMPLE_MATH == 0
@@ -338,7 +396,9 @@ __device__ __forceinline__ V3 sample_diffuse(V3 n, Rng &rng) {
   // sin/cos(2*pi*u2) through sincospi of the exactly representable 2*u2 (the reference rounds 2*pi*u2 first:
   // <= 1.5e-15 absolute difference).  See DESIGN.md "Numerics" for why this cannot move a pixel.
   cos_theta = x;
-  sin_theta = sqrt(fma(-x, x, 1.0));
+  const double s2 = fma(-x, x, 1.0); // >= 2^-53 or exactly 0 (u1 == 0)
+  if (__builtin_expect(__ballot(!(s2 > 0x1p-100)) != 0ull, 0)) sin_theta = sqrt(s2);
+  else sin_theta = sqrt_core(s2);
   sincospi(2.0 * u2, &sin_phi, &cos_phi);
 #endif
   const V3 T = scale(scale(t, cos_phi), sin_theta);
@@ -353,7 +413,7 @@ __device__ __forceinline__ V3 camera_dir(const double *frame, double u, double v
   d.x = (frame[3] + u * frame[6] + v * frame[9]) - frame[0];
   d.y = (frame[4] + u * frame[7] + v * frame[10]) - frame[1];
   d.z = (frame[5] + u * frame[8] + v * frame[11]) - frame[2];
-  return normalized(d);
+  return normalized_w(d);
 }
 
 } // namespace mgpu

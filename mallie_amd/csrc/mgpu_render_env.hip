@@ -314,11 +314,11 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
               sincos(theta, &sin_t, &cos_t);
               const V3 d0 = v3(sin_t * cos_p, cos_t, sin_t * sin_p);
               V3 par = left ? v3(-d0.z, 0.0, d0.x) : v3(d0.z, 0.0, -d0.x);
-              par = scale(normalized(par), 0.5);
+              par = scale(normalized_w(par), 0.5);
               org = v3(P.origin[0] + par.x, P.origin[1] + par.y, P.origin[2] + par.z);
               // psi = atan2(0.5, 4), negated for the left eye; cos / sin of it come from the host's libm
               const double cpsi = P.cos_psi, spsi = left ? -P.sin_psi : P.sin_psi;
-              dir = normalized(v3(d0.x * cpsi - d0.z * spsi, d0.y, d0.x * spsi + d0.z * cpsi));
+              dir = normalized_w(v3(d0.x * cpsi - d0.z * spsi, d0.y, d0.x * spsi + d0.z * cpsi));
             }
             rad = 0.0;
             pathLength = 1;
@@ -326,8 +326,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
           }
           // arm the traversal of (org, dir): BVHAccel::Traverse prologue, bvh_accel.cc:774-802
           sx = dir.x < 0.0; sy = dir.y < 0.0; sz = dir.z < 0.0;
-          ix = 1.0 / dir.x; iy = 1.0 / dir.y; iz = 1.0 / dir.z; // no zero guard, as the reference
-          ray_plain = sc.boxes_ordered && ray_is_plain(org, ix, iy, iz);
+          const bool inv_ok = inverse_dir_w(dir, ix, iy, iz); // 1.0 / dir, no zero guard, as the reference
+          ray_plain = sc.boxes_ordered && inv_ok && origin_is_finite(org);
           bt = kDblMax; bu = 0.0; bv = 0.0; bslot = kNoHit;
           sp = 0;
           stk.put(0, 0u);

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
   bool probe_on = false;
 #ifdef MGPU_UTIL
   uint32_t u_node = 0, u_tri = 0, u_shade = 0, u_shade_lanes = 0;
+  uint32_t u_node_it = 0, u_tri_it = 0; // loop iterations inside NODE / TRI steps (one lane of the wave books each)
   unsigned long long cyc_node = 0, cyc_tri = 0, cyc_shade = 0, cyc_t0 = 0, cyc_s = 0;
   unsigned long long cyc_sub[6] = {0, 0, 0, 0, 0, 0};
 #define MGPU_TICK() (cyc_t0 = clock64())
@@ -196,6 +197,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
           constexpr bool kPlain = decltype(plain_tag)::value;
 #pragma unroll 1
           for (int rep = 0; rep < MGPU_NODES_PER_STEP; ++rep) {
+#ifdef MGPU_UTIL
+            if (lane == __ffsll((long long)__ballot(1)) - 1) u_node_it++;
+#endif
             const uint32_t ni = stk.get(sp);
             --sp;
             ++n_nodes;
@@ -248,6 +252,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
 #endif
 #pragma unroll 1
         for (int rep = 0; rep < MGPU_TRIS_PER_STEP; ++rep) {
+#ifdef MGPU_UTIL
+        if (lane == __ffsll((long long)__ballot(1)) - 1) u_tri_it++;
+#endif
         double2 a0, a1, a2, a3;
         double e2z;
         if (LDS_SCENE) {
@@ -543,8 +550,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
 #endif
           // arm the traversal of (org, dir): BVHAccel::Traverse prologue, bvh_accel.cc:774-802
           sx = dir.x < 0.0; sy = dir.y < 0.0; sz = dir.z < 0.0;
-          ix = 1.0 / dir.x; iy = 1.0 / dir.y; iz = 1.0 / dir.z; // no zero guard, as the reference
-          ray_plain = sc.boxes_ordered && ray_is_plain(org, ix, iy, iz);
+          const bool inv_ok = inverse_dir_w(dir, ix, iy, iz); // 1.0 / dir, no zero guard, as the reference
+          ray_plain = sc.boxes_ordered && inv_ok && origin_is_finite(org);
           bt = kDblMax; bu = 0.0; bv = 0.0; bslot = kNoHit;
           sp = 0;
           stk.put(0, 0u);
@@ -586,7 +593,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
 #ifdef MGPU_UTIL
   {
     unsigned long long a = u_node, b = u_tri, cc = u_shade, d = u_shade_lanes;
-    unsigned long long e_rays = n_rays - dry_rays, e_act = dry_active, e_plen = dry_plen;
+    unsigned long long e_rays = n_rays - dry_rays, e_act = dry_active, e_plen = dry_plen, it_n = u_node_it, it_t = u_tri_it;
     for (int off = 32; off; off >>= 1) {
       a += __shfl_down(a, off);
       b += __shfl_down(b, off);
@@ -595,12 +602,16 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
       e_rays += __shfl_down(e_rays, off);
       e_act += __shfl_down(e_act, off);
       e_plen += __shfl_down(e_plen, off);
+      it_n += __shfl_down(it_n, off);
+      it_t += __shfl_down(it_t, off);
     }
     if (lane == 0) {
       atomicAdd(&P.stats[kUtilNodeSteps], a);
       atomicAdd(&P.stats[kUtilTriSteps], b);
       atomicAdd(&P.stats[kUtilOuter], cc);
       atomicAdd(&P.stats[kUtilShadeLanes], d);
+      atomicAdd(&P.stats[kUtilNodeLanes], it_n); // wave-level iterations of the NODE / TRI inner loops
+      atomicAdd(&P.stats[kUtilTriLanes], it_t);
       atomicAdd(&P.stats[16], cyc_node);
       atomicAdd(&P.stats[17], cyc_tri);
       atomicAdd(&P.stats[18], cyc_shade);

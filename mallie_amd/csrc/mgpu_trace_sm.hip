@@ -259,8 +259,8 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
           org = v3(r->org[0], r->org[1], r->org[2]);
           dir = v3(r->dir[0], r->dir[1], r->dir[2]);
           sx = dir.x < 0.0; sy = dir.y < 0.0; sz = dir.z < 0.0;
-          ix = 1.0 / dir.x; iy = 1.0 / dir.y; iz = 1.0 / dir.z; // no zero guard, as the reference
-          ray_plain = sc.boxes_ordered && ray_is_plain(org, ix, iy, iz);
+          const bool inv_ok = inverse_dir_w(dir, ix, iy, iz); // 1.0 / dir, no zero guard, as the reference
+          ray_plain = sc.boxes_ordered && inv_ok && origin_is_finite(org);
           bt = kDblMax; bu = 0.0; bv = 0.0; bslot = kNoHit;
           sp = 0;
           stk.put(0, 0u);

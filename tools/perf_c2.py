@@ -24,6 +24,8 @@ if os.environ.get("UTIL"):
     ns, nl, ts_, tl, outer, trl, shl, genl = [int(x) for x in w[8:16]]
     print("  wave-level: outer iters %d (ideal %d, trace-lane util %.3f), node steps %d (lane util %.3f), tri steps %d (lane util %.3f), new paths/iter %.1f" % (
         outer, st["real_rays"] // 64, trl / max(1, 64 * outer), ns, st["nodes"] / max(1, 64 * ns), ts_, st["tris"] / max(1, 64 * ts_), genl / max(1, outer)))
+    print("  inner loops: NODE %d iterations (%.2f per step, %.1f of 64 lanes busy per iteration), TRI %d iterations (%.2f per step, %.1f lanes); SHADE steps %d with %.1f lanes" % (
+        nl, nl / max(1, ns), st["nodes"] / max(1, nl), tl, tl / max(1, ts_), st["tris"] / max(1, tl), outer, shl / max(1, outer)))
     print("  per outer iter: node steps %.2f (ideal %.2f)  tri steps %.2f (ideal %.2f)" % (ns / outer, st["nodes"] / 64 / outer, ts_ / outer, st["tris"] / 64 / outer))
     cn, ct, cs = [int(x) for x in w[16:19]]
     cb, nb = int(w[28]), int(w[29])
