@@ -146,6 +146,14 @@ __device__ __forceinline__ bool inverse_dir_w(V3 dir, double &ix, double &iy, do
   return ok;
 }
 
+// 1.0 / det of TriangleIsect (bvh_accel.cc:606) for a det that passed its epsilon test (|det| >= 2^-42, or NaN) as a wave
+// executes it: rcp_core when every active lane's |det| is below 2^400, the plain operator for all lanes otherwise
+// (a NaN fails the comparison and lands there too, so that its payload is the division's).
+__device__ __forceinline__ double inv_det_w(double det) {
+  if (__builtin_expect(__ballot(!(fabs(det) < 0x1p+400)) != 0ull, 0)) return 1.0 / det;
+  return rcp_core(det);
+}
+
 // ---- slab test ----------------------------------------------------------------------------------------------------
 // IntersectRayAABB (bvh_accel.cc:550-593) of the box {b0 = (min.x, min.y), b1 = (min.z, max.x), b2 = (max.y, max.z)}
 // (the node's first 48 bytes as three 16-byte loads) against a ray with inverse direction (ix, iy, iz) and direction

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
           const V3 p = cross(dir, e2);
           const double det = dot(e1, p);
           if (!(fabs(det) < kDblEps1024)) {
-            const double invDet = 1.0 / det;
+            const double invDet = inv_det_w(det); // 1.0 / det
             const V3 s = org - p0;
             const V3 q = cross(s, e1);
             const double u = dot(s, p) * invDet;
