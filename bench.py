@@ -204,8 +204,8 @@ def main():
                          "note": "achieved = algorithmic bytes (nodes*64 + tris*76 + rays*80, SURVEY 8(d)) / kernel time, "
                                  "priced against HBM peak as the contract asks. This scene's 92 KB BVH is staged in LDS, so "
                                  "those bytes are served on-chip (frac can exceed 1); measured HBM traffic is `traffic` "
-                                 "(radiance planes + frame, rocprofv3 PMC) = %s GB/s. The kernel is VALU-issue bound "
-                                 "(SQ_ACTIVE_INST_VALU 89%% of SIMD cycles, profiles/). HBM-resident scenes: DESIGN.md 7."
+                                 "(radiance planes + frame, rocprofv3 PMC) = %s GB/s. What bounds the kernel is VALU issue "
+                                 "(`valu.issue_busy_frac` of the SIMD issue slots, profiles/). HBM-resident scenes: DESIGN.md 7."
                                  % (round(traffic / (kernel_avg_ms * 1e-3) / 1e9, 1) if traffic else "n/a")},
         }
         sqc = valu_counters("k_render_sm") if world == 1 else None
