@@ -158,6 +158,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
   bool probe_on = false;
 #ifdef MGPU_UTIL
   uint32_t u_node = 0, u_tri = 0, u_shade = 0, u_shade_lanes = 0;
+  unsigned long long u_hist = 0;
   uint32_t u_node_it = 0, u_tri_it = 0; // loop iterations inside NODE / TRI steps (one lane of the wave books each)
   unsigned long long cyc_node = 0, cyc_tri = 0, cyc_shade = 0, cyc_t0 = 0, cyc_s = 0;
   unsigned long long cyc_sub[6] = {0, 0, 0, 0, 0, 0};
@@ -315,7 +316,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
       bool path_done = false, want_pixel = false;
       if (shade_lane) {
 #ifdef MGPU_UTIL
-        if (lane == __ffsll((long long)mS) - 1) { u_shade++; u_shade_lanes += (uint32_t)cS; }
+        if (lane == __ffsll((long long)mS) - 1) {
+          u_shade++;
+          u_shade_lanes += (uint32_t)cS;
+          // SHADE steps by lane count: < 16, 16..35 (both only when nothing else was runnable), 36..47, >= 48
+          u_hist += 1ull << (16 * (cS < 16 ? 0 : cS < 36 ? 1 : cS < 48 ? 2 : 3)); // four 16-bit counters per lane
+        }
 #endif
 #ifdef MGPU_UTIL
         cyc_s = clock64();
@@ -596,6 +602,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
     atomicAdd(&P.stats[kStatPaths], v4);
   }
 #ifdef MGPU_UTIL
+  if (u_hist)
+    for (int k = 0; k < 4; ++k)
+      if ((u_hist >> (16 * k)) & 0xffffull) atomicAdd(&P.stats[28 + k], (u_hist >> (16 * k)) & 0xffffull);
   {
     unsigned long long a = u_node, b = u_tri, cc = u_shade, d = u_shade_lanes;
     unsigned long long e_rays = n_rays - dry_rays, e_act = dry_active, e_plen = dry_plen, it_n = u_node_it, it_t = u_tri_it;

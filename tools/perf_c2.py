@@ -28,7 +28,10 @@ if os.environ.get("UTIL"):
         nl, nl / max(1, ns), st["nodes"] / max(1, nl), tl, tl / max(1, ts_), st["tris"] / max(1, tl), outer, shl / max(1, outer)))
     print("  per outer iter: node steps %.2f (ideal %.2f)  tri steps %.2f (ideal %.2f)" % (ns / outer, st["nodes"] / 64 / outer, ts_ / outer, st["tris"] / 64 / outer))
     cn, ct, cs = [int(x) for x in w[16:19]]
-    cb, nb = int(w[28]), int(w[29])
+    cb, nb = 0, 0
+    hb = [int(x) for x in w[28:32]]
+    if sum(hb):
+        print("  SHADE steps by lanes waiting: <16: %.1f%%  16-35: %.1f%%  36-47: %.1f%%  >=48: %.1f%%" % tuple(100.0 * h / sum(hb) for h in hb))
     if cb:
         print("  bounce: %d steps, %.0f cyc/step, share of all body cycles %.1f%%" % (nb, cb / max(1, nb), 100.0 * cb / (cn + ct + cs + cb)))
     if cn:
