@@ -99,6 +99,15 @@ def cpu_baseline(frame, plane, mpl, gpu_frame=None):
                                                                       1e3 * dt / spp_sample))
 
 
+def flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except (OSError, AttributeError):
+        pass
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,8 +138,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # debugging aid: MALLIE_FORCE_GATHER=1 sends a single-GPU run through the N > 1 code path (RCCL gather of the one
+    # rank's strips + re-interleave), to price that machinery without a second GPU
+    force_gather = world == 1 and bool(os.environ.get("MALLIE_FORCE_GATHER"))
+    if world > 1 or force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     W, H = WORKLOAD["width"], WORKLOAD["height"]
@@ -140,7 +153,8 @@ def main():
     frame = M.camera_frame(WORKLOAD["eye"], WORKLOAD["lookat"], width=W, height=H)
     plane = scene.plane() if WORKLOAD["plane"] else None
     fif = args.frames_in_flight if args.frames_in_flight > 0 else (1 if world == 1 else 3)
-    fr = FrameRenderer(scene, frame, W, H, mpl, spp, plane, WORKLOAD["seed"], rank, world, dev, frames_in_flight=fif)
+    fr = FrameRenderer(scene, frame, W, H, mpl, spp, plane, WORKLOAD["seed"], rank, world, dev, frames_in_flight=fif,
+                       force_collective=force_gather)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -151,6 +165,7 @@ def main():
     for _ in range(args.warmup):
         fr.render()
     sync_all()
+    flush_c_stdio()  # the communicators exist by now: whatever RCCL had to say goes out before the measurement
     scene.stats_read(reset=True)
     scene.timing_enable(True)
     t0 = time.perf_counter()
@@ -219,10 +234,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             gpu_frame = fr.frame_buffer.detach().cpu().numpy()  # the last timed frame (pass_base 0), after the timed region
             out["cpu_baseline"] = cpu_baseline(frame, plane, mpl, gpu_frame)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    else:
+        out = None
+    if world > 1 or force_gather:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
+    # RCCL prints a version banner through C stdio, which sits in libc's buffer when stdout is a pipe and would otherwise
+    # come out at process exit, AFTER the result: flush it first, on every rank, so that the JSON line is the last line
+    flush_c_stdio()
+    if out is not None:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

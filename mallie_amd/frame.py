@@ -37,10 +37,13 @@ class FrameRenderer:
     """
 
     def __init__(self, scene, frame, W, H, maxPathLength, passes, plane=None, seed=1, rank=0, world=1, device=None,
-                 strip_h=STRIP_H, render_local=None, tonemap_local=None, frames_in_flight=1):
+                 strip_h=STRIP_H, render_local=None, tonemap_local=None, frames_in_flight=1, force_collective=False):
         """render_local(rows, out, pass_base): optional replacement for the device renderer -- fills out[:len(rows)]
         (float32, len(rows) x W x 3) for the given frame rows.  Used by the CPU (gloo) tests of the partition/gather
         logic, where `device` is torch.device("cpu"); the product path leaves it None and renders through the C ABI."""
+        # force_collective: run the gather and the re-interleaving even with world == 1 (needs an initialised process
+        # group): lets ONE GPU exercise the N > 1 code path -- RCCL on side streams, frames in flight -- end to end
+        self.collective = world > 1 or force_collective
         self.render_local = render_local
         self.tonemap_local = tonemap_local  # (float strips, passes, mode, out u8) -> None; CPU tests only
         self._ldr = {}                      # per display mode: local / gathered / assembled 8-bit buffers
@@ -58,7 +61,7 @@ class FrameRenderer:
         if frames_in_flight < 1:
             raise ValueError("frames_in_flight must be >= 1")
         self.frames_in_flight = frames_in_flight
-        if world > 1 and rank == 0:
+        if self.collective and rank == 0:
             # frame row y lives at slab row perm[y] = owner(y) * max_rows + local index of y at its owner
             perm = np.empty(H, np.int64)
             for r in range(world):
@@ -73,7 +76,7 @@ class FrameRenderer:
             # local strips, padded to the largest share so the gather is uniform
             sl.local = torch.zeros((self.max_rows, W, 3), dtype=torch.float32, device=self.device)
             sl.slab, sl.gathered = None, None
-            if world > 1:
+            if self.collective:
                 if rank == 0:
                     # one contiguous landing area [world, max_rows, W, 3]; rank r's padded strips arrive in slab r
                     sl.slab = torch.empty((world, self.max_rows, W, 3), dtype=torch.float32, device=self.device)
@@ -123,7 +126,7 @@ class FrameRenderer:
             sl.stream.wait_stream(torch.cuda.current_stream(self.device))  # whatever the caller enqueued comes first
         with (torch.cuda.stream(sl.stream) if sl.stream is not None else contextlib.nullcontext()):
             self._render_strips(pass_base)
-            if self.world > 1:
+            if self.collective:
                 # collectives are issued in frame order on every rank; RCCL runs them on its own stream, ordered after
                 # this frame's kernel and before whatever this slot's stream does next
                 dist.gather(self.local, self.gathered if self.rank == 0 else None, dst=0)
@@ -139,11 +142,11 @@ class FrameRenderer:
         ch = 3 if mode == mgpu.TONEMAP_LINEAR_RGB8 else 4
         b = dict(ch=ch, local=torch.zeros((self.max_rows, self.W, ch), dtype=torch.uint8, device=self.device),
                  count=torch.full((self.max_rows, self.W), self.passes, dtype=torch.int32, device=self.device))
-        if self.world > 1 and self.rank == 0:
+        if self.collective and self.rank == 0:
             b["slab"] = torch.empty((self.world, self.max_rows, self.W, ch), dtype=torch.uint8, device=self.device)
             b["gathered"] = list(b["slab"].unbind(0))
             b["frame"] = torch.empty((self.H, self.W, ch), dtype=torch.uint8, device=self.device)
-        elif self.world == 1:
+        elif not self.collective:
             b["frame"] = b["local"]
         self._ldr[mode] = b
         return b
@@ -171,7 +174,7 @@ class FrameRenderer:
                 mgpu.tonemap_device(self.local.data_ptr(), b["count"].data_ptr(), self.n_rows * self.W, mode,
                                     b["local"].data_ptr(), device=self.device.index or 0, stream=stream)
         # 3. one gather of 8-bit strips, re-interleaved on rank 0
-        if self.world > 1:
+        if self.collective:
             dist.gather(b["local"], b["gathered"] if self.rank == 0 else None, dst=0)
             if self.rank == 0:
                 torch.index_select(b["slab"].view(self.world * self.max_rows, self.W, b["ch"]), 0, self.perm, out=b["frame"])

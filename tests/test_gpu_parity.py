@@ -2,11 +2,15 @@
  (1) the committed reference goldens and (2) the oracle on the same seeded inputs.  Bit-exact for everything that is
 IEEE arithmetic (trace records, images); the image tolerance north_star allows (1e-4 per-pixel L2) is only a fallback
 that is reported, never silently used: see test_render_* for the exact criterion."""
+import os
+
 import numpy as np
 import pytest
 
 import mallie_amd as M
 import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -658,6 +662,49 @@ def test_frames_in_flight_on_several_streams():
         orefs.append(img)
     for k, buf in enumerate(bufs):
         assert buf.cpu().numpy().tobytes() == orefs[k % 2].tobytes(), k
+
+
+def test_rccl_gather_path_with_frames_in_flight_on_one_gpu():
+    """bench.py's N > 1 code path end to end on ONE GPU: a world-size-1 RCCL process group, FrameRenderer forced through
+    its gather + re-interleave (force_collective) with three frames in flight on three streams.  What the multi-GPU run
+    adds on top is only more peers in the same gather (covered with gloo on CPU).  Run in a subprocess: the process
+    group must not leak into the other tests."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29591"
+import numpy as np, torch, torch.distributed as dist
+import mallie_amd as M, oracle_lib as O
+from mallie_amd.frame import FrameRenderer
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+g = O.load_golden("cornell_obj")
+sc = M.Scene(g["verts"], g["faces"], g["matIDs"], g["normals"] if g["has_normals"] else None, None)
+W, H, mpl, passes = 320, 200, 5, 4
+frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+one = FrameRenderer(sc, frame, W, H, mpl, passes, sc.plane(), 5, 0, 1, dev)
+refs = []
+for k in range(5):
+    refs.append(one.render(pass_base=4 * k).clone()); torch.cuda.synchronize()
+fr = FrameRenderer(sc, frame, W, H, mpl, passes, sc.plane(), 5, 0, 1, dev, frames_in_flight=3, force_collective=True)
+for rep in range(3):
+    outs = []
+    for k in range(5):
+        out = fr.render(pass_base=4 * k)
+        if k >= 2:  # frames 0 and 1 are overwritten by frames 3 and 4: read each frame before its buffers come round again
+            fr.wait(); torch.cuda.synchronize()
+        outs.append(out.clone() if k >= 2 else None)
+    for k in range(2, 5):
+        assert torch.equal(outs[k], refs[k]), (rep, k)
+ldr = fr.render_ldr(M.TONEMAP_GAMMA22_BGRA8); torch.cuda.synchronize()
+assert ldr.shape == (H, W, 4)
+dist.barrier(device_ids=[0]); dist.destroy_process_group()
+print("RCCL_PATH_OK")
+""" % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 @pytest.mark.parametrize("strip_h,parts", [(5, 3), (8, 2), (13, 4), (1, 2)])
