@@ -38,10 +38,13 @@ namespace mgpu {
 enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 
 
-#ifndef MGPU_NODE_WEIGHT
-#define MGPU_NODE_WEIGHT 4 // NODE runs when cN * MGPU_NODE_WEIGHT >= cT * MGPU_TRI_WEIGHT (measured: 1:1 6.72, 2:1 6.66,
-                           // 4:1 6.58, 8:1 6.58, 64:1 6.80 ms on C2; teapot and the 1M grid do not care)
-#define MGPU_TRI_WEIGHT 1
+// NODE runs when cN * weight >= cT.  BVH in LDS (C2): 1 -> 6.72, 2 -> 6.66, 4 -> 6.58, 8 -> 6.58, 64 -> 6.80 ms.  BVH in
+// HBM: 1 -> 22.9 / 6.63 ms (teapot / 1M grid), 4 -> 23.3 / 6.91, 16 -> 24.3 / 7.44.
+#ifndef MGPU_NODE_WEIGHT_LDS
+#define MGPU_NODE_WEIGHT_LDS 4
+#endif
+#ifndef MGPU_NODE_WEIGHT_HBM
+#define MGPU_NODE_WEIGHT_HBM 1
 #endif
 #ifndef MGPU_SHADE_MIN
 #define MGPU_SHADE_MIN 36
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
     // Scheduling rule: SHADE is by far the most expensive body (fp64 sqrt/div/acos/sin/cos), so it runs only when at
     // least MGPU_SHADE_MIN lanes wait for it or nothing else is runnable; otherwise the fuller of NODE / TRI runs.
     const bool run_shade = (cS >= MGPU_SHADE_MIN) || (cN == 0 && cT == 0);
-    if (!run_shade && cN * MGPU_NODE_WEIGHT >= cT * MGPU_TRI_WEIGHT) {
+    if (!run_shade && cN * (LDS_SCENE ? MGPU_NODE_WEIGHT_LDS : MGPU_NODE_WEIGHT_HBM) >= cT) {
       // ================================ NODE step ================================
       MGPU_TICK();
       const bool all_plain = __ballot(st == ST_NODE && !ray_plain) == 0ull; // wave-uniform
