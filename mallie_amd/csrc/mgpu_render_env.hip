@@ -93,7 +93,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
     const int cN = __popcll(mN), cT = __popcll(mT), cS = __popcll(mS);
     if ((cN | cT | cS) == 0) break;
     const bool run_shade = (cS >= MGPU_ENV_SHADE_MIN) || (cN == 0 && cT == 0);
-    if (!run_shade && cN * MGPU_ENV_NODE_WEIGHT >= cT) {
+    if (!run_shade && cN * (LDS_SCENE ? MGPU_ENV_NODE_WEIGHT : 1) >= cT) { // BVH in HBM: plain majority, as k_render_sm
       // ================================ NODE step ================================
       const bool all_plain = __ballot(st == ES_NODE && !ray_plain) == 0ull; // wave-uniform
       if (st == ES_NODE) {
