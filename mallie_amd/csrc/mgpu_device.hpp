@@ -280,7 +280,9 @@ __device__ __forceinline__ void traverse(const DScene &sc, const Stack<CAP, OVF>
       const double2 b0 = *reinterpret_cast<const double2 *>(&nd->bmin[0]); // bmin.x bmin.y
       const double2 b1 = *reinterpret_cast<const double2 *>(&nd->bmin[2]); // bmin.z bmax.x
       const double2 b2 = *reinterpret_cast<const double2 *>(&nd->bmax[1]); // bmax.y bmax.z
-      const int4 meta = *reinterpret_cast<const int4 *>(&nd->flag);        // flag axis data0 data1
+      int4 meta = *reinterpret_cast<const int4 *>(&nd->flag);              // flag axis data0 data1
+      // issued with the three loads above (same 64-byte node), not sunk into the hit branch as a second dependent load
+      asm volatile("" : "+v"(meta.x), "+v"(meta.y), "+v"(meta.z), "+v"(meta.w));
       // IntersectRayAABB, bvh_accel.cc:550-593
       const double nx = sx ? b1.y : b0.x, fx = sx ? b0.x : b1.y;
       const double ny = sy ? b2.x : b0.y, fy = sy ? b0.y : b2.x;

@@ -95,7 +95,10 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
             const double2 b0 = *reinterpret_cast<const double2 *>(&nd->bmin[0]);
             const double2 b1 = *reinterpret_cast<const double2 *>(&nd->bmin[2]);
             const double2 b2 = *reinterpret_cast<const double2 *>(&nd->bmax[1]);
-            const int4 meta = *reinterpret_cast<const int4 *>(&nd->flag);
+            int4 meta = *reinterpret_cast<const int4 *>(&nd->flag);
+            // keep this load next to the other three (same 64-byte node): the compiler otherwise sinks it into the hit
+            // branch, where it is a second dependent trip to L1/L2 per visited node
+            asm volatile("" : "+v"(meta.x), "+v"(meta.y), "+v"(meta.z), "+v"(meta.w));
             const bool hit = slab_hit<kPlain>(b0, b1, b2, org, ix, iy, iz, sx, sy, sz, bt); // IntersectRayAABB
             if (hit) {
               if (meta.x == 0) {
