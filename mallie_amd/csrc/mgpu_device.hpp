@@ -130,7 +130,7 @@ __device__ __forceinline__ V3 normalized_w(V3 a) {
 }
 // invDir of BVHAccel::Traverse (bvh_accel.cc:774-802: 1.0 / dir, no zero guard) as a wave executes it.  Returns whether
 // all three inverses of this lane came out with 2^-400 < |1/d| < 2^400 -- which implies that the operands were inside
-// rcp_core's range, and is the inverse-direction half of ray_is_plain.  One lane outside sends the wave through the
+// rcp_core's range, and is the inverse-direction half of a "plain" ray (slab_hit).  One lane outside sends the wave through the
 // plain operator.
 __device__ __forceinline__ bool inverse_dir_w(V3 dir, double &ix, double &iy, double &iz) {
   ix = rcp_core(dir.x);
@@ -160,7 +160,7 @@ __device__ __forceinline__ double inv_det_w(double det) {
 // signs (sx, sy, sz), current best t `bt`.
 // kPlain = false is the literal form: near / far plane picked by the direction sign, `(a > b) ? a : b` selects (they
 // keep the SECOND operand when a NaN is involved, which v_max_f64 would not).
-// kPlain = true is for rays with ray_is_plain() in a tree with DScene::boxes_ordered: no product can be a NaN, and
+// kPlain = true is for plain rays (inverse_dir_w() true and origin_is_finite()) in a tree with DScene::boxes_ordered: no product can be a NaN, and
 // with bmin <= bmax and a finite non-zero inverse the near plane's product is the smaller of the two (rounding is
 // monotonic), so the selects collapse to v_min_f64 / v_max_f64.  The values equal the literal form's up to the sign
 // of a zero, which none of the three comparisons can see: 25 instead of 39 VALU instructions per box.
@@ -188,14 +188,11 @@ __device__ __forceinline__ bool slab_hit(double2 b0, double2 b1, double2 b2, V3 
   }
   return (tmax > 0.0) && (tmin <= tmax) && (tmin <= bt);
 }
-// 1/d finite and non-zero on every axis and a finite origin: (b - o) * inv is then never NaN (an overflowed difference
-// gives +-inf), and sign(inv) is the direction sign the literal form selects by.
+// A ray is "plain" when inverse_dir_w() returned true (1/d finite, non-zero, far from the ends of the exponent range on
+// every axis) and its origin is finite: (b - o) * inv is then never NaN (an overflowed difference gives +-inf), and
+// sign(inv) is the direction sign the literal form selects by.
 __device__ __forceinline__ bool origin_is_finite(V3 org) {
   return __builtin_isfinite(org.x) && __builtin_isfinite(org.y) && __builtin_isfinite(org.z);
-}
-__device__ __forceinline__ bool ray_is_plain(V3 org, double ix, double iy, double iz) {
-  return __builtin_isfinite(ix) && ix != 0.0 && __builtin_isfinite(iy) && iy != 0.0 && __builtin_isfinite(iz) && iz != 0.0 &&
-         __builtin_isfinite(org.x) && __builtin_isfinite(org.y) && __builtin_isfinite(org.z);
 }
 
 // ---- RNG ----------------------------------------------------------------------------------------------------------

@@ -11,8 +11,6 @@ namespace mgpu {
 constexpr int kBlock = 256;      // 4 waves per workgroup
 constexpr int kChunkTiles = 2;   // k_render v1: 8x8-pixel tiles handed to a wave per global-counter fetch
 constexpr int kShards = 8;       // k_render_sm: work counters per launch = XCDs of an MI355X
-constexpr int kChunkItemsLds = 2; // k_render_sm: (tile, pass) items of 64 eye paths per counter fetch, BVH in LDS ...
-constexpr int kChunkItemsHbm = 4; // ... and BVH in HBM (measured optima: 9.19 vs 9.58 ms on C2, 9.20 vs 9.90 ms on the 1M grid)
 
 // device-side statistics words (unsigned long long each)
 enum : int { kStatTraceCalls = 0, kStatRays = 1, kStatNodes = 2, kStatTris = 3, kStatPaths = 4,
