@@ -424,28 +424,44 @@ int mgpu_trace_device(MgpuScene *s, const MgpuRay *d_rays, size_t n, MgpuInterse
   hipStream_t st = (hipStream_t)stream;
   // kernel choice: "sm" = persistent wave-scheduled traversal (k_trace_sm), "v1" = one ray per lane to completion
   // (k_trace; also used for batches too small to fill the persistent grid or too large for 32-bit ray indices)
+  // From 262 144 rays up the choice is made on the device: k_trace_probe looks at the batch's coherence, both kernels are
+  // enqueued and the one that was not chosen returns at its first instruction (no host round trip).
   bool use_sm = n >= 16384 && n < 0xF0000000ull;
+  bool use_v1 = !use_sm;
+  bool probe = n >= 262144 && n < 0xF0000000ull;
   if (const char *e = getenv("MGPU_TRACE_KERNEL")) {
+    probe = false;
     if (!strcmp(e, "v1")) use_sm = false;
     else if (!strcmp(e, "sm")) use_sm = n < 0xF0000000ull;
-    else return fail(MGPU_ERR_INVALID, "MGPU_TRACE_KERNEL=%s (expected v1|sm)", e);
+    else if (!strcmp(e, "auto")) probe = n >= 64 * 128 && n < 0xF0000000ull;
+    else return fail(MGPU_ERR_INVALID, "MGPU_TRACE_KERNEL=%s (expected v1|sm|auto)", e);
+    use_v1 = !use_sm;
   }
-  size_t blocks = (n + kBlock - 1) / kBlock;
-  size_t resident = (size_t)s->num_cu * (use_sm ? 4 : 8); // sm: 16 waves per CU; v1: the waves walk the array in grid strides
-  if (const char *e = getenv("MGPU_TRACE_BLOCKS_PER_CU")) resident = (size_t)s->num_cu * (size_t)(atoi(e) < 1 ? 1 : atoi(e));
-  if (blocks > resident) blocks = resident;
-  rc = ensure_overflow(s, blocks * kBlock);
+  if (probe) use_sm = use_v1 = true;
+  const size_t all_blocks = (n + kBlock - 1) / kBlock;
+  size_t blocks_sm = all_blocks, blocks_v1 = all_blocks;
+  size_t res_sm = (size_t)s->num_cu * 4, res_v1 = (size_t)s->num_cu * 8; // sm: 16 waves per CU; v1: grid-stride waves
+  if (const char *e = getenv("MGPU_TRACE_BLOCKS_PER_CU")) res_sm = res_v1 = (size_t)s->num_cu * (size_t)(atoi(e) < 1 ? 1 : atoi(e));
+  if (blocks_sm > res_sm) blocks_sm = res_sm;
+  if (blocks_v1 > res_v1) blocks_v1 = res_v1;
+  rc = ensure_overflow(s, (blocks_v1 > blocks_sm ? blocks_v1 : blocks_sm) * kBlock);
   if (rc) return rc;
-  uint32_t *counter = s->p_counters + (size_t)(s->launch_seq++ % kCounterRing) * kShards;
+  uint32_t *counter = s->p_counters + (size_t)(s->launch_seq++ % kCounterRing) * kShards; // word 0: sm's cursor, 1: select
+  uint32_t *select = probe ? counter + 1 : nullptr;
   if (use_sm) HIP_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), st));
   if (stats) {
     HIP_TRY(hipMemsetAsync(s->p_stats, 0, sizeof(unsigned long long) * kStatWords, st));
     HIP_TRY(hipEventRecord(s->ev0, st));
   }
-  if (use_sm) {
-    HIP_TRY(launch_trace_sm(s->cap, dim3((unsigned)blocks), st, s->d, d_rays, (uint32_t)n, d_out, d_hit, counter, s->p_stats));
-  } else {
-    launch_trace(s->cap, dim3((unsigned)blocks), st, s->d, d_rays, n, d_out, d_hit, s->p_stats);
+  if (probe) {
+    launch_trace_probe(st, d_rays, n, select);
+    HIP_TRY(hipGetLastError());
+  }
+  if (use_sm)
+    HIP_TRY(launch_trace_sm(s->cap, dim3((unsigned)blocks_sm), st, s->d, d_rays, (uint32_t)n, d_out, d_hit, counter, s->p_stats,
+                            select));
+  if (use_v1) {
+    launch_trace(s->cap, dim3((unsigned)blocks_v1), st, s->d, d_rays, n, d_out, d_hit, s->p_stats, select);
     HIP_TRY(hipGetLastError());
   }
   if (stats) {

@@ -49,8 +49,13 @@ struct RenderParams {
 constexpr int kProbeStride = 16; // org[3] dir[3] t hit slot normal[3] materialID pathLength throughput.x radiance.x
 
 // stack capacities (LDS entries per lane) the kernels are instantiated for
+// `select` (device word or null): when given, the kernel runs only if k_trace_probe wrote its own id there
+constexpr uint32_t kTraceSelectV1 = 0, kTraceSelectSm = 1;
 void launch_trace(int cap, dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, size_t n,
-                  MgpuIntersection *out, uint8_t *hit, unsigned long long *stats);
+                  MgpuIntersection *out, uint8_t *hit, unsigned long long *stats, const uint32_t *select);
+// k_trace_probe: samples 128 groups of 64 consecutive rays and writes kTraceSelectV1 to *select when at least three
+// quarters of them are coherent (every direction within ~14 degrees of the group's first), kTraceSelectSm otherwise
+void launch_trace_probe(hipStream_t s, const MgpuRay *rays, size_t n, uint32_t *select);
 void launch_render(int cap, dim3 grid, hipStream_t s, const DScene &sc, const RenderParams &p);
 int pick_stack_cap(int needed_entries);
 // wave-scheduled state-machine renderer (mgpu_render_sm.hip); shmem = stacks (+ scene when lds_scene)
@@ -76,7 +81,8 @@ struct EnvParams {
 hipError_t launch_render_env(int cap, bool lds_scene, dim3 grid, hipStream_t s, const DScene &sc, const EnvParams &p);
 // k_trace_sm (mgpu_trace_sm.hip): persistent, wave-scheduled batched trace; `counter` = one zeroed device word
 hipError_t launch_trace_sm(int cap, dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, uint32_t n,
-                           MgpuIntersection *out, uint8_t *hit, uint32_t *counter, unsigned long long *stats);
+                           MgpuIntersection *out, uint8_t *hit, uint32_t *counter, unsigned long long *stats,
+                           const uint32_t *select);
 void launch_accumulate(hipStream_t s, const float *planes, size_t plane_stride, int passes, size_t n_floats, float *image,
                        int32_t *count, bool resume);
 // tile_order[0..n) = tile indices by descending cost (256 log buckets); zeroes cost[]. One workgroup.

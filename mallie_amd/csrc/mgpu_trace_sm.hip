@@ -41,7 +41,9 @@ template <int CAP, bool OVF>
 __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const MgpuRay *__restrict__ rays, uint32_t n,
                                                             MgpuIntersection *__restrict__ out,
                                                             uint8_t *__restrict__ hit_out, uint32_t *work_counter,
-                                                            unsigned long long *__restrict__ stats) {
+                                                            unsigned long long *__restrict__ stats,
+                                                            const uint32_t *__restrict__ select) {
+  if (select && *select != kTraceSelectSm) return; // k_trace_probe chose the other kernel for this batch
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ unsigned long long s_cnt[3];
   uint32_t *s_stack = reinterpret_cast<uint32_t *>(smem); // [waves][CAP][64]
@@ -303,19 +305,21 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
 
 template <int CAP, bool OVF>
 static hipError_t launch_one(dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, uint32_t n,
-                             MgpuIntersection *out, uint8_t *hit, uint32_t *counter, unsigned long long *stats) {
+                             MgpuIntersection *out, uint8_t *hit, uint32_t *counter, unsigned long long *stats,
+                             const uint32_t *select) {
   const size_t shmem = (size_t)(kTraceBlock / 64) * (CAP * 64 * sizeof(uint32_t) + (16 * 23 + 16) * sizeof(unsigned long long));
-  hipLaunchKernelGGL((k_trace_sm<CAP, OVF>), grid, dim3(kTraceBlock), shmem, s, sc, rays, n, out, hit, counter, stats);
+  hipLaunchKernelGGL((k_trace_sm<CAP, OVF>), grid, dim3(kTraceBlock), shmem, s, sc, rays, n, out, hit, counter, stats, select);
   return hipGetLastError();
 }
 
 hipError_t launch_trace_sm(int cap, dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, uint32_t n,
-                           MgpuIntersection *out, uint8_t *hit, uint32_t *counter, unsigned long long *stats) {
+                           MgpuIntersection *out, uint8_t *hit, uint32_t *counter, unsigned long long *stats,
+                           const uint32_t *select) {
   const bool ovf = sc.overflow_cap != 0;
-  if (cap == 16 && !ovf) return launch_one<16, false>(grid, s, sc, rays, n, out, hit, counter, stats);
-  if (cap == 24 && !ovf) return launch_one<24, false>(grid, s, sc, rays, n, out, hit, counter, stats);
-  if (cap == 32 && !ovf) return launch_one<32, false>(grid, s, sc, rays, n, out, hit, counter, stats);
-  if (cap == 32 && ovf) return launch_one<32, true>(grid, s, sc, rays, n, out, hit, counter, stats);
+  if (cap == 16 && !ovf) return launch_one<16, false>(grid, s, sc, rays, n, out, hit, counter, stats, select);
+  if (cap == 24 && !ovf) return launch_one<24, false>(grid, s, sc, rays, n, out, hit, counter, stats, select);
+  if (cap == 32 && !ovf) return launch_one<32, false>(grid, s, sc, rays, n, out, hit, counter, stats, select);
+  if (cap == 32 && ovf) return launch_one<32, true>(grid, s, sc, rays, n, out, hit, counter, stats, select);
   return hipErrorInvalidConfiguration;
 }
 

@@ -49,11 +49,37 @@ def test_loaded_native_library_and_device():
     assert M.lib_path().endswith("libmallie_mgpu.so")
 
 
-@pytest.fixture(params=["v1", "sm"])
+@pytest.fixture(params=["v1", "sm", "auto"])
 def trace_kernel(request, monkeypatch):
-    """Both batched-trace kernels: k_trace (one ray per lane to completion) and k_trace_sm (persistent, wave-scheduled)."""
+    """Both batched-trace kernels: k_trace (one ray per lane to completion) and k_trace_sm (persistent, wave-scheduled);
+    "auto" = both enqueued behind k_trace_probe, which picks one on the device by the batch's coherence (what large
+    batches get by default; the switch lowers the threshold to 8 192 rays)."""
     monkeypatch.setenv("MGPU_TRACE_KERNEL", request.param)
     return request.param
+
+
+def test_trace_probe_picks_by_coherence_and_both_choices_agree(monkeypatch):
+    """300 000 camera rays in scanline order (coherent: the probe selects k_trace) and the same rays shuffled (incoherent:
+    k_trace_sm) must give the same records as either kernel forced, i.e. exactly one of the two enqueued kernels ran."""
+    sc = gpu_scene("cornell_obj")
+    W, H = 750, 400
+    frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    o, c, du, dv = frame[0:3], frame[3:6], frame[6:9], frame[9:12]
+    xs, ys = np.meshgrid(np.arange(W) + 0.5, np.arange(H) + 0.5)
+    d = c[None, :] + xs.reshape(-1, 1) * du[None, :] + ys.reshape(-1, 1) * dv[None, :] - o[None, :]
+    rays = np.hstack([np.tile(o, (W * H, 1)), d / np.linalg.norm(d, axis=1, keepdims=True)])
+    perm = np.random.default_rng(5).permutation(len(rays))
+    for batch, expect in ((rays, "v1"), (rays[perm], "sm")):
+        res = {}
+        for k in ("v1", "sm", None):  # None: the default = device-side choice from 262 144 rays up
+            if k is None:
+                monkeypatch.delenv("MGPU_TRACE_KERNEL", raising=False)
+            else:
+                monkeypatch.setenv("MGPU_TRACE_KERNEL", k)
+            out, hit, st = sc.trace(batch, want_stats=True)
+            res[k] = (out.tobytes(), hit.tobytes(), st["real_rays"], st["nodes"], st["tris"], st["kernel_ms"])
+        assert res[None][:5] == res["v1"][:5] == res["sm"][:5]
+        assert res[None][2] == len(batch)  # every ray traced exactly once: only one of the two kernels did work
 
 
 @pytest.mark.parametrize("name", ["cornell_obj", "cornell_eson", "teapot_obj"])
