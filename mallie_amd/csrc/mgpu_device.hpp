@@ -253,7 +253,10 @@ template <int CAP, bool OVF = true> struct Stack {
 template <int CAP, bool OVF>
 __device__ __forceinline__ void traverse(const DScene &sc, const Stack<CAP, OVF> &stk, V3 org, V3 dir, Hit &h, Counters &c) {
   const bool sx = dir.x < 0.0, sy = dir.y < 0.0, sz = dir.z < 0.0;
-  const double ix = 1.0 / dir.x, iy = 1.0 / dir.y, iz = 1.0 / dir.z; // no zero guard, as the reference
+  double ix, iy, iz;
+  const bool inv_ok = inverse_dir_w(dir, ix, iy, iz); // 1.0 / dir, no zero guard, as the reference
+  // wave-uniform: every active lane's ray may take the min/max form of the box test (slab_hit)
+  const bool all_plain = __ballot(!(sc.boxes_ordered && inv_ok && origin_is_finite(org))) == 0ull;
   h.t = kDblMax;
   h.u = 0.0;
   h.v = 0.0;
@@ -281,17 +284,8 @@ __device__ __forceinline__ void traverse(const DScene &sc, const Stack<CAP, OVF>
       // issued with the three loads above (same 64-byte node), not sunk into the hit branch as a second dependent load
       asm volatile("" : "+v"(meta.x), "+v"(meta.y), "+v"(meta.z), "+v"(meta.w));
       // IntersectRayAABB, bvh_accel.cc:550-593
-      const double nx = sx ? b1.y : b0.x, fx = sx ? b0.x : b1.y;
-      const double ny = sy ? b2.x : b0.y, fy = sy ? b0.y : b2.x;
-      const double nz = sz ? b2.y : b1.x, fz = sz ? b1.x : b2.y;
-      const double tmin_x = (nx - org.x) * ix, tmax_x = (fx - org.x) * ix;
-      const double tmin_y = (ny - org.y) * iy, tmax_y = (fy - org.y) * iy;
-      double tmin = (tmin_x > tmin_y) ? tmin_x : tmin_y;
-      double tmax = (tmax_x < tmax_y) ? tmax_x : tmax_y;
-      const double tmin_z = (nz - org.z) * iz, tmax_z = (fz - org.z) * iz;
-      tmin = (tmin > tmin_z) ? tmin : tmin_z;
-      tmax = (tmax < tmax_z) ? tmax : tmax_z;
-      const bool hit = (tmax > 0.0) && (tmin <= tmax) && (tmin <= h.t);
+      const bool hit = all_plain ? slab_hit<true>(b0, b1, b2, org, ix, iy, iz, sx, sy, sz, h.t)
+                                 : slab_hit<false>(b0, b1, b2, org, ix, iy, iz, sx, sy, sz, h.t);
       if (hit) {
         if (meta.x == 0) {
           const bool nearIsSecond = (meta.y == 0) ? sx : ((meta.y == 1) ? sy : sz); // dirSign[node.axis]
@@ -325,7 +319,7 @@ __device__ __forceinline__ void traverse(const DScene &sc, const Stack<CAP, OVF>
       const V3 p = cross(dir, e2);
       const double det = dot(e1, p);
       if (fabs(det) < kDblEps1024) continue;
-      const double invDet = 1.0 / det;
+      const double invDet = inv_det_w(det); // 1.0 / det
       const V3 s = org - p0;
       const V3 q = cross(s, e1);
       const double u = dot(s, p) * invDet;
