@@ -25,6 +25,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL across processes needs dmabuf IPC on these hosts (already exported on the GPU boxes; kept in case the launcher's
+# environment was rebuilt): must be set before the HIP runtime loads
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # algorithmic bytes per event: fp64 reference-layout node, pre-gathered fp64 triangle + face id,
 # ray in (org+dir) + hit out (t,u,v,id)
