@@ -142,7 +142,7 @@ int mgpu_render(MgpuScene *scene, const double origin[3], const double corner[3]
  * the scene keeps one set of launch scratch (pass planes, work counters, tile order) per stream, four sets at most; a
  * fifth stream re-uses the least recently used set behind an event, i.e. it is ordered after that set's last launch.
  * Keeping two or three frames in flight this way fills the drain of one persistent launch (its last paths finishing
- * on a mostly idle GPU) with the next frame's work: 7.13 -> 6.91 ms per C2 frame, 1.37 -> 1.08 ms per eighth of it.
+ * on a mostly idle GPU) with the next frame's work: 6.50 -> 6.32 ms per C2 frame, 1.28 -> 1.01 ms per eighth of it.
  * Calls for one scene must still come from one host thread at a time; a call with stats != NULL resets and reads the
  * scene's counters and should not overlap other launches. */
 int mgpu_render_strips_device(MgpuScene *scene, const double frame[12], int W, int H, int x0, int x1, int y_first,
