@@ -40,6 +40,17 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 
 // NODE runs when cN * weight >= cT.  BVH in LDS (C2): 1 -> 6.72, 2 -> 6.66, 4 -> 6.58, 8 -> 6.58, 64 -> 6.80 ms.  BVH in
 // HBM: 1 -> 22.9 / 6.63 ms (teapot / 1M grid), 4 -> 23.3 / 6.91, 16 -> 24.3 / 7.44.
+// Deferred path start: lanes whose path has ended take their next path only when at least MGPU_START_MIN of them ask
+// (or nobody in the wave is traversing); until then they stay parked in SHADE without a ray.  The path-start body (RNG
+// seeding, camera ray: ~150 instructions) then runs for more lanes at once.  Parked lanes do not count towards
+// MGPU_SHADE_MIN; MGPU_START_FORCE of them trigger a SHADE step on their own.  C2 6.47 -> 6.39 ms, an eighth of the
+// frame 1.27 -> 1.23, teapot 22.2 -> 21.7, 1M grid 6.22 -> 6.32 (0 / 65 switch it off).
+#ifndef MGPU_START_MIN
+#define MGPU_START_MIN 12
+#endif
+#ifndef MGPU_START_FORCE
+#define MGPU_START_FORCE 16
+#endif
 #ifndef MGPU_NODE_WEIGHT_LDS
 #define MGPU_NODE_WEIGHT_LDS 4
 #endif
@@ -189,9 +200,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
     if (cyc_dry) ++dry_steps;
 #endif
 
-    // Scheduling rule: SHADE is by far the most expensive body (fp64 sqrt/div/acos/sin/cos), so it runs only when at
-    // least MGPU_SHADE_MIN lanes wait for it or nothing else is runnable; otherwise the fuller of NODE / TRI runs.
-    const bool run_shade = (cS >= MGPU_SHADE_MIN) || (cN == 0 && cT == 0);
+    // Scheduling rule: SHADE is by far the most expensive body (fp64 sqrt/div/sincos), so it runs only when at least
+    // MGPU_SHADE_MIN lanes have a ray to finish, or MGPU_START_FORCE lanes are parked between paths, or nothing else is
+    // runnable; otherwise NODE runs unless TRI has several times more lanes waiting (MGPU_NODE_WEIGHT_*).
+    const int cReal = __popcll(__ballot(st == ST_SHADE && have_ray)); // lanes with a ray to finish (not parked between paths)
+    const bool run_shade = (cReal >= MGPU_SHADE_MIN) || (cN == 0 && cT == 0) || (cS - cReal >= MGPU_START_FORCE);
     if (!run_shade && cN * (LDS_SCENE ? MGPU_NODE_WEIGHT_LDS : MGPU_NODE_WEIGHT_HBM) >= cT) {
       // ================================ NODE step ================================
       MGPU_TICK();
@@ -444,9 +457,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
       cyc_sub[2] += clock64() - cyc_s; cyc_s = clock64();
 #endif
       // ---- (2) path hand-out, executed by the whole wave (cursor variables are wave-uniform) ----
+      // deferred start: with few lanes asking for a new path while others still traverse, the lanes stay parked (state
+      // SHADE, no ray) and the path-start body runs later for more of them at once
+      const bool defer = !exhausted && (cN + cT) > 0 && __popcll(__ballot(want_pixel)) < MGPU_START_MIN;
       for (;;) {
         const unsigned long long want = __ballot(want_pixel);
-        if (!want || exhausted) break;
+        if (!want || exhausted || defer) break;
         if (in_item >= 64) { // current item used up: take the next one from the workgroup's cursor
           uint32_t cur_shard = 0, item_local = 0;
           for (;;) {
@@ -560,7 +576,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
           path_done = false;
         }
         if (path_done) {
-          st = ST_IDLE; // the work counter is exhausted: this lane is finished
+          if (exhausted) st = ST_IDLE; // the work counter is exhausted: this lane is finished (else: parked, start deferred)
         } else {
 #ifdef MGPU_UTIL
           cyc_sub[4] += clock64() - cyc_s; cyc_s = clock64();
