@@ -17,6 +17,14 @@
 #include "mgpu_device.hpp"
 #include "mgpu_kernels.hpp"
 
+// deferred path start, as in k_render_sm (0 / 65: off 24.3 ms; 8 / 12: 24.1; 12 / 16: 23.6; 16 / 24: 23.9; 24 / 32: 25.5 on
+// the 2048x1024 stereo panorama)
+#ifndef MGPU_ENV_START_MIN
+#define MGPU_ENV_START_MIN 12
+#endif
+#ifndef MGPU_ENV_START_FORCE
+#define MGPU_ENV_START_FORCE 16
+#endif
 #ifndef MGPU_ENV_NODE_WEIGHT
 #define MGPU_ENV_NODE_WEIGHT 4 // NODE runs when cN * weight >= cT (1: 25.9, 2: 25.8, 4: 24.2 ms on the 2048x1024 stereo panorama)
 #endif
@@ -69,6 +77,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
   // per-lane pixel / path state
   int st = ES_SHADE;
   bool have_ray = false, have_pixel = false;
+  bool start_pending = false; // parked between two samples of its pixel: the next SHADE step it joins starts the path
   uint32_t lx = 0, ly = 0;
   int sample = 0;
   float acc = 0.0f;    // the pixel's running sum; R = G = B for this integrator
@@ -92,7 +101,9 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
     const unsigned long long mS = __ballot(st == ES_SHADE);
     const int cN = __popcll(mN), cT = __popcll(mT), cS = __popcll(mS);
     if ((cN | cT | cS) == 0) break;
-    const bool run_shade = (cS >= MGPU_ENV_SHADE_MIN) || (cN == 0 && cT == 0);
+    // lanes parked between paths (deferred start, see below) do not count towards the quorum; enough of them force a step
+    const int cReal = __popcll(__ballot(st == ES_SHADE && have_ray));
+    const bool run_shade = (cReal >= MGPU_ENV_SHADE_MIN) || (cN == 0 && cT == 0) || (cS - cReal >= MGPU_ENV_START_FORCE);
     if (!run_shade && cN * (LDS_SCENE ? MGPU_ENV_NODE_WEIGHT : 1) >= cT) { // BVH in HBM: plain majority, as k_render_sm
       // ================================ NODE step ================================
       const bool all_plain = __ballot(st == ES_NODE && !ray_plain) == 0ull; // wave-uniform
@@ -196,7 +207,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
       const bool shade_lane = (st == ES_SHADE);
       bool path_done = false;
       if (shade_lane) {
-        path_done = !have_ray && !have_pixel ? true : false; // a lane without a pixel asks for one below
+        path_done = start_pending || (!have_ray && !have_pixel); // parked before its next sample / asks for a pixel below
+        start_pending = false;
         if (have_ray) {
           // ---- the rest of one PathTraceEnv loop iteration (render.cc:541-585) ----
           const bool hit = bt < kDblMax; // bvh_accel.cc:838
@@ -255,11 +267,16 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
           }
         }
       }
+      // Deferred start: the prologue of a path (two sincos, the stereo rig: ~350 instructions) is worth running only for
+      // many lanes at once.  With fewer than MGPU_ENV_START_MIN lanes between paths while others still traverse, those
+      // lanes stay parked in SHADE without a ray and start together in a later step.
+      const bool restart = shade_lane && !have_ray && (path_done || !have_pixel);
+      const bool defer = (cN + cT) > 0 && __popcll(__ballot(restart)) < MGPU_ENV_START_MIN;
       // ---- pixel hand-out, executed by the whole wave (the cursor is wave-uniform) ----
       bool want = shade_lane && !have_pixel && !have_ray;
       for (;;) {
         const unsigned long long wm = __ballot(want);
-        if (!wm || exhausted) break;
+        if (!wm || exhausted || defer) break;
         if (in_tile >= 64) {
           uint32_t t = 0;
           if (lane == 0) t = atomicAdd(P.work_counter, 1u);
@@ -298,7 +315,9 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
       }
       // ---- next path / next traversal ----
       if (shade_lane) {
-        if (!have_pixel) {
+        if (restart && defer) {
+          start_pending = have_pixel; // stays in SHADE without a ray; resumes with the prologue (or asks for a pixel)
+        } else if (!have_pixel) {
           st = ES_IDLE; // no pixel left for this lane
         } else {
           if (path_done) {
