@@ -43,13 +43,16 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 // Deferred path start: lanes whose path has ended take their next path only when at least MGPU_START_MIN of them ask
 // (or nobody in the wave is traversing); until then they stay parked in SHADE without a ray.  The path-start body (RNG
 // seeding, camera ray: ~150 instructions) then runs for more lanes at once.  Parked lanes do not count towards
-// MGPU_SHADE_MIN; MGPU_START_FORCE of them trigger a SHADE step on their own.  C2 6.47 -> 6.39 ms, an eighth of the
-// frame 1.27 -> 1.23, teapot 22.2 -> 21.7, 1M grid 6.22 -> 6.32 (0 / 65 switch it off).
-#ifndef MGPU_START_MIN
-#define MGPU_START_MIN 12
+// MGPU_SHADE_MIN; MGPU_START_FORCE of them trigger a SHADE step on their own.  BVH in LDS: 12 / 16 (C2 6.47 -> 6.39 ms,
+// an eighth of the frame 1.27 -> 1.23; 0 / 65 switch it off).
+// BVH in HBM: 8 / 12 (teapot 22.1 -> 21.7 ms, 1M grid 6.21 -> 6.08, 10M grid 84.8 -> 85.1; 12 / 16: 21.6 / 6.22 / 86.6).
+#ifndef MGPU_START_MIN_LDS
+#define MGPU_START_MIN_LDS 12
+#define MGPU_START_FORCE_LDS 16
 #endif
-#ifndef MGPU_START_FORCE
-#define MGPU_START_FORCE 16
+#ifndef MGPU_START_MIN_HBM
+#define MGPU_START_MIN_HBM 8
+#define MGPU_START_FORCE_HBM 12
 #endif
 #ifndef MGPU_NODE_WEIGHT_LDS
 #define MGPU_NODE_WEIGHT_LDS 4
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
     // MGPU_SHADE_MIN lanes have a ray to finish, or MGPU_START_FORCE lanes are parked between paths, or nothing else is
     // runnable; otherwise NODE runs unless TRI has several times more lanes waiting (MGPU_NODE_WEIGHT_*).
     const int cReal = __popcll(__ballot(st == ST_SHADE && have_ray)); // lanes with a ray to finish (not parked between paths)
-    const bool run_shade = (cReal >= MGPU_SHADE_MIN) || (cN == 0 && cT == 0) || (cS - cReal >= MGPU_START_FORCE);
+    const bool run_shade = (cReal >= MGPU_SHADE_MIN) || (cN == 0 && cT == 0) || (cS - cReal >= (LDS_SCENE ? MGPU_START_FORCE_LDS : MGPU_START_FORCE_HBM));
     if (!run_shade && cN * (LDS_SCENE ? MGPU_NODE_WEIGHT_LDS : MGPU_NODE_WEIGHT_HBM) >= cT) {
       // ================================ NODE step ================================
       MGPU_TICK();
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
       // ---- (2) path hand-out, executed by the whole wave (cursor variables are wave-uniform) ----
       // deferred start: with few lanes asking for a new path while others still traverse, the lanes stay parked (state
       // SHADE, no ray) and the path-start body runs later for more of them at once
-      const bool defer = !exhausted && (cN + cT) > 0 && __popcll(__ballot(want_pixel)) < MGPU_START_MIN;
+      const bool defer = !exhausted && (cN + cT) > 0 && __popcll(__ballot(want_pixel)) < (LDS_SCENE ? MGPU_START_MIN_LDS : MGPU_START_MIN_HBM);
       for (;;) {
         const unsigned long long want = __ballot(want_pixel);
         if (!want || exhausted || defer) break;
