@@ -64,6 +64,8 @@ struct RenderSlot {
   unsigned order_age = 0;           // launches of this layout so far (the hand-out order is renewed every few)
   void *p_overflow = nullptr;       // HBM stack overflow columns (deep trees only)
   size_t overflow_lanes = 0;
+  void *p_woverflow = nullptr;      // the same for the wide traversal's far-child stack (16-byte entries)
+  size_t woverflow_lanes = 0;
 };
 
 struct MgpuScene {
@@ -77,8 +79,9 @@ struct MgpuScene {
   DScene d{};
   // owned device allocations
   void *p_nodes = nullptr, *p_tris = nullptr, *p_slotn = nullptr, *p_mat = nullptr, *p_verts = nullptr,
-       *p_faces = nullptr, *p_fvn = nullptr, *p_fvuv = nullptr, *p_overflow = nullptr;
-  size_t overflow_lanes = 0;
+       *p_faces = nullptr, *p_fvn = nullptr, *p_fvuv = nullptr, *p_overflow = nullptr, *p_wnodes = nullptr,
+       *p_woverflow = nullptr;
+  size_t overflow_lanes = 0, woverflow_lanes = 0;
   uint32_t *p_counters = nullptr;         // kCounterRing work counters
   unsigned long long *p_stats = nullptr;  // kStatWords
   unsigned launch_seq = 0;
@@ -148,6 +151,7 @@ int tree_depth(const MgpuNode *nodes, size_t nn, size_t nf, int *depth_out, bool
     } else {
       if ((size_t)n.data[1] + n.data[0] > nf)
         return fail(MGPU_ERR_INVALID, "leaf %u: range [%u,+%u) exceeds %zu faces", it.node, n.data[1], n.data[0], nf);
+      if (n.data[0] >= kWInterior) return fail(MGPU_ERR_INVALID, "leaf %u: %u triangles in one leaf", it.node, n.data[0]);
     }
   }
   *depth_out = depth;
@@ -179,6 +183,31 @@ int ensure_overflow(MgpuScene *s, size_t lanes) {
   }
   s->d.stack_overflow = (uint32_t *)s->p_overflow;
   s->d.overflow_cap = (uint32_t)extra;
+  return MGPU_OK;
+}
+
+// The same for the wide traversal (k_trace_sm, HBM-resident k_render_env): far-child entries beyond the LDS part.
+int ensure_woverflow(MgpuScene *s, size_t lanes) {
+  const int extra = s->tree_depth - kWideStackLds; // at most one far child per interior level
+  if (extra <= 0) {
+    s->d.wstack_overflow = nullptr;
+    s->d.woverflow_cap = 0;
+    return MGPU_OK;
+  }
+  if (lanes > s->woverflow_lanes) {
+    if (s->p_woverflow) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(s->p_woverflow));
+      s->device_bytes -= s->woverflow_lanes * (size_t)extra * sizeof(uint4);
+      s->p_woverflow = nullptr;
+      s->woverflow_lanes = 0;
+    }
+    int rc = dev_alloc(s, &s->p_woverflow, lanes * (size_t)extra * sizeof(uint4));
+    if (rc) return rc;
+    s->woverflow_lanes = lanes;
+  }
+  s->d.wstack_overflow = (uint4 *)s->p_woverflow;
+  s->d.woverflow_cap = (uint32_t)extra;
   return MGPU_OK;
 }
 
@@ -226,6 +255,29 @@ int slot_overflow(MgpuScene *s, RenderSlot &r, size_t lanes, DScene &d) {
   }
   d.stack_overflow = (uint32_t *)r.p_overflow;
   d.overflow_cap = (uint32_t)extra;
+  return MGPU_OK;
+}
+
+// The same for the wide traversal of the HBM-resident render kernel.
+int slot_woverflow(MgpuScene *s, RenderSlot &r, size_t lanes, DScene &d) {
+  const int extra = s->tree_depth - kWideStackLds;
+  d.wstack_overflow = nullptr;
+  d.woverflow_cap = 0;
+  if (extra <= 0) return MGPU_OK;
+  if (lanes > r.woverflow_lanes) {
+    if (r.p_woverflow) {
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipFree(r.p_woverflow));
+      s->device_bytes -= r.woverflow_lanes * (size_t)extra * sizeof(uint4);
+      r.p_woverflow = nullptr;
+      r.woverflow_lanes = 0;
+    }
+    int rc = dev_alloc(s, &r.p_woverflow, lanes * (size_t)extra * sizeof(uint4));
+    if (rc) return rc;
+    r.woverflow_lanes = lanes;
+  }
+  d.wstack_overflow = (uint4 *)r.p_woverflow;
+  d.woverflow_cap = (uint32_t)extra;
   return MGPU_OK;
 }
 
@@ -331,8 +383,10 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
     if (!lrc && matIDs) lrc = upload(s, &d_mat, matIDs, sizeof(uint32_t) * nf);
     if (!lrc) lrc = dev_alloc(s, &s->p_tris, sizeof(DTri) * nf);
     if (!lrc) lrc = dev_alloc(s, &s->p_slotn, sizeof(double) * (fv_normals ? 9 : 3) * nf);
+    if (!lrc) lrc = dev_alloc(s, &s->p_wnodes, sizeof(WNode) * (nn + 1));
     hipError_t e = hipSuccess;
     if (!lrc) {
+      launch_wide_layout(0, (const MgpuNode *)s->p_nodes, nn, (WNode *)s->p_wnodes);
       launch_scene_layout(0, (const double *)s->p_verts, (const uint32_t *)s->p_faces, (const uint32_t *)d_idx,
                           (const uint32_t *)d_mat, (const double *)s->p_fvn, nf, (DTri *)s->p_tris, (double *)s->p_slotn);
       e = hipGetLastError();
@@ -364,6 +418,10 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
     s->num_cu = prop.multiProcessorCount;
   }
   s->d.nodes = (const MgpuNode *)s->p_nodes;
+  s->d.wnodes = (const WNode *)s->p_wnodes;
+  s->d.wroot = (uint32_t)nn;
+  s->d.wstack_overflow = nullptr;
+  s->d.woverflow_cap = 0;
   s->d.tris = (const DTri *)s->p_tris;
   s->d.slot_normal = (const double *)s->p_slotn;
   s->d.mat_diffuse = (const double *)s->p_mat;
@@ -388,11 +446,12 @@ int mgpu_scene_destroy(MgpuScene *s) {
   (void)hipSetDevice(s->device);
   (void)hipDeviceSynchronize();
   void *ptrs[] = {s->p_nodes, s->p_tris, s->p_slotn, s->p_mat, s->p_verts, s->p_faces, s->p_fvn, s->p_fvuv,
-                  s->p_overflow, s->p_counters, s->p_stats, s->p_wave_log, s->p_host_img, s->p_trace};
+                  s->p_overflow, s->p_counters, s->p_stats, s->p_wave_log, s->p_host_img, s->p_trace, s->p_wnodes,
+                  s->p_woverflow};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (RenderSlot &r : s->slot) {
-    void *rp[] = {r.p_planes, r.p_tile_cost, r.p_tile_order, r.p_overflow};
+    void *rp[] = {r.p_planes, r.p_tile_cost, r.p_tile_order, r.p_overflow, r.p_woverflow};
     for (void *p : rp)
       if (p) (void)hipFree(p);
     if (r.done) (void)hipEventDestroy(r.done);
@@ -447,6 +506,8 @@ int mgpu_trace_device(MgpuScene *s, const MgpuRay *d_rays, size_t n, MgpuInterse
   if (blocks_v1 > res_v1) blocks_v1 = res_v1;
   rc = ensure_overflow(s, (blocks_v1 > blocks_sm ? blocks_v1 : blocks_sm) * kBlock);
   if (rc) return rc;
+  rc = ensure_woverflow(s, blocks_sm * kBlock);
+  if (rc) return rc;
   uint32_t *counter = s->p_counters + (size_t)(s->launch_seq++ % kCounterRing) * kShards; // word 0: sm's cursor, 1: select
   uint32_t *select = probe ? counter + 1 : nullptr;
   if (use_sm) HIP_TRY(hipMemsetAsync(counter, 0, sizeof(uint32_t), st));
@@ -459,7 +520,7 @@ int mgpu_trace_device(MgpuScene *s, const MgpuRay *d_rays, size_t n, MgpuInterse
     HIP_TRY(hipGetLastError());
   }
   if (use_sm)
-    HIP_TRY(launch_trace_sm(s->cap, dim3((unsigned)blocks_sm), st, s->d, d_rays, (uint32_t)n, d_out, d_hit, counter, s->p_stats,
+    HIP_TRY(launch_trace_sm(dim3((unsigned)blocks_sm), st, s->d, d_rays, (uint32_t)n, d_out, d_hit, counter, s->p_stats,
                             select));
   if (use_v1) {
     launch_trace(s->cap, dim3((unsigned)blocks_v1), st, s->d, d_rays, n, d_out, d_hit, s->p_stats, select);
@@ -590,6 +651,7 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
       shmem += scene_lds;
     }
   }
+  if (kern == 1) shmem = (size_t)(block / 64) * WStack<kWideStackLds>::kWaveBytes; // wide traversal: far-child stack
   int per_cu = kern == 2 ? 1 : (kern == 1 ? 4 : 2); // workgroups per CU: 16 waves per CU for the state-machine kernels
   if (const char *e = getenv("MGPU_RENDER_BLOCKS_PER_CU")) per_cu = atoi(e) < 1 ? 1 : atoi(e);
   // persistent grid: as many workgroups as stay resident, capped by the work available
@@ -605,6 +667,10 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   DScene dsc = s->d; // this launch's scene descriptor: the overflow columns are the slot's
   rc = slot_overflow(s, R, blocks * block, dsc);
   if (rc) return rc;
+  if (kern == 1) {
+    rc = slot_woverflow(s, R, blocks * block, dsc);
+    if (rc) return rc;
+  }
 
   RenderParams P;
   memcpy(P.frame, frame, sizeof(P.frame));

@@ -34,8 +34,29 @@ struct alignas(16) DTri {
 };
 static_assert(sizeof(DTri) == 80, "DTri must be 80 bytes (5 x 16B loads)");
 
+// One record per INTERIOR node of the reference tree, indexed by that node's index in BVHAccel::nodes_ (records of leaf
+// indices stay unused), plus a "super root" at index nn whose child 0 is the root: the boxes of BOTH children and what a
+// traversal needs to enter either of them, so that one 128-byte fetch decides both (see wide_node_step).
+//   box k   = child k's bmin[3], bmax[3] (the child node's first 48 bytes, verbatim)
+//   ref k   = interior child: its node index;  leaf child: first slot of its triangle run (BVHNode::data[1])
+//   tag k   = interior child: kWInterior;      leaf child: triangle count (BVHNode::data[0], < kWInterior)
+//   tag 0 additionally carries this node's split axis in its top two bits
+struct alignas(16) WNode {
+  double box0[6];
+  double box1[6];
+  uint32_t ref0, tag0, ref1, tag1;
+  uint32_t pad_[4];
+};
+static_assert(sizeof(WNode) == 128, "WNode must be 128 bytes (one L2 line)");
+constexpr uint32_t kWInterior = 0x3FFFFFFFu;
+constexpr uint32_t kWNone = 0xFFFFFFFFu;
+
 struct DScene {
   const MgpuNode *nodes;     // reference 64-byte layout, uploaded verbatim
+  const WNode *wnodes;       // nn + 1 wide records (k_wide_layout); record nn is the super root
+  uint32_t wroot;            // = nn
+  uint4 *wstack_overflow;    // wide traversal: far-child stack entries beyond the LDS part, per hardware lane slot
+  uint32_t woverflow_cap;    // entries per lane (0: the tree is shallow enough for the LDS part alone)
   const DTri *tris;          // nf entries, slot order
   const double *slot_normal; // slot order: 9 doubles (facevarying n0,n1,n2) or 3 doubles (geometric normal)
   const double *mat_diffuse; // 3*nm
@@ -165,9 +186,9 @@ __device__ __forceinline__ double inv_det_w(double det) {
 // monotonic), so the selects collapse to v_min_f64 / v_max_f64.  The values equal the literal form's up to the sign
 // of a zero, which none of the three comparisons can see: 25 instead of 39 VALU instructions per box.
 template <bool kPlain>
-__device__ __forceinline__ bool slab_hit(double2 b0, double2 b1, double2 b2, V3 org, double ix, double iy, double iz,
-                                         bool sx, bool sy, bool sz, double bt) {
-  double tmin, tmax;
+__device__ __forceinline__ bool slab_t(double2 b0, double2 b1, double2 b2, V3 org, double ix, double iy, double iz,
+                                       bool sx, bool sy, bool sz, double bt, double &tmin) {
+  double tmax;
   if (kPlain) {
     const double lx = (b0.x - org.x) * ix, hx = (b1.y - org.x) * ix;
     const double ly = (b0.y - org.y) * iy, hy = (b2.x - org.y) * iy;
@@ -187,6 +208,12 @@ __device__ __forceinline__ bool slab_hit(double2 b0, double2 b1, double2 b2, V3 
     tmax = (tmax < tmax_z) ? tmax : tmax_z;
   }
   return (tmax > 0.0) && (tmin <= tmax) && (tmin <= bt);
+}
+template <bool kPlain>
+__device__ __forceinline__ bool slab_hit(double2 b0, double2 b1, double2 b2, V3 org, double ix, double iy, double iz,
+                                         bool sx, bool sy, bool sz, double bt) {
+  double tmin;
+  return slab_t<kPlain>(b0, b1, b2, org, ix, iy, iz, sx, sy, sz, bt, tmin);
 }
 // A ray is "plain" when inverse_dir_w() returned true (1/d finite, non-zero, far from the ends of the exponent range on
 // every axis) and its origin is finite: (b - o) * inv is then never NaN (an overflowed difference gives +-inf), and
@@ -245,6 +272,129 @@ template <int CAP, bool OVF = true> struct Stack {
     return v;
   }
 };
+
+// ---- wide traversal (BVH in HBM) ------------------------------------------------------------------------------------
+// BVHAccel::Traverse (bvh_accel.cc:805-834) pops a node, tests ITS box against the best t so far, and on a hit pushes the
+// far child, then the near child.  A visited node costs one dependent fetch that way, and with the tree in HBM the walk
+// is a chain of such fetches.  The wide form fetches an interior node's WNode record instead -- both children's boxes in
+// one 128-byte line -- and decides both at once:
+//   * the near child is what the reference pops next, with an unchanged best t: it is tested now and, when hit, entered
+//     directly (leaf: its triangle run is in the record, the leaf's own node is never fetched);
+//   * the far child's test reads `tmax > 0 && tmin <= tmax && tmin <= best`.  Only the last clause can change until the
+//     reference pops it, and `best` only shrinks: the child goes on the stack with its exact tmin iff it passes now, and
+//     `tmin <= best` is asked again when it is popped.  Same accept / reject decisions, same order.
+// The reference pops (and counts) every pushed node; both children of every entered interior node are pushed there, so
+// nodes visited = 1 + 2 * (interior nodes entered) -- counted here as 2 per record, less 1 for the super root's dummy.
+// The stack holds far children only: at most one per interior level, in practice < 8 (tools/wide_proto.c: 99 % of the
+// rays of the 1M-triangle grid never hold more than 6).  K entries of {ref, tag, tmin} per lane live in LDS
+// (entry-major, lane-minor: conflict-free), deeper ones in the lane's HBM column.
+template <int K> struct WStack {
+  __attribute__((address_space(3))) unsigned long long *rt; // &s_rt[wave][0][lane]: ref | tag << 32
+  __attribute__((address_space(3))) double *tm; // &s_tm[wave][0][lane]
+  uint4 *overflow;                              // this lane's column, entries K.. (null when the tree is shallow)
+  __device__ __forceinline__ void put(int i, uint32_t ref, uint32_t tag, double t) const {
+    if (i < K) {
+      rt[i * 64] = (unsigned long long)ref | ((unsigned long long)tag << 32);
+      tm[i * 64] = t;
+    } else {
+      const unsigned long long tb = (unsigned long long)__double_as_longlong(t);
+      overflow[i - K] = make_uint4(ref, tag, (uint32_t)tb, (uint32_t)(tb >> 32));
+    }
+  }
+  __device__ __forceinline__ void get(int i, uint32_t &ref, uint32_t &tag, double &t) const {
+    if (i < K) {
+      const unsigned long long a = rt[i * 64];
+      ref = (uint32_t)a;
+      tag = (uint32_t)(a >> 32);
+      t = tm[i * 64];
+    } else {
+      const uint4 a = overflow[i - K];
+      ref = a.x;
+      tag = a.y;
+      t = __longlong_as_double((long long)(((unsigned long long)a.w << 32) | (unsigned long long)a.z));
+    }
+  }
+  // bytes of LDS per wave
+  static constexpr size_t kWaveBytes = (size_t)K * 64 * (sizeof(unsigned long long) + sizeof(double));
+  __device__ __forceinline__ void bind(unsigned char *wave_base, int lane) {
+    rt = (__attribute__((address_space(3))) unsigned long long *)(wave_base) + lane;
+    tm = (__attribute__((address_space(3))) double *)(wave_base + (size_t)K * 64 * sizeof(unsigned long long)) + lane;
+  }
+};
+
+enum : int { WT_NODE = 0, WT_TRI = 1, WT_DONE = 2 };
+
+// Up to REPS interior nodes for the calling lane.  `cur` = record to enter next (kWNone: take one from the stack), `sp` =
+// entries on the stack.  Returns WT_TRI with [tri_cur, tri_end) set when a leaf was opened, WT_DONE when the stack ran
+// empty, WT_NODE when the repetitions are used up.  n_nodes += 2 per record entered.
+template <bool kPlain, int REPS, int K>
+__device__ __forceinline__ int wide_node_step(const WNode *__restrict__ wn, const WStack<K> &stk, V3 org, double ix,
+                                              double iy, double iz, bool sx, bool sy, bool sz, double bt, uint32_t &cur,
+                                              int &sp, uint32_t &tri_cur, uint32_t &tri_end, uint32_t &n_nodes) {
+  int res = WT_NODE;
+#pragma unroll 1
+  for (int rep = 0; rep < REPS; ++rep) {
+    if (cur == kWNone) {
+      // next far child whose tmin still is <= the best t (bvh_accel.cc:586: `tmin <= maxT`, the only clause that can
+      // have changed since it was pushed)
+      uint32_t ref = 0, tag = 0;
+      bool got = false;
+      while (sp > 0) {
+        double tmin;
+        --sp;
+        stk.get(sp, ref, tag, tmin);
+        if (tmin <= bt) {
+          got = true;
+          break;
+        }
+      }
+      if (!got) {
+        res = WT_DONE;
+        break;
+      }
+      if (tag != kWInterior) {
+        tri_cur = ref;
+        tri_end = ref + tag;
+        res = WT_TRI;
+        break;
+      }
+      cur = ref;
+    }
+    const WNode *r = wn + cur;
+    const double2 *q = reinterpret_cast<const double2 *>(r);
+    const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5];
+    uint4 m = *reinterpret_cast<const uint4 *>(&r->ref0);
+    // all seven loads of the record are issued together (the compiler would sink the last behind the box tests)
+    asm volatile("" : "+v"(m.x), "+v"(m.y), "+v"(m.z), "+v"(m.w));
+    n_nodes += 2;
+    double t0, t1;
+    const bool h0 = slab_t<kPlain>(a0, a1, a2, org, ix, iy, iz, sx, sy, sz, bt, t0);
+    const bool h1 = slab_t<kPlain>(a3, a4, a5, org, ix, iy, iz, sx, sy, sz, bt, t1);
+    const uint32_t axis = m.y >> 30, tag0 = m.y & kWInterior, tag1 = m.w;
+    const bool nearIsSecond = (axis == 0) ? sx : ((axis == 1) ? sy : sz); // dirSign[node.axis], bvh_accel.cc:818-824
+    const bool hn = nearIsSecond ? h1 : h0, hf = nearIsSecond ? h0 : h1;
+    const uint32_t refn = nearIsSecond ? m.z : m.x, tagn = nearIsSecond ? tag1 : tag0;
+    const uint32_t reff = nearIsSecond ? m.x : m.z, tagf = nearIsSecond ? tag0 : tag1;
+    const double tf = nearIsSecond ? t0 : t1;
+    if (hf && tagf != 0u) { // an empty leaf (count 0) has nothing to test
+      stk.put(sp, reff, tagf, tf);
+      ++sp;
+    }
+    cur = kWNone;
+    if (hn) {
+      if (tagn == kWInterior) {
+        cur = refn;
+      } else if (tagn != 0u) {
+        tri_cur = refn;
+        tri_end = refn + tagn;
+        res = WT_TRI;
+        break;
+      }
+    }
+  }
+  if (res == WT_NODE && cur == kWNone && sp == 0) res = WT_DONE; // nothing left: spare the caller a round that finds out
+  return res;
+}
 
 // ---- BVHAccel::Traverse (bvh_accel.cc:773-844) without the final BuildIntersection ----------------------------------
 // while-while form: every lane pops and box-tests nodes until it holds a leaf (or runs dry), then the wave tests leaf

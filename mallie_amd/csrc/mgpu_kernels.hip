@@ -450,6 +450,46 @@ void launch_scene_layout(hipStream_t s, const double *verts, const uint32_t *fac
                      slot_normal);
 }
 
+// =====================================================================================================================
+// k_wide_layout: the WNode records of the wide traversal (mgpu_device.hpp), one thread per node index 0..nn.
+// Pure copies of the reference node fields (boxes verbatim), so nothing here can change a decision.
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void k_wide_layout(const MgpuNode *__restrict__ nodes, size_t nn, WNode *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i > nn) return;
+  WNode w;
+  for (int k = 0; k < 6; ++k) w.box0[k] = w.box1[k] = 0.0;
+  w.ref0 = w.tag0 = w.ref1 = w.tag1 = 0u;
+  for (int k = 0; k < 4; ++k) w.pad_[k] = 0u;
+  auto child = [&](uint32_t c, double *box, uint32_t &ref, uint32_t &tag) {
+    const MgpuNode &n = nodes[c];
+    for (int k = 0; k < 3; ++k) {
+      box[k] = n.bmin[k];
+      box[3 + k] = n.bmax[k];
+    }
+    if (n.flag == 0) {
+      ref = c;
+      tag = kWInterior;
+    } else {
+      ref = n.data[1];
+      tag = n.data[0]; // < kWInterior, checked by mgpu_scene_create
+    }
+  };
+  if (i == nn) { // super root: child 0 = the root, child 1 = an empty leaf far away
+    child(0u, w.box0, w.ref0, w.tag0);
+    for (int k = 0; k < 6; ++k) w.box1[k] = kDblMax;
+  } else if (nodes[i].flag == 0) {
+    child(nodes[i].data[0], w.box0, w.ref0, w.tag0);
+    child(nodes[i].data[1], w.box1, w.ref1, w.tag1);
+    w.tag0 |= (uint32_t)nodes[i].axis << 30;
+  }
+  out[i] = w;
+}
+
+void launch_wide_layout(hipStream_t s, const MgpuNode *nodes, size_t nn, WNode *out) {
+  hipLaunchKernelGGL(k_wide_layout, dim3((unsigned)((nn + 1 + 255) / 256)), dim3(256), 0, s, nodes, nn, out);
+}
+
 int pick_stack_cap(int needed_entries) {
   if (needed_entries <= 16) return 16;
   if (needed_entries <= 24) return 24;

@@ -80,7 +80,7 @@ struct EnvParams {
 };
 hipError_t launch_render_env(int cap, bool lds_scene, dim3 grid, hipStream_t s, const DScene &sc, const EnvParams &p);
 // k_trace_sm (mgpu_trace_sm.hip): persistent, wave-scheduled batched trace; `counter` = one zeroed device word
-hipError_t launch_trace_sm(int cap, dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, uint32_t n,
+hipError_t launch_trace_sm(dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, uint32_t n,
                            MgpuIntersection *out, uint8_t *hit, uint32_t *counter, unsigned long long *stats,
                            const uint32_t *select);
 void launch_accumulate(hipStream_t s, const float *planes, size_t plane_stride, int passes, size_t n_floats, float *image,
@@ -90,6 +90,9 @@ void launch_order_tiles(hipStream_t s, uint32_t *cost, uint32_t n_tiles, uint32_
 // slot-ordered DTri records + per-slot shading normals (9 doubles with face-varying normals, else the geometric normal)
 void launch_scene_layout(hipStream_t s, const double *verts, const uint32_t *faces, const uint32_t *indices,
                          const uint32_t *matIDs, const double *fv_normals, size_t nf, DTri *tris, double *slot_normal);
+// WNode records of the wide traversal (nn + 1 of them, the last is the super root)
+void launch_wide_layout(hipStream_t s, const MgpuNode *nodes, size_t nn, WNode *out);
+constexpr int kWideStackLds = 8; // far-child stack entries per lane kept in LDS by the wide traversal (16 bytes each)
 void launch_tonemap(hipStream_t s, const float *image, const int32_t *count, size_t npix, int mode, unsigned char *out);
 constexpr size_t kLdsBudget = 160 * 1024 - 512; // bytes of LDS per CU on gfx950, less the kernels' static cursor words
 

@@ -55,10 +55,19 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 #define MGPU_START_FORCE_HBM 12
 #endif
 #ifndef MGPU_NODE_WEIGHT_LDS
-#define MGPU_NODE_WEIGHT_LDS 4
+#define MGPU_NODE_WEIGHT_LDS 1
 #endif
 #ifndef MGPU_NODE_WEIGHT_HBM
 #define MGPU_NODE_WEIGHT_HBM 1
+#endif
+#ifndef MGPU_TRI_WEIGHT_LDS
+#define MGPU_TRI_WEIGHT_LDS 4
+#endif
+#ifndef MGPU_TRI_WEIGHT_HBM
+#define MGPU_TRI_WEIGHT_HBM 4
+#endif
+#ifndef MGPU_SHARE8_MAX
+#define MGPU_SHARE8_MAX 0 // open leaves up to which 8 lanes share one (0: never)
 #endif
 #ifndef MGPU_SHADE_MIN
 #define MGPU_SHADE_MIN 36
@@ -76,6 +85,12 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 #endif
 #ifndef MGPU_NODES_PER_STEP
 #define MGPU_NODES_PER_STEP 6
+#endif
+#ifndef MGPU_WIDE_PER_STEP
+#define MGPU_WIDE_PER_STEP 3 // interior nodes entered per NODE step with the BVH in HBM (two box tests each)
+#endif
+#ifndef MGPU_SHARED_LEAVES
+#define MGPU_SHARED_LEAVES 1
 #endif
 #ifndef MGPU_TRIS_PER_STEP
 #define MGPU_TRIS_PER_STEP 16
@@ -96,9 +111,17 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
   uint32_t *s_stack = reinterpret_cast<uint32_t *>(smem); // [kWaves][CAP][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  // traversal stack: LDS_SCENE walks the reference's 64-byte nodes staged in LDS with a stack of node indices; with the
+  // BVH in HBM the wide form is used (mgpu_device.hpp, wide_node_step): far children with their tmin
   Stack<CAP, OVF> stk;
   stk.lds = s_stack + ((size_t)wave * CAP) * 64 + lane;
   stk.overflow = (OVF && sc.stack_overflow) ? sc.stack_overflow + gid * sc.overflow_cap : nullptr;
+  using WS = WStack<kWideStackLds>;
+  WS wstk;
+  if (!LDS_SCENE) {
+    wstk.bind(smem + (size_t)wave * WS::kWaveBytes, lane);
+    wstk.overflow = sc.wstack_overflow ? sc.wstack_overflow + gid * sc.woverflow_cap : nullptr;
+  }
 
   // ---- optional: stage nodes + triangles into LDS -------------------------------------------------------------
   const unsigned char *lds_nodes = smem + (size_t)kWaves * CAP * 64 * sizeof(uint32_t);
@@ -140,6 +163,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(home_shard)); // which XCD this workgroup runs on (0..7)
   home_shard &= 7u;
   // LDS cursor: hi32 = end, lo32 = next, both (shard << 28) | index of the item inside its shard's part
+  __shared__ unsigned char s_owner[BLOCK]; // TRI step with shared leaves: lane of the k-th open leaf, per wave
   __shared__ unsigned long long wg_cursor;
   __shared__ uint32_t wg_lock, wg_shard_off, wg_dry;
   if (threadIdx.x == 0) {
@@ -166,7 +190,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
   double ix = 0, iy = 0, iz = 0;
   bool sx = false, sy = false, sz = false;
   bool ray_plain = false; // this ray may take the min/max form of the slab test (see the NODE step)
-  int sp = -1;
+  int sp = -1;           // LDS_SCENE: index of the stack top; wide form: number of far children on the stack
+  uint32_t cur = kWNone; // wide form: record to enter next (kWNone: pop)
   double bt = kDblMax, bu = 0, bv = 0;
   uint32_t bslot = kNoHit;
   uint32_t tri_cur = 0, tri_end = 0;
@@ -208,7 +233,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
     // runnable; otherwise NODE runs unless TRI has several times more lanes waiting (MGPU_NODE_WEIGHT_*).
     const int cReal = __popcll(__ballot(st == ST_SHADE && have_ray)); // lanes with a ray to finish (not parked between paths)
     const bool run_shade = (cReal >= MGPU_SHADE_MIN) || (cN == 0 && cT == 0) || (cS - cReal >= (LDS_SCENE ? MGPU_START_FORCE_LDS : MGPU_START_FORCE_HBM));
-    if (!run_shade && cN * (LDS_SCENE ? MGPU_NODE_WEIGHT_LDS : MGPU_NODE_WEIGHT_HBM) >= cT) {
+    if (!run_shade && cN * (LDS_SCENE ? MGPU_NODE_WEIGHT_LDS : MGPU_NODE_WEIGHT_HBM) >= cT * (LDS_SCENE ? MGPU_TRI_WEIGHT_LDS : MGPU_TRI_WEIGHT_HBM)) {
       // ================================ NODE step ================================
       MGPU_TICK();
       const bool all_plain = __ballot(st == ST_NODE && !ray_plain) == 0ull; // wave-uniform
@@ -263,9 +288,21 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
             if (st != ST_NODE || sp < 0) break;
           }
         };
-        if (all_plain) node_pops(std::true_type{});
-        else node_pops(std::false_type{});
-        if (st == ST_NODE && sp < 0) st = ST_SHADE;
+        if constexpr (LDS_SCENE) {
+          if (all_plain) node_pops(std::true_type{});
+          else node_pops(std::false_type{});
+          if (st == ST_NODE && sp < 0) st = ST_SHADE;
+        } else {
+          int r;
+          if (all_plain)
+            r = wide_node_step<true, MGPU_WIDE_PER_STEP, kWideStackLds>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, bt, cur, sp,
+                                                                       tri_cur, tri_end, n_nodes);
+          else
+            r = wide_node_step<false, MGPU_WIDE_PER_STEP, kWideStackLds>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, bt, cur, sp,
+                                                                        tri_cur, tri_end, n_nodes);
+          if (r == WT_TRI) st = ST_TRI;
+          else if (r == WT_DONE) st = ST_SHADE;
+        }
       }
 #ifdef MGPU_UTIL
       if (cyc_dry) ++steps_n;
@@ -274,57 +311,170 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
     } else if (!run_shade) {
       // ================================ TRI step =================================
       MGPU_TICK();
-      if (st == ST_TRI) {
+      // Shared leaves: with at most 32 (16) lanes holding an open leaf, 2 (4) lanes work on each -- lane L serves the
+      // (L / m)-th open leaf and tests its triangles first + L % m, + m, ... with the owner's ray (fetched across lanes),
+      // idle and NODE / SHADE lanes included; their own state is untouched.  The m partial results are merged by the rule
+      // the reference's in-order loop obeys for ordinary numbers -- smallest t, the LATER triangle on equal t
+      // (TriangleIsect rejects only `t > tBest`, bvh_accel.cc:631) -- and the owner applies the same `t > bt` test to the
+      // merged candidate.  A NaN t (which that loop would accept, and after which it accepts everything) cannot be
+      // merged this way: a step that produces one is thrown away and redone in order by the owners alone.
+      bool shared_done = false;
+#if MGPU_SHARED_LEAVES
+      if (cT <= 32) {
+        const int sh = cT <= MGPU_SHARE8_MAX ? 3 : (cT <= 16 ? 2 : 1), m = 1 << sh;
+        const uint32_t rank = (uint32_t)__popcll(mT & ((1ull << lane) - 1ull));
+        unsigned char *tbl = s_owner + wave * 64;
+        if (st == ST_TRI) tbl[rank] = (unsigned char)lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int grp = lane >> sh, sub = lane & (m - 1);
+        const bool serving = grp < cT;
+        const int own = serving ? (int)tbl[grp] : lane;
+        const V3 o = v3(__shfl(org.x, own), __shfl(org.y, own), __shfl(org.z, own));
+        const V3 d = v3(__shfl(dir.x, own), __shfl(dir.y, own), __shfl(dir.z, own));
+        const uint32_t first = (uint32_t)__shfl((int)tri_cur, own), last = (uint32_t)__shfl((int)tri_end, own);
+        double lt = __builtin_inf(), lu = 0.0, lv = 0.0;
+        uint32_t ls = kNoHit;
+        if (serving) {
+          uint32_t i = first + (uint32_t)sub;
+#pragma unroll 1
+          for (int rep = 0; rep < MGPU_TRIS_PER_STEP && i < last; ++rep, i += (uint32_t)m) {
+#ifdef MGPU_UTIL
+            if (lane == __ffsll((long long)__ballot(1)) - 1) u_tri_it++;
+#endif
+            double2 a0, a1, a2, a3;
+            double e2z;
+            if (LDS_SCENE) {
+              const unsigned char *tp = lds_tris + (size_t)i * 80;
+              a0 = *reinterpret_cast<const double2 *>(tp);
+              a1 = *reinterpret_cast<const double2 *>(tp + 16);
+              a2 = *reinterpret_cast<const double2 *>(tp + 32);
+              a3 = *reinterpret_cast<const double2 *>(tp + 48);
+              e2z = *reinterpret_cast<const double *>(tp + 64);
+            } else {
+              const DTri *tp = sc.tris + i;
+              a0 = reinterpret_cast<const double2 *>(tp)[0];
+              a1 = reinterpret_cast<const double2 *>(tp)[1];
+              a2 = reinterpret_cast<const double2 *>(tp)[2];
+              a3 = reinterpret_cast<const double2 *>(tp)[3];
+              e2z = tp->e2[2];
+            }
+            ++n_tris;
+            const V3 p0 = v3(a0.x, a0.y, a1.x), e1 = v3(a1.y, a2.x, a2.y), e2 = v3(a3.x, a3.y, e2z);
+            const V3 p = cross(d, e2);
+            const double det = dot(e1, p);
+            if (!(fabs(det) < kDblEps1024)) {
+              const double invDet = inv_det_w(det);
+              const V3 sv = o - p0;
+              const V3 q = cross(sv, e1);
+              const double u = dot(sv, p) * invDet;
+              const double v = dot(q, d) * invDet;
+              const double t = dot(e2, q) * invDet;
+              const bool rej = (u < 0.0 || u > 1.0) || (v < 0.0 || u + v > 1.0) || (t < 0.0 || t > lt);
+              if (!rej) {
+                lt = t;
+                lu = u;
+                lv = v;
+                ls = i;
+              }
+            }
+          }
+        }
+        if (__ballot(lt != lt) == 0ull) { // no NaN candidate anywhere: merge
+          for (int x = 1; x < m; x <<= 1) {
+            const double pt = __shfl_xor(lt, x), pu = __shfl_xor(lu, x), pv = __shfl_xor(lv, x);
+            const uint32_t ps = (uint32_t)__shfl_xor((int)ls, x);
+            // partner wins with a smaller t, or with an equal t and the later triangle (kNoHit never wins: its t is +inf
+            // and an equal +inf from a real triangle loses nothing -- the owner's `t > bt` test rejects it either way)
+            const bool take = ps != kNoHit && (ls == kNoHit || pt < lt || (pt == lt && ps > ls));
+            if (take) {
+              lt = pt;
+              lu = pu;
+              lv = pv;
+              ls = ps;
+            }
+          }
+          const int from = (int)(rank << sh); // lane 0 of this owner's group holds the merged candidate (as do the others)
+          const double ct = __shfl(lt, from), cu = __shfl(lu, from), cv = __shfl(lv, from);
+          const uint32_t cs = (uint32_t)__shfl((int)ls, from);
+          if (st == ST_TRI) {
+            if (cs != kNoHit && !(ct > bt)) {
+              bt = ct;
+              bu = cu;
+              bv = cv;
+              bslot = cs;
+            }
+            const uint32_t done = min(tri_end - tri_cur, (uint32_t)(MGPU_TRIS_PER_STEP * m));
+            tri_cur += done;
+          }
+          shared_done = true;
+        } else {
+          if (serving) n_tris -= min(((last - first) + (uint32_t)(m - 1 - sub)) >> sh, (uint32_t)MGPU_TRIS_PER_STEP); // not counted twice
+        }
+      }
+#endif
+      if (!shared_done && st == ST_TRI) {
 #ifdef MGPU_UTIL
         if (lane == __ffsll((long long)mT) - 1) u_tri++;
 #endif
+        // TriangleIsect, bvh_accel.cc:595-638, on the triangle in (a0..a3, e2z)
+        auto tri_test = [&](double2 a0, double2 a1, double2 a2, double2 a3, double e2z) {
+          ++n_tris;
+          const V3 p0 = v3(a0.x, a0.y, a1.x), e1 = v3(a1.y, a2.x, a2.y), e2 = v3(a3.x, a3.y, e2z);
+          const V3 p = cross(dir, e2);
+          const double det = dot(e1, p);
+          if (!(fabs(det) < kDblEps1024)) {
+            const double invDet = inv_det_w(det); // 1.0 / det
+            const V3 s = org - p0;
+            const V3 q = cross(s, e1);
+            const double u = dot(s, p) * invDet;
+            const double v = dot(q, dir) * invDet;
+            const double t = dot(e2, q) * invDet;
+            const bool rej = (u < 0.0 || u > 1.0) || (v < 0.0 || u + v > 1.0) || (t < 0.0 || t > bt);
+            if (!rej) {
+              bt = t;
+              bu = u;
+              bv = v;
+              bslot = tri_cur;
+            }
+          }
+        };
+        if constexpr (LDS_SCENE) {
 #pragma unroll 1
-        for (int rep = 0; rep < MGPU_TRIS_PER_STEP; ++rep) {
+          for (int rep = 0; rep < MGPU_TRIS_PER_STEP; ++rep) {
 #ifdef MGPU_UTIL
-        if (lane == __ffsll((long long)__ballot(1)) - 1) u_tri_it++;
+            if (lane == __ffsll((long long)__ballot(1)) - 1) u_tri_it++;
 #endif
-        double2 a0, a1, a2, a3;
-        double e2z;
-        if (LDS_SCENE) {
-          const unsigned char *tp = lds_tris + (size_t)tri_cur * 80;
-          a0 = *reinterpret_cast<const double2 *>(tp);
-          a1 = *reinterpret_cast<const double2 *>(tp + 16);
-          a2 = *reinterpret_cast<const double2 *>(tp + 32);
-          a3 = *reinterpret_cast<const double2 *>(tp + 48);
-          e2z = *reinterpret_cast<const double *>(tp + 64);
+            const unsigned char *tp = lds_tris + (size_t)tri_cur * 80;
+            const double2 a0 = *reinterpret_cast<const double2 *>(tp);
+            const double2 a1 = *reinterpret_cast<const double2 *>(tp + 16);
+            const double2 a2 = *reinterpret_cast<const double2 *>(tp + 32);
+            const double2 a3 = *reinterpret_cast<const double2 *>(tp + 48);
+            const double e2z = *reinterpret_cast<const double *>(tp + 64);
+            tri_test(a0, a1, a2, a3, e2z);
+            ++tri_cur;
+            if (tri_cur == tri_end) break;
+          }
         } else {
-          const DTri *tp = sc.tris + tri_cur;
-          a0 = reinterpret_cast<const double2 *>(tp)[0];
-          a1 = reinterpret_cast<const double2 *>(tp)[1];
-          a2 = reinterpret_cast<const double2 *>(tp)[2];
-          a3 = reinterpret_cast<const double2 *>(tp)[3];
-          e2z = tp->e2[2];
-        }
-        ++n_tris;
-        // TriangleIsect, bvh_accel.cc:595-638
-        const V3 p0 = v3(a0.x, a0.y, a1.x), e1 = v3(a1.y, a2.x, a2.y), e2 = v3(a3.x, a3.y, e2z);
-        const V3 p = cross(dir, e2);
-        const double det = dot(e1, p);
-        if (!(fabs(det) < kDblEps1024)) {
-          const double invDet = inv_det_w(det); // 1.0 / det
-          const V3 s = org - p0;
-          const V3 q = cross(s, e1);
-          const double u = dot(s, p) * invDet;
-          const double v = dot(q, dir) * invDet;
-          const double t = dot(e2, q) * invDet;
-          const bool rej = (u < 0.0 || u > 1.0) || (v < 0.0 || u + v > 1.0) || (t < 0.0 || t > bt);
-          if (!rej) {
-            bt = t;
-            bu = u;
-            bv = v;
-            bslot = tri_cur;
+          // (requesting triangle i + 1 before triangle i is tested costs 38 more spilled registers and loses 10 %:
+          // profiles/experiments/README.md)
+#pragma unroll 1
+          for (int rep = 0; rep < MGPU_TRIS_PER_STEP; ++rep) {
+#ifdef MGPU_UTIL
+            if (lane == __ffsll((long long)__ballot(1)) - 1) u_tri_it++;
+#endif
+            const DTri *tp = sc.tris + tri_cur;
+            const double2 a0 = reinterpret_cast<const double2 *>(tp)[0], a1 = reinterpret_cast<const double2 *>(tp)[1],
+                          a2 = reinterpret_cast<const double2 *>(tp)[2], a3 = reinterpret_cast<const double2 *>(tp)[3];
+            const double e2z = tp->e2[2];
+            tri_test(a0, a1, a2, a3, e2z);
+            ++tri_cur;
+            if (tri_cur == tri_end) break;
           }
         }
-        ++tri_cur;
-        if (tri_cur == tri_end) break;
-        }
-        if (tri_cur == tri_end) st = (sp < 0) ? ST_SHADE : ST_NODE;
       }
+      if (st == ST_TRI && tri_cur == tri_end) st = (LDS_SCENE ? sp < 0 : sp == 0) ? ST_SHADE : ST_NODE;
 #ifdef MGPU_UTIL
       if (cyc_dry) ++steps_t;
 #endif
@@ -590,7 +740,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
           ray_plain = sc.boxes_ordered && inv_ok && origin_is_finite(org);
           bt = kDblMax; bu = 0.0; bv = 0.0; bslot = kNoHit;
           sp = 0;
-          stk.put(0, 0u);
+          if constexpr (LDS_SCENE) {
+            stk.put(0, 0u);
+          } else {
+            cur = sc.wroot; // the super root: its child 0 is the tree's root (the reference's first pop)
+            n_nodes -= 1u;  // ... and its child 1 a dummy the reference never pops
+          }
           have_ray = true;
           ++n_rays;
           st = ST_NODE;
@@ -880,12 +1035,7 @@ hipError_t launch_render_sm(int cap, bool lds_scene, int block, dim3 grid, hipSt
     if (cap == 24 && block == 1024) return launch_one<24, true, 1024, false>(grid, s, shmem, sc, p);
     if (cap == 24 && block == 512) return launch_one<24, true, 512, false>(grid, s, shmem, sc, p);
   }
-  if (!lds_scene && block == 256) {
-    if (cap == 16 && !ovf) return launch_one<16, false, 256, false>(grid, s, shmem, sc, p);
-    if (cap == 24 && !ovf) return launch_one<24, false, 256, false>(grid, s, shmem, sc, p);
-    if (cap == 32 && !ovf) return launch_one<32, false, 256, false>(grid, s, shmem, sc, p);
-    if (cap == 32 && ovf) return launch_one<32, false, 256, true>(grid, s, shmem, sc, p);
-  }
+  if (!lds_scene && block == 256) return launch_one<1, false, 256, false>(grid, s, shmem, sc, p); // wide form: one variant
   return hipErrorInvalidConfiguration;
 }
 

@@ -5,7 +5,8 @@
 // for its slowest lane's chain of dependent HBM loads while 63 lanes idle.  Here the waves are persistent and every lane
 // carries an explicit state
 //
-//     NODE : pop up to 4 nodes, slab test, push children / open a leaf        (bvh_accel.cc:805-834, 550-593)
+//     NODE : enter up to 4 interior nodes: both child boxes from one 128-byte record, near child entered directly,
+//            far child stacked with its tmin (wide_node_step, mgpu_device.hpp)  (bvh_accel.cc:805-834, 550-593)
 //     TRI  : test the open leaf's triangles in leaf order                      (bvh_accel.cc:595-697)
 //     EMIT : write the finished ray's Intersection record and hit flag, take the next ray index from the wave's cursor,
 //            load the ray and arm its traversal                                (bvh_accel.cc:774-802, 699-769, 838)
@@ -17,7 +18,6 @@
 // Ray indices are handed out in order: a wave reserves kRayChunk consecutive indices with one global atomic and deals
 // them to its lanes as they free up, so neighbouring lanes mostly hold neighbouring rays (coalesced-ish loads, record
 // stores that fill whole cache lines between them).
-#include <type_traits>
 #include "mgpu_device.hpp"
 #include "mgpu_kernels.hpp"
 
@@ -37,7 +37,6 @@ constexpr int kTraceBlock = 256;
 #define MGPU_EMIT_MIN 24
 #endif
 
-template <int CAP, bool OVF>
 __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const MgpuRay *__restrict__ rays, uint32_t n,
                                                             MgpuIntersection *__restrict__ out,
                                                             uint8_t *__restrict__ hit_out, uint32_t *work_counter,
@@ -46,14 +45,15 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
   if (select && *select != kTraceSelectSm) return; // k_trace_probe chose the other kernel for this batch
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ unsigned long long s_cnt[3];
-  uint32_t *s_stack = reinterpret_cast<uint32_t *>(smem); // [waves][CAP][64]
-  // record staging: per wave 16 records of 23 8-byte pieces + their 16 ray indices
-  unsigned long long *s_stage = reinterpret_cast<unsigned long long *>(smem + (size_t)(kTraceBlock / 64) * CAP * 64 * sizeof(uint32_t));
+  using WS = WStack<kWideStackLds>;
+  // per wave: the far-child stack's LDS part, then (all waves) the record staging: 16 records of 23 8-byte pieces + their
+  // 16 ray indices per wave
+  unsigned long long *s_stage = reinterpret_cast<unsigned long long *>(smem + (size_t)(kTraceBlock / 64) * WS::kWaveBytes);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t slot = (size_t)blockIdx.x * kTraceBlock + threadIdx.x;
-  Stack<CAP, OVF> stk;
-  stk.lds = s_stack + ((size_t)wave * CAP) * 64 + lane;
-  stk.overflow = (OVF && sc.stack_overflow) ? sc.stack_overflow + slot * sc.overflow_cap : nullptr;
+  WS stk;
+  stk.bind(smem + (size_t)wave * WS::kWaveBytes, lane);
+  stk.overflow = sc.wstack_overflow ? sc.wstack_overflow + slot * sc.woverflow_cap : nullptr;
   if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0ull;
   __syncthreads();
 
@@ -68,7 +68,8 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
   double ix = 0, iy = 0, iz = 0;
   bool sx = false, sy = false, sz = false;
   bool ray_plain = false; // the ray may take the min/max form of the slab test (mgpu_device.hpp, slab_hit)
-  int sp = -1;
+  int sp = 0;               // far children on the stack
+  uint32_t cur = kWNone;    // wide record to enter next (kWNone: pop)
   double bt = kDblMax, bu = 0, bv = 0;
   uint32_t bslot = kNoHit;
   uint32_t tri_cur = 0, tri_end = 0;
@@ -85,42 +86,14 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
       // ================================ NODE step ================================
       const bool all_plain = __ballot(st == TS_NODE && !ray_plain) == 0ull; // wave-uniform
       if (st == TS_NODE) {
-        // slab_hit<true> (min/max form) when every lane's ray qualifies, the literal form for this step otherwise
-        auto node_pops = [&](auto plain_tag) {
-          constexpr bool kPlain = decltype(plain_tag)::value;
-#pragma unroll 1
-          for (int rep = 0; rep < 4; ++rep) {
-            const uint32_t ni = stk.get(sp);
-            --sp;
-            ++n_nodes;
-            const MgpuNode *nd = sc.nodes + ni;
-            const double2 b0 = *reinterpret_cast<const double2 *>(&nd->bmin[0]);
-            const double2 b1 = *reinterpret_cast<const double2 *>(&nd->bmin[2]);
-            const double2 b2 = *reinterpret_cast<const double2 *>(&nd->bmax[1]);
-            int4 meta = *reinterpret_cast<const int4 *>(&nd->flag);
-            // keep this load next to the other three (same 64-byte node): the compiler otherwise sinks it into the hit
-            // branch, where it is a second dependent trip to L1/L2 per visited node
-            asm volatile("" : "+v"(meta.x), "+v"(meta.y), "+v"(meta.z), "+v"(meta.w));
-            const bool hit = slab_hit<kPlain>(b0, b1, b2, org, ix, iy, iz, sx, sy, sz, bt); // IntersectRayAABB
-            if (hit) {
-              if (meta.x == 0) {
-                const bool nearIsSecond = (meta.y == 0) ? sx : ((meta.y == 1) ? sy : sz); // dirSign[node.axis]
-                const uint32_t c0 = (uint32_t)meta.z, c1 = (uint32_t)meta.w;
-                stk.put(sp + 1, nearIsSecond ? c0 : c1); // far
-                stk.put(sp + 2, nearIsSecond ? c1 : c0); // near: popped first
-                sp += 2;
-              } else if (meta.z != 0) {
-                tri_cur = (uint32_t)meta.w;
-                tri_end = (uint32_t)meta.w + (uint32_t)meta.z;
-                st = TS_TRI;
-              }
-            }
-            if (st != TS_NODE || sp < 0) break;
-          }
-        };
-        if (all_plain) node_pops(std::true_type{});
-        else node_pops(std::false_type{});
-        if (st == TS_NODE && sp < 0) st = TS_EMIT;
+        // slab test in min/max form when every lane's ray qualifies, the literal form for this step otherwise
+        int r;
+        if (all_plain)
+          r = wide_node_step<true, 4, kWideStackLds>(sc.wnodes, stk, org, ix, iy, iz, sx, sy, sz, bt, cur, sp, tri_cur, tri_end, n_nodes);
+        else
+          r = wide_node_step<false, 4, kWideStackLds>(sc.wnodes, stk, org, ix, iy, iz, sx, sy, sz, bt, cur, sp, tri_cur, tri_end, n_nodes);
+        if (r == WT_TRI) st = TS_TRI;
+        else if (r == WT_DONE) st = TS_EMIT;
       }
     } else if (!run_emit) {
       // ================================ TRI step =================================
@@ -156,7 +129,7 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
           ++tri_cur;
           if (tri_cur == tri_end) break;
         }
-        if (tri_cur == tri_end) st = (sp < 0) ? TS_EMIT : TS_NODE;
+        if (tri_cur == tri_end) st = (sp == 0) ? TS_EMIT : TS_NODE; // cur == kWNone: the next NODE step pops
       }
     } else {
       // ================================ EMIT step ================================
@@ -272,7 +245,8 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
           ray_plain = sc.boxes_ordered && inv_ok && origin_is_finite(org);
           bt = kDblMax; bu = 0.0; bv = 0.0; bslot = kNoHit;
           sp = 0;
-          stk.put(0, 0u);
+          cur = sc.wroot; // the super root: its child 0 is the tree's root (whose box test is the reference's first pop)
+          n_nodes -= 1u;  // ... and its child 1 a dummy the reference never pops
           ++n_rays;
           st = TS_NODE;
         } else {
@@ -303,24 +277,11 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
   }
 }
 
-template <int CAP, bool OVF>
-static hipError_t launch_one(dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, uint32_t n,
-                             MgpuIntersection *out, uint8_t *hit, uint32_t *counter, unsigned long long *stats,
-                             const uint32_t *select) {
-  const size_t shmem = (size_t)(kTraceBlock / 64) * (CAP * 64 * sizeof(uint32_t) + (16 * 23 + 16) * sizeof(unsigned long long));
-  hipLaunchKernelGGL((k_trace_sm<CAP, OVF>), grid, dim3(kTraceBlock), shmem, s, sc, rays, n, out, hit, counter, stats, select);
+hipError_t launch_trace_sm(dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, uint32_t n, MgpuIntersection *out,
+                           uint8_t *hit, uint32_t *counter, unsigned long long *stats, const uint32_t *select) {
+  const size_t shmem = (size_t)(kTraceBlock / 64) * (WStack<kWideStackLds>::kWaveBytes + (16 * 23 + 16) * sizeof(unsigned long long));
+  hipLaunchKernelGGL(k_trace_sm, grid, dim3(kTraceBlock), shmem, s, sc, rays, n, out, hit, counter, stats, select);
   return hipGetLastError();
-}
-
-hipError_t launch_trace_sm(int cap, dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, uint32_t n,
-                           MgpuIntersection *out, uint8_t *hit, uint32_t *counter, unsigned long long *stats,
-                           const uint32_t *select) {
-  const bool ovf = sc.overflow_cap != 0;
-  if (cap == 16 && !ovf) return launch_one<16, false>(grid, s, sc, rays, n, out, hit, counter, stats, select);
-  if (cap == 24 && !ovf) return launch_one<24, false>(grid, s, sc, rays, n, out, hit, counter, stats, select);
-  if (cap == 32 && !ovf) return launch_one<32, false>(grid, s, sc, rays, n, out, hit, counter, stats, select);
-  if (cap == 32 && ovf) return launch_one<32, true>(grid, s, sc, rays, n, out, hit, counter, stats, select);
-  return hipErrorInvalidConfiguration;
 }
 
 } // namespace mgpu
