@@ -543,6 +543,84 @@ def test_million_triangle_grid_rows_vs_oracle():
     assert torch.equal(full[y0:y0 + rows], buf) and st["paths"] == 2 * W * H
 
 
+def test_c5_ten_million_triangle_grid():
+    """BASELINE config C5's scene (102x102 suzanne grid, 10 071 072 triangles) at its 3840x2160 frame: the device BVH build
+    (multi-workgroup top levels) against the host builder byte for byte (bvh_accel.cc:321-482), a band of rows of the frame
+    against the oracle with equal work counters (render.cc:381-456), whole-frame determinism and path count."""
+    import torch
+    from mallie_amd.scenes import suzanne_grid
+    c = O.load_golden("cornell_obj")
+    verts, faces, mats, normals = suzanne_grid(c["verts"], c["faces"], 102)
+    assert len(faces) == 10071072
+    nodes, idx, st = M.bvh_build(verts, faces)                 # host builder (pinned to the reference's trees)
+    dn, di, dst = M.bvh_build(verts, faces, device=0)          # device builder
+    assert dn.tobytes() == nodes.tobytes() and np.array_equal(di, idx)
+    assert {k: dst[k] for k in st} == st and st["maxTreeDepth"] == 27
+    sc = M.Scene(verts, faces, mats, normals, None, nodes, idx)
+    osc = O.OracleScene(verts, faces, mats, normals, None, nodes, idx)
+    W, H, mpl = 3840, 2160, 5
+    frame = M.camera_frame((0, 40, 80), (0, 0, 0), width=W, height=H)
+    plane = osc.plane()
+    y0, rows = 1200, 4
+    oimg, _, ost, _ = osc.render(frame, W, H, mpl, 2, plane, O.RNG_HASH, seed=1, window=(0, y0, W, y0 + rows))
+    buf = torch.empty((rows, W, 3), dtype=torch.float32, device="cuda")
+    st = sc.render_strips_device(frame, W, H, buf.data_ptr(), rows, y_first=y0, strip_h=rows, y_period=rows,
+                                 maxPathLength=mpl, passes=2, plane=plane, seed=1, want_stats=True)
+    assert_images_match(buf.cpu().numpy(), oimg[y0:y0 + rows], "C5 rows")
+    assert_same_work(st, ost)
+    full = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    again = torch.empty_like(full)
+    st = sc.render_strips_device(frame, W, H, full.data_ptr(), H, maxPathLength=mpl, passes=2, plane=plane, seed=1,
+                                 want_stats=True)
+    sc.render_strips_device(frame, W, H, again.data_ptr(), H, maxPathLength=mpl, passes=2, plane=plane, seed=1)
+    torch.cuda.synchronize()
+    assert torch.equal(full[y0:y0 + rows], buf) and torch.equal(full, again) and st["paths"] == 2 * W * H
+
+
+def test_c3_teapot_full_size():
+    """BASELINE config C3 at its full size (teapot, 1920x1080, 64 spp, maxPathLength 9, eye (0,40,250) -> (0,40,0)): a band
+    of the 64-spp frame against the oracle's 64-spp band with equal work counters, and the whole frame's determinism."""
+    import torch
+    sc, osc = gpu_scene("teapot_obj"), O.scene_from_golden("teapot_obj")
+    W, H, mpl, spp = 1920, 1080, 9, 64
+    frame = M.camera_frame((0, 40, 250), (0, 40, 0), width=W, height=H)
+    plane = osc.plane()
+    y0, rows = 560, 4
+    oimg, _, ost, _ = osc.render(frame, W, H, mpl, spp, plane, O.RNG_HASH, seed=1, window=(0, y0, W, y0 + rows))
+    buf = torch.empty((rows, W, 3), dtype=torch.float32, device="cuda")
+    st = sc.render_strips_device(frame, W, H, buf.data_ptr(), rows, y_first=y0, strip_h=rows, y_period=rows,
+                                 maxPathLength=mpl, passes=spp, plane=plane, seed=1, want_stats=True)
+    assert_images_match(buf.cpu().numpy(), oimg[y0:y0 + rows], "C3 rows")
+    assert_same_work(st, ost)
+    full = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    again = torch.empty_like(full)
+    st = sc.render_strips_device(frame, W, H, full.data_ptr(), H, maxPathLength=mpl, passes=spp, plane=plane, seed=1,
+                                 want_stats=True)
+    sc.render_strips_device(frame, W, H, again.data_ptr(), H, maxPathLength=mpl, passes=spp, plane=plane, seed=1)
+    torch.cuda.synchronize()
+    assert torch.equal(full[y0:y0 + rows], buf) and torch.equal(full, again) and st["paths"] == spp * W * H
+
+
+def test_c2_full_frame_digest_vs_oracle():
+    """BASELINE config C2 exactly as bench.py renders it (cornellbox_suzanne, 1920x1080, 16 spp, maxPathLength 5, plane on,
+    seed 1): the whole float frame against the digest of the ORACLE's frame committed under tests/golden
+    (oracle/make_c2_digest.py), sample rows, and the work counters."""
+    import hashlib
+    import torch
+    d = O.load_golden("c2_1080p_16spp_digest")
+    W, H, mpl, spp = int(d["W"]), int(d["H"]), int(d["maxPathLength"]), int(d["passes"])
+    sc = gpu_scene("cornell_obj", own_bvh=True)
+    frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    buf = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    st = sc.render_strips_device(frame, W, H, buf.data_ptr(), H, maxPathLength=mpl, passes=spp, plane=sc.plane(),
+                                 seed=int(d["seed"]), want_stats=True)
+    img = buf.cpu().numpy()
+    assert np.array_equal(img[d["row_ids"]], d["rows"])
+    assert hashlib.sha256(img.tobytes()).digest() == d["sha256"].tobytes()
+    assert st["real_rays"] == int(d["real_rays"]) and st["trace_calls"] == int(d["trace_calls"]) and st["paths"] == int(d["paths"])
+    assert abs(st["nodes"] - int(d["nodes"])) <= 2e-3 * int(d["nodes"]) and abs(st["tris"] - int(d["tris"])) <= 2e-3 * int(d["tris"])
+
+
 PANOS = ["pano_cornell_stereo_96x64", "pano_cornell_mono_80x40", "pano_cornell_stereo_50x37_view2", "pano_teapot_mono_64x32"]
 
 
