@@ -5,19 +5,31 @@ Workload (configs[1]): cornellbox_suzanne, 1920x1080, 16 spp,
 eye (0,0,20) -> (0,0,0), per-(pixel,pass) seeding, seed 1.  One "step" = one whole frame: 16 passes of Render()
 semantics accumulated on the device in one persistent-kernel launch per GPU (+ one RCCL gather of the row strips to
 rank 0 when N > 1; there three frames are kept in flight on three streams so that the gather and the drain of one
-launch overlap the next frames, see --frames-in-flight and DESIGN.md 6).  The scene (mesh arrays from tests/golden, BVH built by this library's host builder) is resident
-in HBM before the timed region; the frame stays in HBM.
+launch overlap the next frames, see --frames-in-flight and DESIGN.md 6).  Step k renders passes [16k, 16k+16) -- a
+progressive renderer's next frame, not the same frame again.  The scene (mesh arrays from tests/golden, BVH built by this
+library's host builder) is resident in HBM before the timed region; the frame stays in HBM (`value`); the same frame
+including its read-back to pinned host memory is timed separately (`frame_with_readback`).
 
 "rays" = BVH traversals actually performed ("real" rays: primary + bounce rays up to and including a path's first
 miss); the reference's post-miss continuation rays are finished analytically and are NOT counted.
+
+Roofline: what bounds the dominant kernel on this workload is fp64 VALU issue (the 92 KB BVH lives in LDS; HBM carries
+1 % of its peak), so `roofline.bound` = "valu": executed VALU wave-instructions per second against the issue peak, from
+the rocprofv3 PMC passes committed under profiles/ -- used only when they were collected on the very library this run
+loads (sha256 stamp), null otherwise.  The active-lane fraction of the kernel's bodies is measured in this run by an
+instrumented pass (libmallie_mgpu_occ.so, not timed).  The SURVEY 8(d) HBM-priced figure is kept as
+`algorithmic_vs_hbm`.  `extra_configs` carries single-GPU lines for the HBM-resident scenes C3 and C4.
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
                 bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import hashlib
 import json
 import os
+import re
+import subprocess
 import sys
 import time
 
@@ -32,74 +44,124 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # algorithmic bytes per event: fp64 reference-layout node, pre-gathered fp64 triangle + face id,
 # ray in (org+dir) + hit out (t,u,v,id)
 B_NODE, B_TRI, B_RAY = 64, 76, 80
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+N_SIMD, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, max clock
+# a wave64 fp64 VALU instruction occupies its SIMD for 4 cycles (16 fp64 lanes per SIMD and cycle = the 78.6 TFLOP/s fp64
+# vector peak of the guide); SQ_ACTIVE_INST_VALU counts in those 4-cycle units
+VALU_PEAK_GINST = N_SIMD * CLOCK_HZ / 4 / 1e9
+# nominal VALU instructions per trip of each body of k_render_sm (ISA of the shipped library): only used
+# to weight the three measured lane fractions into one number
+BODY_WEIGHT = {"node": 50.0, "tri": 80.0, "shade": 870.0}
 
-WORKLOAD = dict(scene="cornellbox_suzanne", width=1920, height=1080, spp=16, bounces=4, plane=True, eye=(0.0, 0.0, 20.0),
-                lookat=(0.0, 0.0, 0.0), seed=1)
+
+def so_sha256(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
 
 
-def hbm_traffic(kernel_prefix):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json,
-    produced by profiles/collect_r1.sh + profiles/summarize_csv.py on this same bench command); None if absent."""
+def pmc_for(workload, lib_path):
+    """Per-launch PMC numbers of the dominant kernel on `workload` from profiles/pmc_current.json (profiles/collect_pmc.sh +
+    profiles/summarize_pmc.py) -- only if they were collected on the library loaded now.  Returns (dict or None, reason)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "pmc_current.json")) as f:
             d = json.load(f)
-        for k, v in d["bytes_per_launch"].items():
-            if kernel_prefix in k:
-                return int(v)
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+    except (OSError, ValueError):
+        return None, "no profiles/pmc_current.json"
+    if d.get("so_sha256") != so_sha256(lib_path):
+        return None, "profiles/pmc_current.json was collected on another build of the library (sha256 differs)"
+    w = d.get("workloads", {}).get(workload)
+    if not w:
+        return None, "profiles/pmc_current.json has no entry for %s" % workload
+    return w, "profiles/pmc_current.json (rocprofv3 --pmc, separate passes), library sha256 %s" % d["so_sha256"][:16]
 
 
-def valu_counters(kernel_prefix):
-    """SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU per launch of the dominant kernel from the same committed PMC passes."""
+def hbm_bytes(p):
+    """HBM bytes per launch: 2 x FETCH_SIZE (gfx950 correction of the guide) + WRITE_SIZE, both reported in KiB."""
+    if not p or "FETCH_SIZE" not in p or "WRITE_SIZE" not in p:
+        return None
+    return int(2 * p["FETCH_SIZE"] * 1024 + p["WRITE_SIZE"] * 1024)
+
+
+def occupancy_pass(workload):
+    """The instrumented library on one frame of `workload` in a process of its own (one library per process)."""
+    occ_lib = os.path.join(ROOT, "mallie_amd", "libmallie_mgpu_occ.so")
+    if not os.path.exists(occ_lib):
+        return None
+    env = dict(os.environ, MALLIE_MGPU_LIB=occ_lib)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
     try:
-        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-            d = json.load(f)
-        for k, v in d.get("sq_per_launch", {}).items():
-            if kernel_prefix in k:
-                return v
-    except (OSError, ValueError, KeyError):
+        r = subprocess.run([sys.executable, "-m", "mallie_amd.occupancy", workload], cwd=ROOT, env=env, capture_output=True,
+                           text=True, timeout=300)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        o = json.loads(line)
+    except (subprocess.SubprocessError, IndexError, ValueError, OSError):
+        return None
+    out = {k: (round(o[k], 4) if o[k] is not None else None) for k in ("node_frac", "tri_frac", "shade_frac")}
+    wsum = usum = 0.0
+    for body, trips in (("node", o["node_trips"]), ("tri", o["tri_trips"]), ("shade", o["shade_steps"])):
+        if o[body + "_frac"] is not None:
+            wsum += trips * BODY_WEIGHT[body]
+            usum += trips * BODY_WEIGHT[body] * o[body + "_frac"]
+    out["weighted"] = round(usum / wsum, 4) if wsum else None
+    out["source"] = ("instrumented pass in this run (libmallie_mgpu_occ.so = same sources + -DMGPU_OCC=1, one frame, not timed; ~1 step "
+                     "in %d booked: node %d, tri %d, shade %d steps); active lanes / 64 per trip of each body's loop, `weighted` by "
+                     "trips x nominal instructions per trip (%s)" % (o["sample_every"], o["node_steps"], o["tri_steps"], o["shade_steps"],
+                                                                      BODY_WEIGHT))
+    return out
+
+
+def cpu_info():
+    model, sockets, cores_per_socket = "unknown", 1, None
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        m = re.search(r"Model name:\s*(.+)", txt)
+        if m:
+            model = m.group(1).strip()
+        m = re.search(r"Socket\(s\):\s*(\d+)", txt)
+        if m:
+            sockets = int(m.group(1))
+        m = re.search(r"Core\(s\) per socket:\s*(\d+)", txt)
+        if m:
+            cores_per_socket = int(m.group(1))
+    except (OSError, subprocess.SubprocessError):
         pass
-    return None
+    physical = sockets * cores_per_socket if cores_per_socket else None
+    return model, physical
 
 
-def load_scene_arrays():
-    g = np.load(os.path.join(ROOT, "tests", "golden", "cornell_obj.npz"))
-    return g["verts"].astype(np.float64), g["faces"], g["matIDs"], g["normals"]
-
-
-def cpu_baseline(frame, plane, mpl, gpu_frame=None):
+def cpu_baseline(cfg, frame, plane, mpl, pass_base, gpu_frame=None):
     """The oracle (this repo's CPU restatement, pinned bit-exact to the reference) timed on the host cores on a bounded
-    sample of the same workload: the same 1920x1080 frame, same path length and seeding, `spp_sample` passes."""
+    sample of the same workload: whole 1920x1080 frames, same path length and seeding."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O  # the checker -- used here only as the timed CPU baseline
-    verts, faces, mats, normals = load_scene_arrays()
+    from mallie_amd import workloads
+    verts, faces, mats, normals = workloads.mesh_arrays(cfg)
     nodes, idx, _ = O.bvh_build(verts, faces)
     osc = O.OracleScene(verts, faces, mats, normals, None, nodes, idx)
-    cores = len(os.sched_getaffinity(0))
-    W, H = WORKLOAD["width"], WORKLOAD["height"]
-    # warm-up band (thread start-up, page faults), then the sample: whole frames of the workload until >= ~10 s of
-    # wall time or 4 frames, whichever comes first
-    osc.render(frame, W, H, mpl, 1, plane, O.RNG_HASH, seed=WORKLOAD["seed"], window=(0, 512, W, 576), nthreads=cores)
-    spp_sample, dt, rays = 0, 0.0, 0
-    same = None
-    while dt < 10.0 and spp_sample < 4 * WORKLOAD["spp"]:
+    threads = len(os.sched_getaffinity(0))
+    model, physical = cpu_info()
+    W, H, spp = cfg["width"], cfg["height"], cfg["spp"]
+    osc.render(frame, W, H, mpl, 1, plane, O.RNG_HASH, seed=cfg["seed"], window=(0, 512, W, 576), nthreads=threads)  # warm-up band
+    done, dt, rays, same = 0, 0.0, 0, None
+    while dt < 10.0 and done < 4 * spp:
         t0 = time.perf_counter()
-        img, _, st, _ = osc.render(frame, W, H, mpl, WORKLOAD["spp"], plane, O.RNG_HASH, seed=WORKLOAD["seed"],
-                                   pass_base=spp_sample, nthreads=cores)
+        img, _, st, _ = osc.render(frame, W, H, mpl, spp, plane, O.RNG_HASH, seed=cfg["seed"], pass_base=pass_base + done,
+                                   nthreads=threads)
         dt += time.perf_counter() - t0
-        if spp_sample == 0 and gpu_frame is not None:
-            # the first sample frame IS the benchmarked frame (same seed, passes 0..15): the checker's image against the GPU's
+        if done == 0 and gpu_frame is not None:
+            # the first sample frame IS the last benchmarked frame (same seed and passes): the checker's image against the GPU's
             same = bool(img.tobytes() == gpu_frame.tobytes())
         rays += st["real_rays"]
-        spp_sample += WORKLOAD["spp"]
-    st = dict(real_rays=rays)
-    return dict(gpu_frame_byte_equal=same, value=round(st["real_rays"] / dt / 1e6, 3), unit="Mrays/s", cores=cores, kind="port",
-                sample="%dx%d frames of the workload, %d passes in total (%d spp each), maxPathLength %d, OpenMP %d "
-                              "threads, %.1f s wall, %.0f ms/pass" % (W, H, spp_sample, WORKLOAD["spp"], mpl, cores, dt,
-                                                                      1e3 * dt / spp_sample))
+        done += spp
+    return dict(gpu_frame_byte_equal=same, value=round(rays / dt / 1e6, 3), unit="Mrays/s", cores=threads, kind="port",
+                cpu_model=model, physical_cores=physical, threads=threads,
+                sample="%dx%d frames of the workload, %d passes in total (%d spp each), maxPathLength %d, OpenMP %d threads "
+                       "(all logical CPUs of the host: %s physical cores, %s), %.1f s wall, %.0f ms/pass"
+                       % (W, H, done, spp, mpl, threads, physical, model, dt, 1e3 * dt / done))
 
 
 def flush_c_stdio():
@@ -111,12 +173,71 @@ def flush_c_stdio():
     sys.stdout.flush()
 
 
+def time_frames(scene, render, steps, sync):
+    """ms per frame (wall), mean kernel ms (HIP events on the launch stream), work counters of `steps` frames."""
+    scene.stats_read(reset=True)
+    scene.timing_enable(True)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        render(k)
+    sync()
+    wall = time.perf_counter() - t0
+    kernel_ms, launches = scene.timing_read()
+    scene.timing_enable(False)
+    st = scene.stats_read(reset=True)
+    return 1e3 * wall / steps, kernel_ms / max(launches, 1), st
+
+
+def extra_config(key, lib_path, torch, steps=5):
+    """One single-GPU line for an HBM-resident BASELINE configuration (C3 / C4): frames rendered into HBM, HIP-event kernel
+    time, algorithmic bytes, and the counter-based HBM fraction when the committed PMC passes match this library."""
+    import mallie_amd as M
+    from mallie_amd import workloads
+    cfg = workloads.CONFIGS[key]
+    sc = workloads.make_scene(cfg)
+    W, H, mpl, spp = cfg["width"], cfg["height"], cfg["bounces"] + 1, cfg["spp"]
+    frame = workloads.camera(cfg)
+    plane = sc.plane()
+    buf = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+
+    def render(k):
+        sc.render_strips_device(frame, W, H, buf.data_ptr(), H, maxPathLength=mpl, passes=spp, plane=plane, seed=cfg["seed"],
+                                pass_base=k * spp)
+    for k in range(2):
+        render(k)
+    torch.cuda.synchronize()
+    ms, kms, st = time_frames(sc, render, steps, torch.cuda.synchronize)
+    rays = st["real_rays"] / steps
+    alg = (st["nodes"] * B_NODE + st["tris"] * B_TRI + st["real_rays"] * B_RAY) / steps
+    p, why = pmc_for(key, lib_path)
+    traffic = hbm_bytes(p)
+    out = {"config": workloads.describe(cfg, len(workloads.mesh_arrays(cfg)[1]) if "grid" not in cfg else cfg["grid"] ** 2 * 968),
+           "n_gpus": 1, "steps": steps, "ms_per_frame": round(ms, 3), "kernel_avg_ms": round(kms, 3),
+           "value": round(rays / ms / 1e3, 1), "unit": "Mrays/s", "rays_per_frame": int(rays),
+           "nodes_per_ray": round(st["nodes"] / st["real_rays"], 3), "tris_per_ray": round(st["tris"] / st["real_rays"], 3),
+           "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                        "achieved": round(traffic / (kms * 1e-3) / 1e9, 1) if traffic else None,
+                        "frac": round(traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                        "traffic": traffic, "pmc_source": why,
+                        "algorithmic_vs_hbm": {"bytes_per_launch": int(alg), "GBps": round(alg / (kms * 1e-3) / 1e9, 1),
+                                               "ratio_to_peak": round(alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                        "valu_issue_busy": (round(p["SQ_ACTIVE_INST_VALU"] * 4.0 / (kms * 1e-3 * CLOCK_HZ * N_SIMD), 3)
+                                            if p and "SQ_ACTIVE_INST_VALU" in p else None),
+                        "note": "BVH resident in HBM (wide 128-byte node records + 80-byte triangles through L1/L2). `achieved` = "
+                                "measured HBM bytes (2*FETCH_SIZE + WRITE_SIZE) / kernel time; the algorithmic bytes of SURVEY 8(d) "
+                                "are mostly L1/L2 hits. Neither HBM nor VALU issue is saturated: the walk is bound by dependent "
+                                "L1/L2 round trips (DESIGN.md 7)."}}
+    sc.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the occupancy pass, the read-back timing and extra_configs")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames enqueued concurrently (own stream and buffers each); default 1 on one GPU -- kernel time "
                          "then is what rocprofv3 shows -- and 3 on N > 1, where the RCCL gather and the end of a launch "
@@ -126,6 +247,7 @@ def main():
     import torch
     import torch.distributed as dist
     import mallie_amd as M
+    from mallie_amd import workloads
     from mallie_amd.frame import FrameRenderer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,14 +271,15 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    W, H = WORKLOAD["width"], WORKLOAD["height"]
-    mpl, spp = WORKLOAD["bounces"] + 1, WORKLOAD["spp"]
-    verts, faces, mats, normals = load_scene_arrays()
+    cfg = workloads.CONFIGS["c2"]
+    W, H = cfg["width"], cfg["height"]
+    mpl, spp = cfg["bounces"] + 1, cfg["spp"]
+    verts, faces, mats, normals = workloads.mesh_arrays(cfg)
     scene = M.Scene(verts, faces, mats, normals, None, device=local_rank)  # BVH: this library's host builder
-    frame = M.camera_frame(WORKLOAD["eye"], WORKLOAD["lookat"], width=W, height=H)
-    plane = scene.plane() if WORKLOAD["plane"] else None
+    frame = workloads.camera(cfg)
+    plane = scene.plane() if cfg["plane"] else None
     fif = args.frames_in_flight if args.frames_in_flight > 0 else (1 if world == 1 else 3)
-    fr = FrameRenderer(scene, frame, W, H, mpl, spp, plane, WORKLOAD["seed"], rank, world, dev, frames_in_flight=fif,
+    fr = FrameRenderer(scene, frame, W, H, mpl, spp, plane, cfg["seed"], rank, world, dev, frames_in_flight=fif,
                        force_collective=force_gather)
 
     def sync_all():
@@ -165,22 +288,24 @@ def main():
             dist.barrier(device_ids=[local_rank])
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        fr.render()
+    for k in range(args.warmup):
+        fr.render(pass_base=k * spp)
     sync_all()
     flush_c_stdio()  # the communicators exist by now: whatever RCCL had to say goes out before the measurement
     scene.stats_read(reset=True)
     scene.timing_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        fr.render()
+    for k in range(args.steps):
+        fr.render(pass_base=k * spp)  # frame k = passes [k*spp, (k+1)*spp): the next 16 samples per pixel, not the same ones
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = scene.timing_read()
+    scene.timing_enable(False)
     st = scene.stats_read(reset=True)
+    last_pass_base = (args.steps - 1) * spp
 
     # max elapsed over ranks, sum of work over ranks
     red = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -194,49 +319,95 @@ def main():
     rays, nodes, tris, trace_calls, paths = [float(x) for x in work.tolist()]
 
     if rank == 0:
+        lib_path = M.lib_path()
         ms_per_step = 1e3 * elapsed / args.steps
         value = rays / elapsed / 1e6
-        # roofline of the dominant kernel (k_render) on THIS rank: algorithmic bytes of one launch / its mean duration
+        # the dominant kernel (k_render_sm) on THIS rank: algorithmic bytes of one launch / its mean duration
         alg_bytes_launch = (st["nodes"] * B_NODE + st["tris"] * B_TRI + st["real_rays"] * B_RAY) / max(launches, 1)
         kernel_avg_ms = float(kern.item())
-        traffic = hbm_traffic("k_render_sm") if world == 1 else None
-        achieved = alg_bytes_launch / (kernel_avg_ms * 1e-3) / 1e9 if kernel_avg_ms > 0 else 0.0
+        ksec = kernel_avg_ms * 1e-3
+        p, why = pmc_for("c2", lib_path) if world == 1 else (None, "PMC passes are single-GPU")
+        traffic = hbm_bytes(p)
+        alg_gbs = alg_bytes_launch / ksec / 1e9 if ksec > 0 else 0.0
+        ginst = p["SQ_INSTS_VALU"] / ksec / 1e9 if p and "SQ_INSTS_VALU" in p and ksec > 0 else None
+        roof = {"bound": "valu", "unit": "Ginst/s", "peak": round(VALU_PEAK_GINST, 1),
+                "achieved": round(ginst, 1) if ginst else None, "frac": round(ginst / VALU_PEAK_GINST, 4) if ginst else None,
+                "traffic": traffic, "kernel": "k_render_sm", "kernel_avg_ms": round(kernel_avg_ms, 3), "pmc_source": why,
+                "valu": None, "hbm": None,
+                "algorithmic_vs_hbm": {"bytes_per_launch": int(alg_bytes_launch), "GBps": round(alg_gbs, 1),
+                                       "ratio_to_peak": round(alg_gbs / HBM_PEAK_GBS, 4),
+                                       "note": "SURVEY 8(d): nodes*64 + tris*76 + rays*80 over the kernel time against 8 TB/s. Not a "
+                                               "roofline here: this scene's BVH is staged in LDS and those bytes never leave the CU"},
+                "note": "bound = fp64 VALU issue: `achieved` = executed VALU wave-instructions (SQ_INSTS_VALU per launch) / mean kernel "
+                        "time of THIS run (HIP events on the launch stream); `peak` = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 fp64 "
+                        "instruction. `valu.issue_busy` = SQ_ACTIVE_INST_VALU x 4 cycles / SIMD cycles; `lane_occupancy` = active lanes "
+                        "per executed instruction, measured in this run; their product is the useful share of the issue peak."}
+        if p and "SQ_ACTIVE_INST_VALU" in p and ksec > 0:
+            roof["valu"] = {"insts_per_launch": int(p["SQ_INSTS_VALU"]),
+                            "wave_insts_per_ray": round(p["SQ_INSTS_VALU"] / max(st["real_rays"] / max(launches, 1), 1), 2),
+                            "issue_busy": round(p["SQ_ACTIVE_INST_VALU"] * 4.0 / (ksec * CLOCK_HZ * N_SIMD), 3),
+                            "salu_insts_per_launch": int(p["SQ_INSTS_SALU"]) if "SQ_INSTS_SALU" in p else None}
+        if traffic and ksec > 0:
+            roof["hbm"] = {"measured_GBps": round(traffic / ksec / 1e9, 1), "frac_of_peak": round(traffic / ksec / 1e9 / HBM_PEAK_GBS, 4),
+                           "fetch_bytes": int(2 * p["FETCH_SIZE"] * 1024), "write_bytes": int(p["WRITE_SIZE"] * 1024),
+                           "needed_write_bytes": int(12 * W * H * spp),
+                           "note": "2*FETCH_SIZE + WRITE_SIZE per launch of k_render_sm; needed_write = the per-pass radiance planes it produces"}
         out = {
             "metric": "Mrays/sec + ms/frame at 1920x1080, cornellbox_suzanne, 1/2/4/8 GPU",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "cornellbox_suzanne.obj mesh (980 tris, 205-node binned-SAH BVH), 1920x1080, 16 spp, "
-                                   "4 bounces (maxPathLength 5), plane on, eye (0,0,20), per-(pixel,pass) xorshift128 "
-                                   "seeding, seed 1; 1 step = 1 frame",
+            "config": {"workload": workloads.describe(cfg, len(faces)) + "; 1 step = 1 frame = the next %d passes per pixel "
+                                   "(pass_base advances by %d per step)" % (spp, spp),
                        "parallelism": "replicated scene, interleaved 8-row strips x%d, 1 RCCL gather/frame" % world
                                       if world > 1 else "single GPU, persistent-threads kernel",
                        "frames_in_flight": fif,
                        "rays_per_frame": int(rays / args.steps), "trace_calls_per_frame": int(trace_calls / args.steps),
                        "nodes_per_ray": round(nodes / rays, 3), "tris_per_ray": round(tris / rays, 3),
                        "mtrace_calls_per_s": round(trace_calls / elapsed / 1e6, 2)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_render_sm", "kernel_avg_ms": round(kernel_avg_ms, 3),
-                         "algorithmic_bytes_per_launch": int(alg_bytes_launch),
-                         "note": "achieved = algorithmic bytes (nodes*64 + tris*76 + rays*80, SURVEY 8(d)) / kernel time, "
-                                 "priced against HBM peak as the contract asks. This scene's 92 KB BVH is staged in LDS, so "
-                                 "those bytes are served on-chip (frac can exceed 1); measured HBM traffic is `traffic` "
-                                 "(radiance planes + frame, rocprofv3 PMC) = %s GB/s. What bounds the kernel is VALU issue "
-                                 "(`valu.issue_busy_frac` of the SIMD issue slots, profiles/). HBM-resident scenes: DESIGN.md 7."
-                                 % (round(traffic / (kernel_avg_ms * 1e-3) / 1e9, 1) if traffic else "n/a")},
+            "roofline": roof,
         }
-        sqc = valu_counters("k_render_sm") if world == 1 else None
-        if sqc and kernel_avg_ms > 0:
-            # what actually bounds the kernel: VALU issue.  SQ_ACTIVE_INST_VALU counts 4-cycle issue slots; 256 CUs x 4 SIMDs
-            # at the 2.4 GHz peak clock (measured under this load: 2.35-2.39 GHz, profiles/microbench/RESULTS.md)
-            out["roofline"]["valu"] = {
-                "insts_per_launch": sqc.get("SQ_INSTS_VALU"), "insts_per_ray": round(sqc.get("SQ_INSTS_VALU", 0) * 64.0 / max(st["real_rays"] / max(launches, 1), 1), 1),
-                "issue_busy_frac": round(sqc.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / (kernel_avg_ms * 1e-3 * 2.4e9 * 1024), 3),
-                "note": "from the committed rocprofv3 PMC pass (profiles/); wave-instructions x 64 lanes per real ray"}
+        if world == 1 and not args.no_extras:
+            occ = occupancy_pass("c2")
+            roof["lane_occupancy"] = occ
+            if occ and occ.get("weighted") and roof.get("valu"):
+                roof["useful_frac"] = round(roof["valu"]["issue_busy"] * occ["weighted"], 4)
+            # SURVEY 8(d)'s frame = passes + ONE read-back: the same frames, each followed by its copy to pinned host memory
+            host = torch.empty((H, W, 3), dtype=torch.float32).pin_memory()
+            fr1 = FrameRenderer(scene, frame, W, H, mpl, spp, plane, cfg["seed"], 0, 1, dev)
+
+            def render_rb(k):
+                host.copy_(fr1.render(pass_base=k * spp), non_blocking=True)
+                torch.cuda.synchronize(dev)  # the caller owns the frame before the next one starts (mallie::Render semantics)
+            render_rb(0)
+            ms_rb, _, _ = time_frames(scene, render_rb, args.steps, lambda: torch.cuda.synchronize(dev))
+            out["frame_with_readback"] = {"ms_per_frame": round(ms_rb, 3), "value": round(rays / args.steps / ms_rb / 1e3, 2),
+                                          "unit": "Mrays/s", "note": "same frames, each followed by its 24.9 MB device-to-host copy "
+                                          "(pinned memory) and a synchronisation; SURVEY 8(d) frame definition"}
+            # the cost-ordered tile hand-out predicts a frame from the previous one: the same run without it
+            os.environ["MGPU_TILE_ORDER"] = "0"
+            fr1.render(pass_base=0)
+            ms_no, _, _ = time_frames(scene, lambda k: fr1.render(pass_base=k * spp), args.steps, lambda: torch.cuda.synchronize(dev))
+            del os.environ["MGPU_TILE_ORDER"]
+            out["tile_order_off"] = {"ms_per_frame": round(ms_no, 3), "note": "MGPU_TILE_ORDER=0 (image-order hand-out), same frames"}
+        gpu_frame = None
         if world == 1 and not args.no_cpu_baseline:
-            gpu_frame = fr.frame_buffer.detach().cpu().numpy()  # the last timed frame (pass_base 0), after the timed region
-            out["cpu_baseline"] = cpu_baseline(frame, plane, mpl, gpu_frame)
+            # the last timed frame (pass_base of the last step), re-rendered after the timed region so that the extras above
+            # cannot have touched it
+            fr.render(pass_base=last_pass_base)
+            torch.cuda.synchronize(dev)
+            gpu_frame = fr.frame_buffer.detach().cpu().numpy()
+        if world == 1 and not args.no_extras:
+            del fr
+            extras = {}
+            for key in ("c3", "c4"):
+                try:
+                    extras[key] = extra_config(key, lib_path, torch)
+                except Exception as e:  # an extra line must never take the headline down
+                    extras[key] = {"error": repr(e)}
+            out["extra_configs"] = extras
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, frame, plane, mpl, last_pass_base, gpu_frame)
     else:
         out = None
     if world > 1 or force_gather:

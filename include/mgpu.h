@@ -179,6 +179,18 @@ int mgpu_stats_read(MgpuScene *scene, MgpuStats *out, int reset);
  * -DMGPU_UTIL experiment builds). */
 int mgpu_debug_words(MgpuScene *scene, unsigned long long *out32);
 
+/* Active-lane accounting of the render kernel's three bodies (NODE: box tests, TRI: triangle tests, SHADE: the rest of a
+ * PathTrace iteration), accumulated like the work counters (mgpu_stats_read resets them too).  The kernel books about one
+ * step in `sample_every` (chosen by the low bits of the shader clock, whatever the step does): `*_trips` = trips of the
+ * body's loop the wave made on the booked steps, `*_lanes` = lanes active summed over those trips, so
+ * lanes / (64 * trips) is the body's active-lane fraction; `node_steps` / `tri_steps` / `shade_steps` = steps booked
+ * (SHADE has one trip per step).  Synchronises the device. */
+typedef struct {
+  uint64_t node_trips, node_lanes, tri_trips, tri_lanes, shade_steps, shade_lanes, node_steps, tri_steps;
+  uint32_t sample_every, pad_;
+} MgpuOccupancy;
+int mgpu_occupancy_read(MgpuScene *scene, MgpuOccupancy *out);
+
 /* Diagnostic (MGPU_WAVE_LOG=1 + -DMGPU_UTIL builds): 8 words per wave, `out` holds 8 * n_waves words:
  * {start, end, time the work cursor was found dry (100 MHz device ticks), XCC id | rays << 8,
  *  rays traced after dry, lanes alive at dry | their pathLength sum << 16, NODE | TRI << 20 | SHADE << 40 steps after dry,

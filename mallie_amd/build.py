@@ -11,6 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmallie_mgpu.so")
+LIB_OCC = os.path.join(HERE, "libmallie_mgpu_occ.so")
 SOURCES = ["mgpu_kernels.hip", "mgpu_render_sm.hip", "mgpu_trace_sm.hip", "mgpu_render_env.hip", "mgpu_bvh_build.hip", "mgpu_api.hip", "host/bvh_build.cc", "host/camera.cc", "host/scene_render.cc",
            "host/mesh_io.cc"]
 HEADERS = ["mgpu_device.hpp", "mgpu_kernels.hpp", "host/mesh_io.hpp", os.path.join("..", "..", "include", "mgpu.h"),
@@ -46,15 +47,23 @@ def build_variant(out_path, extra_flags):
 
 
 def build(force=False, verbose=False):
-    if not force and not is_stale():
+    """libmallie_mgpu.so (the product) and libmallie_mgpu_occ.so (the same sources with -DMGPU_OCC=1: the render kernel's
+    active-lane accounting, used only by bench.py's occupancy pass -- python -m mallie_amd.occupancy), side by side."""
+    if not force and not is_stale() and os.path.exists(LIB_OCC) and os.path.getmtime(LIB_OCC) >= os.path.getmtime(LIB):
         return LIB
-    cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building %s" % LIB)
-    if verbose:
-        sys.stderr.write(r.stderr)
+    srcs = [os.path.join(CSRC, f) for f in SOURCES]
+    procs = [(out, subprocess.Popen([hipcc()] + FLAGS + extra + ["-o", out] + srcs, stdout=subprocess.PIPE,
+                                    stderr=subprocess.STDOUT, text=True))
+             for out, extra in ((LIB + ".tmp", []), (LIB_OCC, ["-DMGPU_OCC=1"]))]
+    for out, p in procs:
+        log, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(log)
+            raise RuntimeError("hipcc failed building %s" % out)
+        if verbose:
+            sys.stderr.write(log)
+    os.replace(LIB + ".tmp", LIB)  # the product library last: the variant is never newer than it is stale
+    os.utime(LIB_OCC, None)
     return LIB
 
 

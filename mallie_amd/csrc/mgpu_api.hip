@@ -1078,7 +1078,27 @@ int mgpu_debug_words(MgpuScene *s, unsigned long long *out32) {
   int rc = set_device(s);
   if (rc) return rc;
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out32, s->p_stats, sizeof(unsigned long long) * kStatWords, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out32, s->p_stats, sizeof(unsigned long long) * 32, hipMemcpyDeviceToHost));
+  return MGPU_OK;
+}
+
+int mgpu_occupancy_read(MgpuScene *s, MgpuOccupancy *out) {
+  if (!s || !out) return fail(MGPU_ERR_INVALID, "NULL argument");
+  int rc = set_device(s);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  unsigned long long w[kStatWords];
+  HIP_TRY(hipMemcpy(w, s->p_stats, sizeof(w), hipMemcpyDeviceToHost));
+  out->node_trips = w[kOccNodeTrips];
+  out->node_lanes = w[kOccNodeLanes];
+  out->tri_trips = w[kOccTriTrips];
+  out->tri_lanes = w[kOccTriLanes];
+  out->shade_steps = w[kOccShadeSteps];
+  out->shade_lanes = w[kOccShadeLanes];
+  out->node_steps = w[kOccNodeBooked];
+  out->tri_steps = w[kOccTriBooked];
+  out->sample_every = (uint32_t)kSampleEvery;
+  out->pad_ = 0;
   return MGPU_OK;
 }
 

@@ -11,12 +11,19 @@ namespace mgpu {
 constexpr int kBlock = 256;      // 4 waves per workgroup
 constexpr int kChunkTiles = 2;   // k_render v1: 8x8-pixel tiles handed to a wave per global-counter fetch
 constexpr int kShards = 8;       // k_render_sm: work counters per launch = XCDs of an MI355X
+constexpr int kSampleEvery = 8;  // k_render_sm: lane-occupancy accounting on every 8th NODE / TRI / SHADE step
 
 // device-side statistics words (unsigned long long each)
 enum : int { kStatTraceCalls = 0, kStatRays = 1, kStatNodes = 2, kStatTris = 3, kStatPaths = 4,
               // wave-level utilisation probes, filled only by -DMGPU_UTIL builds (scratch experiments)
               kUtilNodeSteps = 8, kUtilNodeLanes = 9, kUtilTriSteps = 10, kUtilTriLanes = 11, kUtilOuter = 12,
-              kUtilTraceLanes = 13, kUtilShadeLanes = 14, kUtilGenLanes = 15, kStatWords = 32 };
+              kUtilTraceLanes = 13, kUtilShadeLanes = 14, kUtilGenLanes = 15,
+              // k_render_sm, always on: the active-lane fraction of its three bodies measured in the run itself.  One step in
+              // kSampleEvery (picked by the shader clock's low bits) is booked: wave-level trips of the body's loop and the
+              // lanes active summed over those trips (a few compares after the loop; SHADE: the step and the lanes in it),
+              // and the number of steps booked per body.
+              kOccNodeTrips = 32, kOccNodeLanes = 33, kOccTriTrips = 34, kOccTriLanes = 35, kOccShadeSteps = 36,
+              kOccShadeLanes = 37, kOccNodeBooked = 38, kOccTriBooked = 39, kStatWords = 40 };
 
 struct RenderParams {
   double frame[12]; // origin, corner, du, dv  (Camera::BuildCameraFrame, camera.cc:40-220)

@@ -89,6 +89,9 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 #ifndef MGPU_WIDE_PER_STEP
 #define MGPU_WIDE_PER_STEP 3 // interior nodes entered per NODE step with the BVH in HBM (two box tests each)
 #endif
+#ifndef MGPU_OCC
+#define MGPU_OCC 0 // 1: active-lane accounting (kOcc* words); built into libmallie_mgpu_occ.so only, see mallie_amd/build.py
+#endif
 #ifndef MGPU_SHARED_LEAVES
 #define MGPU_SHARED_LEAVES 1
 #endif
@@ -163,9 +166,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(home_shard)); // which XCD this workgroup runs on (0..7)
   home_shard &= 7u;
   // LDS cursor: hi32 = end, lo32 = next, both (shard << 28) | index of the item inside its shard's part
+  __shared__ uint32_t s_occ[8]; // occupancy accounting of the workgroup: kOccNodeTrips.. in that order
   __shared__ unsigned char s_owner[BLOCK]; // TRI step with shared leaves: lane of the k-th open leaf, per wave
   __shared__ unsigned long long wg_cursor;
   __shared__ uint32_t wg_lock, wg_shard_off, wg_dry;
+#if MGPU_OCC
+  if (threadIdx.x < 8) s_occ[threadIdx.x] = 0u;
+#endif
   if (threadIdx.x == 0) {
     wg_cursor = 0ull;
     wg_lock = 0u;
@@ -197,6 +204,29 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
   uint32_t tri_cur = 0, tri_end = 0;
   // ---- counters -------------------------------------------------------------------------------------------------
   uint32_t n_rays = 0, n_nodes = 0, n_tris = 0, trace_calls = 0, paths = 0;
+  // Occupancy accounting (kOcc* in mgpu_kernels.hpp): a step is booked when the low bits of the shader clock say so (one
+  // step in kSampleEvery on average, independent of what the step does), into LDS words of the workgroup -- nothing is
+  // kept in registers between steps.  Trips of a body's loop = the largest per-lane iteration count `d`, lanes over those
+  // trips = the sum of the counts; both from one ballot per possible count.
+#if MGPU_OCC
+  auto occ_sampled = [&]() -> bool { return (__builtin_amdgcn_s_memtime() & (unsigned long long)((kSampleEvery - 1) << 2)) == 0ull; };
+#else
+  auto occ_sampled = [&]() -> bool { return false; }; // product build: the accounting folds away (it costs 3-4 % in registers)
+#endif
+  auto occ_book = [&](uint32_t d, int max_d, int word) {
+    uint32_t trips = 0, lanes = 0;
+    for (int k = 1; k <= max_d; ++k) {
+      const unsigned long long b = __ballot(d >= (uint32_t)k);
+      if (b == 0ull) break;
+      trips += 1u;
+      lanes += (uint32_t)__popcll(b);
+    }
+    if (lane == 0) {
+      atomicAdd(&s_occ[word], trips);
+      atomicAdd(&s_occ[word + 1], lanes);
+      atomicAdd(&s_occ[6 + (word >> 1)], 1u); // steps booked
+    }
+  };
   bool probe_on = false;
 #ifdef MGPU_UTIL
   uint32_t u_node = 0, u_tri = 0, u_shade = 0, u_shade_lanes = 0;
@@ -237,6 +267,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
       // ================================ NODE step ================================
       MGPU_TICK();
       const bool all_plain = __ballot(st == ST_NODE && !ray_plain) == 0ull; // wave-uniform
+      const bool occ_sample = occ_sampled();
+      const uint32_t occ_n0 = MGPU_OCC ? n_nodes : 0u;
       if (st == ST_NODE) {
 #ifdef MGPU_UTIL
         if (lane == __ffsll((long long)mN) - 1) u_node++;
@@ -304,6 +336,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
           else if (r == WT_DONE) st = ST_SHADE;
         }
       }
+      if (occ_sample) occ_book(LDS_SCENE ? n_nodes - occ_n0 : (n_nodes - occ_n0) >> 1, LDS_SCENE ? MGPU_NODES_PER_STEP : MGPU_WIDE_PER_STEP,
+                               0);
 #ifdef MGPU_UTIL
       if (cyc_dry) ++steps_n;
 #endif
@@ -319,6 +353,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
       // merged candidate.  A NaN t (which that loop would accept, and after which it accepts everything) cannot be
       // merged this way: a step that produces one is thrown away and redone in order by the owners alone.
       bool shared_done = false;
+      const bool occ_sample = occ_sampled();
+      const uint32_t occ_t0 = MGPU_OCC ? tri_cur : 0u;
 #if MGPU_SHARED_LEAVES
       if (cT <= 32) {
         const int sh = cT <= MGPU_SHARE8_MAX ? 3 : (cT <= 16 ? 2 : 1), m = 1 << sh;
@@ -409,6 +445,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
             tri_cur += done;
           }
           shared_done = true;
+          if (occ_sample) // iterations of this lane as one of the m workers of its leaf
+            occ_book(serving ? min(((last - first) + (uint32_t)(m - 1 - sub)) >> sh, (uint32_t)MGPU_TRIS_PER_STEP) : 0u,
+                     MGPU_TRIS_PER_STEP, 2);
         } else {
           if (serving) n_tris -= min(((last - first) + (uint32_t)(m - 1 - sub)) >> sh, (uint32_t)MGPU_TRIS_PER_STEP); // not counted twice
         }
@@ -474,6 +513,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
           }
         }
       }
+      if (occ_sample && !shared_done) occ_book(tri_cur - occ_t0, MGPU_TRIS_PER_STEP, 2);
       if (st == ST_TRI && tri_cur == tri_end) st = (LDS_SCENE ? sp < 0 : sp == 0) ? ST_SHADE : ST_NODE;
 #ifdef MGPU_UTIL
       if (cyc_dry) ++steps_t;
@@ -485,6 +525,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
       // Three parts: (1) lanes in SHADE finish their ray; (2) ALL lanes of the wave run the pixel hand-out so the
       // work cursor stays wave-uniform; (3) lanes in SHADE start their next path / arm their next traversal.
       const bool shade_lane = (st == ST_SHADE);
+#if MGPU_OCC
+      if (occ_sampled() && lane == 0) {
+        atomicAdd(&s_occ[4], 1u);
+        atomicAdd(&s_occ[5], (uint32_t)cS);
+      }
+#endif
       bool path_done = false, want_pixel = false;
       if (shade_lane) {
 #ifdef MGPU_UTIL
@@ -781,6 +827,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
     atomicAdd(&P.stats[kStatTris], v3_);
     atomicAdd(&P.stats[kStatPaths], v4);
   }
+#if MGPU_OCC
+  __syncthreads();
+  if (threadIdx.x < 8 && P.stats && s_occ[threadIdx.x]) atomicAdd(&P.stats[kOccNodeTrips + threadIdx.x], (unsigned long long)s_occ[threadIdx.x]);
+#endif
 #ifdef MGPU_UTIL
   if (u_hist)
     for (int k = 0; k < 4; ++k)

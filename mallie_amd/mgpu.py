@@ -85,6 +85,8 @@ def load_library():
     L.mgpu_stats_read.restype = i32
     L.mgpu_debug_words.argtypes = [vp, vp]
     L.mgpu_debug_words.restype = i32
+    L.mgpu_occupancy_read.argtypes = [vp, vp]
+    L.mgpu_occupancy_read.restype = i32
     L.mgpu_render_panoramic.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, u64, u32, vp, vp,
                                         C.POINTER(Stats)]
     L.mgpu_render_panoramic.restype = i32
@@ -314,6 +316,19 @@ class Scene:
         st = Stats()
         _check(load_library().mgpu_stats_read(self.h, C.byref(st), 1 if reset else 0), "mgpu_stats_read")
         return st.as_dict()
+
+    def occupancy(self):
+        """Active-lane accounting of the render kernel since the last stats reset (mgpu_occupancy_read): dict with the raw
+        counters and the three fractions node / tri / shade (None where nothing was booked)."""
+        w = np.zeros(9, "<u8")
+        _check(load_library().mgpu_occupancy_read(self.h, _p(w)), "mgpu_occupancy_read")
+        k = ("node_trips", "node_lanes", "tri_trips", "tri_lanes", "shade_steps", "shade_lanes", "node_steps", "tri_steps")
+        d = {n: int(v) for n, v in zip(k, w[:8])}
+        d["sample_every"] = int(w[8] & 0xFFFFFFFF)
+        frac = lambda lanes, trips: (lanes / (64.0 * trips)) if trips else None
+        d["node_frac"], d["tri_frac"] = frac(d["node_lanes"], d["node_trips"]), frac(d["tri_lanes"], d["tri_trips"])
+        d["shade_frac"] = frac(d["shade_lanes"], d["shade_steps"])
+        return d
 
     def debug_words(self):
         w = np.zeros(32, "<u8")

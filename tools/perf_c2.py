@@ -57,3 +57,7 @@ if os.environ.get("UTIL"):
             if m.any(): print("   xcc %d: waves %d end median %.1f max %.1f rays/wave %.0f" % (x, m.sum(), np.median(end[m]), end[m].max(), rays[m].mean()))
         # per block
         bl = np.arange(nw) // (nw // 256 if nw >= 256 else 1)
+o = sc.occupancy()
+print("  occupancy (sampled every %d): NODE %.3f  TRI %.3f  SHADE %.3f; booked steps node %d tri %d shade %d; trips/step node %.2f tri %.2f" % (
+    o["sample_every"], o["node_frac"] or 0, o["tri_frac"] or 0, o["shade_frac"] or 0, o["node_steps"], o["tri_steps"], o["shade_steps"],
+    o["node_trips"] / max(1, o["node_steps"]), o["tri_trips"] / max(1, o["tri_steps"])))
