@@ -384,12 +384,17 @@ def main():
             out["frame_with_readback"] = {"ms_per_frame": round(ms_rb, 3), "value": round(rays / args.steps / ms_rb / 1e3, 2),
                                           "unit": "Mrays/s", "note": "same frames, each followed by its 24.9 MB device-to-host copy "
                                           "(pinned memory) and a synchronisation; SURVEY 8(d) frame definition"}
-            # the cost-ordered tile hand-out predicts a frame from the previous one: the same run without it
+            # the cost-ordered tile hand-out predicts a frame from an earlier one: the same frames without it (the switch is
+            # read when a scene is created)
             os.environ["MGPU_TILE_ORDER"] = "0"
-            fr1.render(pass_base=0)
-            ms_no, _, _ = time_frames(scene, lambda k: fr1.render(pass_base=k * spp), args.steps, lambda: torch.cuda.synchronize(dev))
+            scene0 = M.Scene(verts, faces, mats, normals, None, device=local_rank)
             del os.environ["MGPU_TILE_ORDER"]
+            fr0 = FrameRenderer(scene0, frame, W, H, mpl, spp, plane, cfg["seed"], 0, 1, dev)
+            fr0.render(pass_base=0)
+            ms_no, _, _ = time_frames(scene0, lambda k: fr0.render(pass_base=k * spp), args.steps, lambda: torch.cuda.synchronize(dev))
             out["tile_order_off"] = {"ms_per_frame": round(ms_no, 3), "note": "MGPU_TILE_ORDER=0 (image-order hand-out), same frames"}
+            del fr0
+            scene0.close()
         gpu_frame = None
         if world == 1 and not args.no_cpu_baseline:
             # the last timed frame (pass_base of the last step), re-rendered after the timed region so that the extras above

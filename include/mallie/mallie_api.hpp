@@ -11,7 +11,8 @@
 //    per (pixel, pass) instead (MGPU_RNG_HASH, seed settable with mallie::SetRenderSeed), or from a caller-supplied
 //    table of start states (mallie::SetRenderRngTable).  Given the same start states the image is the reference's.
 //  * kMaxPathLength (render.cc:52) is a run-time setting here: mallie::SetMaxPathLength (default 16 = reference).
-//  * Render() with step > 1 (progressive block fill, render.cc:684-696) is not implemented and reports an error.
+//  * Render() with step > 1 (progressive block fill, render.cc:684-696) needs a frame whose sizes are multiples of the
+//    step: for other sizes the reference writes outside the image, and this implementation reports an error instead.
 #ifndef MALLIE_MI355X_API_HPP_
 #define MALLIE_MI355X_API_HPP_
 
@@ -221,6 +222,10 @@ public:
   void BuildCameraFrame(double origin[3], double corner[3], double u[3], double v[3], double fov, const double quat[4],
                         int width, int height);
   Ray GenerateRay(double u, double v) const;
+  // camera.cc:242-329: equirectangular directions of RenderPanoramic (host code; the device kernel evaluates the same
+  // expressions per sample)
+  Ray GenerateEnvRay(double u, double v) const;
+  Ray GenerateStereoEnvRay(double u, double v) const;
 
   double eye_[3], up_[3], lookat_[3];
   double origin_[3], corner_[3], du_[3], dv_[3]; // world space
@@ -238,6 +243,8 @@ public:
     m_c = c;
     m_d = d;
   }
+  // prim-plane.cc:8-44 (host code, float core; the device renderer evaluates the same test per ray)
+  bool intersect(Intersection *info, const Ray &ray);
   float m_a, m_b, m_c, m_d;
 };
 

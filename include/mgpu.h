@@ -115,6 +115,11 @@ int mgpu_trace(MgpuScene *scene, const MgpuRay *rays, size_t n, MgpuIntersection
  * returns its counters and time. */
 int mgpu_trace_device(MgpuScene *scene, const MgpuRay *d_rays, size_t n, MgpuIntersection *d_out, uint8_t *d_hit,
                       void *stream, MgpuStats *stats);
+/* Threading contract of the *_device entry points: calls for one scene come from one host thread at a time (the
+ * host-buffer entry points mgpu_trace / mgpu_render / mgpu_render_step / mgpu_render_panoramic take a lock and may be
+ * called concurrently).  mgpu_render_strips_device keeps its launch scratch per stream (see below);
+ * mgpu_trace_device and mgpu_render_panoramic_device share one set per scene (stack overflow columns of deep trees,
+ * counters, events): successive calls must use ONE stream, or be separated by a synchronisation. */
 
 /* -- Render (render.cc:593-708: per-pixel PathTrace, render.cc:381-456) ---------------------------------------------- */
 /* Renders `passes` passes of the window [x0,x1) x [y0,y1) of a W x H frame and returns, per window pixel, the float32
@@ -130,6 +135,16 @@ int mgpu_render(MgpuScene *scene, const double origin[3], const double corner[3]
                 const double dv[3], int W, int H, int x0, int y0, int x1, int y1, int maxPathLength, int passes,
                 const float plane[4], int rng_mode, const uint32_t *rng_states, uint64_t seed, uint32_t pass_base,
                 float *image_out, int32_t *count_out, MgpuStats *stats);
+
+/* Render() with its `step` argument (render.cc:657-696): step == 1 is mgpu_render with passes = 1 on the whole frame.
+ * step > 1 traces one path per step x step block -- the path of the block's top-left pixel (its jitter, its RNG start
+ * state: TABLE index / HASH pixel id are those of that pixel in the W x H frame) -- and fills the block with its radiance;
+ * count_out is incremented by 3 per pixel, as the reference's fill loop does (once per colour channel).  W and H must be
+ * multiples of step: otherwise the reference writes outside the image, and this returns MGPU_ERR_UNSUPPORTED. */
+int mgpu_render_step(MgpuScene *scene, const double origin[3], const double corner[3], const double du[3],
+                     const double dv[3], int W, int H, int step, int maxPathLength, const float plane[4], int rng_mode,
+                     const uint32_t *rng_states, uint64_t seed, uint32_t pass_base, float *image_out, int32_t *count_out,
+                     MgpuStats *stats);
 
 /* Device-resident variant used by the multi-GPU strip renderer and the benchmark: nothing crosses PCIe.
  * The pixel set is a list of row strips: local row j (0 <= j < n_rows) is frame row

@@ -198,6 +198,88 @@ Ray Camera::GenerateRay(double u, double v) const {
   return ray;
 }
 
+// camera.cc:242-257
+Ray Camera::GenerateEnvRay(double u, double v) const {
+  const double theta = M_PI * (v / height_);
+  const double phi = 2.0 * M_PI * (u / width_);
+  Ray ray;
+  memset(&ray, 0, sizeof(ray));
+  ray.org = real3(origin_[0], origin_[1], origin_[2]);
+  ray.dir[0] = sin(theta) * cos(phi); // y up
+  ray.dir[1] = cos(theta);
+  ray.dir[2] = sin(theta) * sin(phi);
+  return ray;
+}
+
+// camera.cc:259-329: top half of the frame = left eye, bottom half = right eye; the eyes sit on a circle of radius 0.5
+// around origin_ and are toed in towards a focal distance of 4
+Ray Camera::GenerateStereoEnvRay(double u, double v) const {
+  const bool is_left_side = v < (height_ >> 1);
+  const double focal_length = 4.0;
+  const double r = 0.5;
+  const double theta = M_PI * fmod(2.0 * v / height_, 1.0);
+  const double phi = 2.0 * M_PI * (u / width_);
+  real3 d0;
+  d0[0] = sin(theta) * cos(phi);
+  d0[1] = cos(theta);
+  d0[2] = sin(theta) * sin(phi);
+  real3 parallax;
+  if (is_left_side) { // positive rotation
+    parallax[0] = -d0[2];
+    parallax[1] = 0.0;
+    parallax[2] = d0[0];
+  } else { // negative rotation
+    parallax[0] = d0[2];
+    parallax[1] = 0.0;
+    parallax[2] = -d0[0];
+  }
+  parallax.normalize();
+  parallax = parallax * r;
+  Ray ray;
+  memset(&ray, 0, sizeof(ray));
+  ray.org[0] = origin_[0] + parallax[0];
+  ray.org[1] = origin_[1] + parallax[1];
+  ray.org[2] = origin_[2] + parallax[2];
+  double psi = atan2(r, focal_length);
+  if (is_left_side) psi = -psi;
+  ray.dir[0] = d0[0] * cos(psi) - d0[2] * sin(psi);
+  ray.dir[1] = d0[1];
+  ray.dir[2] = d0[0] * sin(psi) + d0[2] * cos(psi);
+  ray.dir.normalize();
+  return ray;
+}
+
+// prim-plane.cc:8-44: the plane test in float, the record in double; faceID, u, v are left as they were
+bool Plane::intersect(Intersection *info, const Ray &ray) {
+  real3 n(m_a, m_b, m_c);
+  real3 v = ray.dir;
+  v.normalize();
+  const float vn = (float)vdot(v, n);
+  if (std::fabs(vn) > 1.1920928955078125e-07f * 1024.0f) { // std::numeric_limits<float>::epsilon() * 1024
+    const float on_d = (float)(vdot(ray.org, n) + m_d);
+    const float t = -on_d / vn;
+    if ((t > 0) && (t < info->t)) {
+      info->t = t;
+      info->position = ray.org + (real)t * v;
+      n.normalize();
+      info->geometricNormal = n;
+      info->normal = n;
+      info->tangent[0] = 1.0;
+      info->tangent[1] = 0.0;
+      info->tangent[2] = 0.0;
+      info->binormal[0] = 0.0;
+      info->binormal[1] = 0.0;
+      info->binormal[2] = -1.0;
+      info->texcoord[0] = 0.0;
+      info->texcoord[1] = 0.0;
+      info->materialID = (unsigned int)(-1);
+      return true;
+    }
+    return false;
+  }
+  return false;
+}
+
 } // namespace mallie
 
 extern "C" int mgpu_camera_frame(const double eye[3], const double lookat[3], const double up[3], const double quat[4],

@@ -141,7 +141,8 @@ struct ObjFile {
   Shape cur;
   std::map<std::string, int> materials;
   int material;
-  ObjFile() : material(-1) {}
+  bool bad_index; // a face named a v / vn / vt entry the file does not have (the reference reads out of bounds there)
+  ObjFile() : material(-1), bad_index(false) {}
 
   // tiny_obj_loader.cc:352-403: returns false (and adds nothing) for an empty group
   bool flush() {
@@ -158,6 +159,12 @@ struct ObjFile {
             id = it->second;
           } else {
             const Corner &q = tri[c];
+            if (q.v < 0 || (size_t)q.v >= v.size() / 3 || (q.vn >= 0 && (size_t)q.vn >= vn.size() / 3) ||
+                (q.vt >= 0 && (size_t)q.vt >= vt.size() / 2)) {
+              bad_index = true; // the whole file is refused (LoadObj), nothing of this corner is read
+              cur.idx.push_back(0u);
+              continue;
+            }
             for (int a = 0; a < 3; a++) cur.pos.push_back(v[3 * (size_t)q.v + a]);
             if (q.vn >= 0) for (int a = 0; a < 3; a++) cur.nrm.push_back(vn[3 * (size_t)q.vn + a]);
             if (q.vt >= 0) for (int a = 0; a < 2; a++) cur.uv.push_back(vt[2 * (size_t)q.vt + a]);
@@ -257,6 +264,10 @@ bool read_obj(const char *filename, ObjFile &o) {
     }
   }
   o.end_shape();
+  if (o.bad_index) {
+    fprintf(stderr, "Mallie:err\tface index out of range in [%s]\n", filename);
+    return false;
+  }
   return true;
 }
 

@@ -188,10 +188,11 @@ void SetRenderSeed(unsigned long long seed) {
 }
 void SetRenderRngTable(const unsigned int *states) { gRngTable = states; }
 
-bool RenderPasses(Scene &scene, const RenderConfig &config, std::vector<float> &image, std::vector<int> &count,
-                  const double eye[3], const double lookat[3], const double up[3], const double quat[4], int passes) {
+static bool render_impl(Scene &scene, const RenderConfig &config, std::vector<float> &image, std::vector<int> &count,
+                        const double eye[3], const double lookat[3], const double up[3], const double quat[4], int passes,
+                        int step) {
   const int width = config.width, height = config.height;
-  if (width <= 0 || height <= 0 || passes < 1) return false;
+  if (width <= 0 || height <= 0 || passes < 1 || step < 1) return false;
   if (image.size() < (size_t)3 * width * height || count.size() < (size_t)width * height) {
     printf("Mallie:err\tmsg:Render: image/count buffers are smaller than %dx%d\n", width, height);
     return false;
@@ -218,10 +219,19 @@ bool RenderPasses(Scene &scene, const RenderConfig &config, std::vector<float> &
   }
   const float pl[4] = {gPlaneObject.m_a, gPlaneObject.m_b, gPlaneObject.m_c, gPlaneObject.m_d};
   const bool table = gRngTable != NULL;
+  if (table && passes != 1) { // SetRenderRngTable holds the start states of ONE pass (width * height * 4 words)
+    gRngTable = NULL;
+    printf("Mallie:err\tmsg:RenderPasses: a start-state table covers one pass, %d were asked for\n", passes);
+    return false;
+  }
   MgpuStats st;
-  const int rc = mgpu_render(dev, origin, corner, du, dv, width, height, 0, 0, width, height, gMaxPathLength, passes,
-                             gPlane ? pl : NULL, table ? MGPU_RNG_TABLE : MGPU_RNG_HASH, gRngTable, gSeed, gPassCounter,
-                             &image[0], &count[0], &st);
+  const int rc = step == 1
+                     ? mgpu_render(dev, origin, corner, du, dv, width, height, 0, 0, width, height, gMaxPathLength, passes,
+                                   gPlane ? pl : NULL, table ? MGPU_RNG_TABLE : MGPU_RNG_HASH, gRngTable, gSeed, gPassCounter,
+                                   &image[0], &count[0], &st)
+                     : mgpu_render_step(dev, origin, corner, du, dv, width, height, step, gMaxPathLength, gPlane ? pl : NULL,
+                                        table ? MGPU_RNG_TABLE : MGPU_RNG_HASH, gRngTable, gSeed, gPassCounter, &image[0],
+                                        &count[0], &st);
   gRngTable = NULL;
   if (rc != MGPU_OK) {
     printf("Mallie:err\tmsg:Render failed: %s\n", mgpu_last_error());
@@ -234,13 +244,21 @@ bool RenderPasses(Scene &scene, const RenderConfig &config, std::vector<float> &
   return true;
 }
 
+bool RenderPasses(Scene &scene, const RenderConfig &config, std::vector<float> &image, std::vector<int> &count,
+                  const double eye[3], const double lookat[3], const double up[3], const double quat[4], int passes) {
+  return render_impl(scene, config, image, count, eye, lookat, up, quat, passes, 1);
+}
+
+// render.cc:593-708.  step > 1 (progressive block fill, render.cc:684-696): one path per step x step block, count += 3 per
+// pixel as the reference's fill loop does; sizes that are not multiples of the step are refused (the reference writes
+// outside the image there).
 void Render(Scene &scene, const RenderConfig &config, std::vector<float> &image, std::vector<int> &count,
             const double eye[3], const double lookat[3], const double up[3], const double quat[4], int step) {
-  if (step != 1) {
-    printf("Mallie:err\tmsg:Render: step = %d is not supported by the MI355X path (only step 1)\n", step);
+  if (step < 1) {
+    printf("Mallie:err\tmsg:Render: step = %d\n", step);
     return;
   }
-  RenderPasses(scene, config, image, count, eye, lookat, up, quat, 1);
+  render_impl(scene, config, image, count, eye, lookat, up, quat, 1, step);
 }
 
 // RenderPanoramic, render.cc:710-763 (what main_console.cc:111 calls): 10 PathTraceEnv samples per pixel of an

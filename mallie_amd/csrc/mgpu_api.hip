@@ -107,6 +107,9 @@ struct MgpuScene {
   unsigned long long *p_wave_log = nullptr; // 4 words x 16384 waves, diagnostic
   double *probe_buf = nullptr; // set only for the duration of mgpu_probe_path
   uint32_t probe_pixel = 0, probe_pass = 0;
+  int pix_step = 1;            // set only for the duration of mgpu_render_step
+  bool tile_order_on = true;   // MGPU_TILE_ORDER (read once, when the scene is created)
+  unsigned tile_order_every = 4; // MGPU_TILE_ORDER_EVERY
 };
 
 namespace {
@@ -436,6 +439,8 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
   s->d.boxes_ordered = s->boxes_ordered ? 1 : 0;
   if (const char *e = getenv("MGPU_PLAIN_SLABS")) // 0: literal slab test only (A/B measurements, tests)
     if (atoi(e) == 0) s->d.boxes_ordered = 0;
+  if (const char *e = getenv("MGPU_TILE_ORDER")) s->tile_order_on = atoi(e) != 0;
+  if (const char *e = getenv("MGPU_TILE_ORDER_EVERY")) s->tile_order_every = atoi(e) < 1 ? 1u : (unsigned)atoi(e);
   *out = s;
   return MGPU_OK;
 #undef TRY_OR_FREE
@@ -601,7 +606,8 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
                               const float plane[4], int rng_mode, const uint32_t *d_rng_states, uint64_t seed,
                               uint32_t pass_base, float *d_image, int32_t *d_count, void *stream, MgpuStats *stats) {
   if (!s || !frame || !d_image) return fail(MGPU_ERR_INVALID, "scene/frame/d_image must be non-NULL");
-  if (W <= 0 || H <= 0 || x0 < 0 || x1 > W || x0 > x1) return fail(MGPU_ERR_INVALID, "bad window columns");
+  const int pstep = s ? s->pix_step : 1; // > 1: the window is given in step x step blocks of the W x H frame
+  if (W <= 0 || H <= 0 || x0 < 0 || (long long)x1 * pstep > W || x0 > x1) return fail(MGPU_ERR_INVALID, "bad window columns");
   if (strip_h <= 0 || y_period < strip_h || n_rows < 0 || y_first < 0) return fail(MGPU_ERR_INVALID, "bad strip layout");
   if (maxPathLength < 1 || passes < 1) return fail(MGPU_ERR_INVALID, "maxPathLength and passes must be >= 1");
   if ((uint64_t)W * (uint64_t)H > 0xFFFFFFFFull) return fail(MGPU_ERR_INVALID, "frame too large");
@@ -614,7 +620,7 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   if (n_rows > 0) {
     const int j = n_rows - 1;
     const long long ylast = (long long)y_first + (long long)(j / strip_h) * y_period + (j % strip_h);
-    if (ylast >= H) return fail(MGPU_ERR_INVALID, "strip layout reaches row %lld of a %d-row frame", ylast, H);
+    if (ylast * pstep >= H) return fail(MGPU_ERR_INVALID, "strip layout reaches row %lld of a %d-row frame", ylast * pstep, H);
   }
   const double t0 = now_ms();
   int rc = set_device(s);
@@ -690,6 +696,8 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   P.W = W; P.H = H; P.x0 = x0; P.x1 = x1;
   P.y_first = y_first; P.strip_h = strip_h; P.y_period = y_period; P.n_rows = n_rows;
   P.maxPathLength = maxPathLength; P.passes = passes;
+  P.pix_step = pstep;
+  if (pstep != 1 && kern == 0) return fail(MGPU_ERR_UNSUPPORTED, "MGPU_RENDER_KERNEL=v1 has no pixel step");
   P.rng_mode = rng_mode;
   P.rng_states = d_rng_states;
   P.seed = seed;
@@ -743,8 +751,7 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   // 7.8 -> 7.7 ms).  MGPU_TILE_ORDER=0 keeps the image order.
   P.tile_order = nullptr;
   P.tile_cost = nullptr;
-  bool use_order = kern != 0 && tiles >= 2 * blocks;
-  if (const char *e = getenv("MGPU_TILE_ORDER")) use_order = use_order && atoi(e) != 0;
+  const bool use_order = kern != 0 && tiles >= 2 * blocks && s->tile_order_on;
   if (use_order) {
     if (tiles > R.tile_cap) {
       HIP_TRY(hipDeviceSynchronize());
@@ -766,16 +773,17 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
       R.order_age = 0;
     }
     P.tile_order = R.p_tile_order;
-    P.tile_cost = R.p_tile_cost;
     // The order is renewed on the first two launches of a layout (image order, then the first measured costs) and every
-    // fourth launch after that; in between the costs keep adding up in the table.  A frame's costs change slowly, and
-    // the sort is one workgroup's work (35 us at 1080p) in front of every launch otherwise.
-    unsigned every = 4;
-    if (const char *e = getenv("MGPU_TILE_ORDER_EVERY")) every = atoi(e) < 1 ? 1u : (unsigned)atoi(e);
-    if (R.order_age < 2 || R.order_age % every == 0) {
+    // fourth launch after that (MGPU_TILE_ORDER_EVERY): a frame's costs change slowly, and the sort is one workgroup's work
+    // (35 us at 1080p) in front of the launch.  Costs are recorded only by the launch right before a renewal, so the
+    // table always holds ONE launch's costs (no sums that could wrap) and the other launches skip the atomics.
+    const unsigned every = s->tile_order_every;
+    auto renews = [&](unsigned age) { return age < 2 || age % every == 0; };
+    if (renews(R.order_age)) {
       launch_order_tiles(st, R.p_tile_cost, (uint32_t)tiles, R.p_tile_order); // outside the kernel-time bracket
       HIP_TRY(hipGetLastError());
     }
+    P.tile_cost = renews(R.order_age + 1) ? R.p_tile_cost : nullptr;
     ++R.order_age;
   }
   if (stats) {
@@ -923,6 +931,88 @@ int mgpu_render(MgpuScene *s, const double origin[3], const double corner[3], co
   }
   return MGPU_OK;
 #undef TRY_R
+}
+
+int mgpu_render_step(MgpuScene *s, const double origin[3], const double corner[3], const double du[3], const double dv[3],
+                     int W, int H, int step, int maxPathLength, const float plane[4], int rng_mode,
+                     const uint32_t *rng_states, uint64_t seed, uint32_t pass_base, float *image_out, int32_t *count_out,
+                     MgpuStats *stats) {
+  if (step == 1)
+    return mgpu_render(s, origin, corner, du, dv, W, H, 0, 0, W, H, maxPathLength, 1, plane, rng_mode, rng_states, seed,
+                       pass_base, image_out, count_out, stats);
+  if (!s || !origin || !corner || !du || !dv || !image_out) return fail(MGPU_ERR_INVALID, "NULL argument");
+  if (step < 1 || W <= 0 || H <= 0) return fail(MGPU_ERR_INVALID, "bad step / frame size");
+  if (W % step || H % step)
+    return fail(MGPU_ERR_UNSUPPORTED,
+                "Render(step = %d) of a %dx%d frame: the reference's block fill (render.cc:684-696) writes outside the "
+                "image unless both sizes are multiples of the step",
+                step, W, H);
+  std::lock_guard<std::mutex> host_lock(s->host_mutex);
+  const double t0 = now_ms();
+  int rc = set_device(s);
+  if (rc) return rc;
+  if (stats) memset(stats, 0, sizeof(*stats));
+  const int cw = W / step, ch = H / step;
+  double frame[12];
+  memcpy(frame + 0, origin, 24);
+  memcpy(frame + 3, corner, 24);
+  memcpy(frame + 6, du, 24);
+  memcpy(frame + 9, dv, 24);
+  const size_t img_bytes = sizeof(float) * 3 * (size_t)cw * ch;
+  if (img_bytes > s->host_img_bytes) {
+    if (s->p_host_img) {
+      (void)hipFree(s->p_host_img);
+      s->device_bytes -= s->host_img_bytes;
+      s->p_host_img = nullptr;
+      s->host_img_bytes = 0;
+    }
+    rc = dev_alloc(s, (void **)&s->p_host_img, img_bytes);
+    if (rc) return rc;
+    s->host_img_bytes = img_bytes;
+  }
+  uint32_t *d_states = nullptr;
+  if (rng_mode == MGPU_RNG_TABLE) {
+    if (!rng_states) return fail(MGPU_ERR_INVALID, "MGPU_RNG_TABLE needs rng_states");
+    const size_t bytes = (size_t)W * H * 16;
+    HIP_TRY(hipMalloc((void **)&d_states, bytes));
+    hipError_t e = hipMemcpy(d_states, rng_states, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      (void)hipFree(d_states);
+      return fail(MGPU_ERR_HIP, "rng table upload: %s", hipGetErrorString(e));
+    }
+  }
+  MgpuStats local;
+  s->pix_step = step; // the window below counts step x step blocks; a block's path is its top-left pixel's
+  rc = mgpu_render_strips_device(s, frame, W, H, 0, cw, 0, ch, ch, ch, maxPathLength, 1, plane, rng_mode, d_states, seed,
+                                 pass_base, (float *)s->p_host_img, nullptr, nullptr, &local);
+  s->pix_step = 1;
+  std::vector<float> coarse;
+  if (!rc) {
+    coarse.resize((size_t)3 * cw * ch);
+    hipError_t e = hipMemcpy(coarse.data(), s->p_host_img, img_bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(MGPU_ERR_HIP, "read-back: %s", hipGetErrorString(e));
+  }
+  if (d_states) (void)hipFree(d_states);
+  if (rc) return rc;
+  // block fill, render.cc:684-696: every pixel of a block takes the block's radiance; count is incremented once per
+  // colour channel there, i.e. by 3
+  for (int by = 0; by < ch; by++)
+    for (int bx = 0; bx < cw; bx++) {
+      const float *src = &coarse[3 * ((size_t)by * cw + bx)];
+      for (int v = 0; v < step; v++)
+        for (int u = 0; u < step; u++) {
+          const size_t px = (size_t)(by * step + v) * W + (size_t)(bx * step + u);
+          image_out[3 * px + 0] = src[0];
+          image_out[3 * px + 1] = src[1];
+          image_out[3 * px + 2] = src[2];
+          if (count_out) count_out[px] += 3;
+        }
+    }
+  if (stats) {
+    *stats = local;
+    stats->total_ms = now_ms() - t0;
+  }
+  return MGPU_OK;
 }
 
 int mgpu_render_panoramic_device(MgpuScene *s, const double origin[3], int W, int H, int x0, int y0, int x1, int y1,

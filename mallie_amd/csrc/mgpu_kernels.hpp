@@ -34,6 +34,7 @@ struct RenderParams {
   int x0, x1;       // window columns
   int y_first, strip_h, y_period, n_rows; // row strips: local row j -> y_first + (j/strip_h)*y_period + j%strip_h
   int maxPathLength, passes;
+  int pix_step;     // 1, or Render()'s `step`: window coordinates then count step x step blocks (k_render_sm only)
   int rng_mode;
   const uint32_t *rng_states; // device, MGPU_RNG_TABLE layout, or null
   unsigned long long seed;

@@ -751,8 +751,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
           have_path = false;
           // start a new eye path (PathTrace prologue, render.cc:387-400)
           const uint32_t j = ly;
-          const int gy = P.y_first + (int)(j / (uint32_t)P.strip_h) * P.y_period + (int)(j % (uint32_t)P.strip_h);
-          const int gx = P.x0 + (int)lx;
+          // pix_step > 1: Render(step): the window is in units of step x step blocks and a block's path is that of its
+          // top-left pixel (render.cc:657-681)
+          const int gy = (P.y_first + (int)(j / (uint32_t)P.strip_h) * P.y_period + (int)(j % (uint32_t)P.strip_h)) * P.pix_step;
+          const int gx = (P.x0 + (int)lx) * P.pix_step;
           const uint32_t gpix = (uint32_t)gy * (uint32_t)P.W + (uint32_t)gx;
           uint32_t s4[4];
           if (P.rng_mode == MGPU_RNG_TABLE) {

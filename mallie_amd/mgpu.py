@@ -85,6 +85,8 @@ def load_library():
     L.mgpu_stats_read.restype = i32
     L.mgpu_debug_words.argtypes = [vp, vp]
     L.mgpu_debug_words.restype = i32
+    L.mgpu_render_step.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, u64, u32, vp, vp, vp]
+    L.mgpu_render_step.restype = i32
     L.mgpu_occupancy_read.argtypes = [vp, vp]
     L.mgpu_occupancy_read.restype = i32
     L.mgpu_render_panoramic.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, u64, u32, vp, vp,
@@ -282,6 +284,19 @@ class Scene:
         _check(load_library().mgpu_render(self.h, _p(frame[0:3]), _p(frame[3:6]), _p(frame[6:9]), _p(frame[9:12]), W, H,
                                           x0, y0, x1, y1, maxPathLength, passes, _p(plane), rng_mode, _p(rng_states),
                                           seed, pass_base, _p(image), _p(count), C.byref(st)), "mgpu_render")
+        return image, count, st.as_dict()
+
+    def render_step(self, frame, W, H, step, maxPathLength=16, plane=None, rng_mode=RNG_HASH, rng_states=None, seed=1,
+                    pass_base=0, count=None):
+        """mgpu_render_step: ONE Render() call with its `step` argument -> (image, count, stats)."""
+        frame = _c(frame, "<f8")
+        image = np.zeros((H, W, 3), "<f4")
+        if count is None:
+            count = np.zeros((H, W), "<i4")
+        st = Stats()
+        _check(load_library().mgpu_render_step(self.h, _p(frame[0:3]), _p(frame[3:6]), _p(frame[6:9]), _p(frame[9:12]), W, H,
+                                               step, maxPathLength, _p(_c(plane, "<f4")), rng_mode, _p(_c(rng_states, "<u4")),
+                                               seed, pass_base, _p(image), _p(count), C.byref(st)), "mgpu_render_step")
         return image, count, st.as_dict()
 
     def render_panoramic(self, origin, W, H, stereo, maxPathLength=16, samples=10, rng_mode=RNG_HASH, rng_states=None,

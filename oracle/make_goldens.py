@@ -138,13 +138,16 @@ def gen_trace(tmp, kind, fname, name, rays):
     print(name, len(rays), "rays", int(hits["hit"].sum()), "hits")
 
 
-def gen_render(tmp, kind, fname, name, W, H, plane, passes, eye, lookat, up=(0, 1, 0), quat=(0, 0, 0, 0), store=True):
+def gen_render(tmp, kind, fname, name, W, H, plane, passes, eye, lookat, up=(0, 1, 0), quat=(0, 0, 0, 0), store=True,
+               step=1):
     prefix = os.path.join(tmp, name)
-    run(["render", kind, fname, 1.0, W, H, int(plane), passes, *eye, *lookat, *up, *quat, prefix])
+    run(["render", kind, fname, 1.0, W, H, int(plane), passes, *eye, *lookat, *up, *quat, prefix] + ([step] if step != 1 else []))
     imgs = [np.fromfile("%s.pass%d.f32" % (prefix, p), "<f4").reshape(H, W, 3) for p in range(passes)]
     count = np.fromfile(prefix + ".count.i32", "<i4").reshape(H, W)
     meta = dict(W=W, H=H, plane=int(plane), passes=passes, eye=np.array(eye, "f8"), lookat=np.array(lookat, "f8"),
                 up=np.array(up, "f8"), quat=np.array(quat, "f8"), maxPathLength=16, scene=name.split("_")[1])
+    if step != 1:
+        meta["step"] = step
     if store:
         np.savez_compressed(os.path.join(OUT, name + ".npz"), images=np.stack(imgs), count=count, **meta)
     else:
@@ -177,6 +180,41 @@ def gen_pano_all(tmp):
     gen_pano(tmp, "obj", "cornellbox_suzanne.obj", "pano_cornell_stereo_50x37_view2", 50, 37, True, (2.5, 3.0, -1.5),
              quat=(0.05, -0.1, 0.02, 0.99))
     gen_pano(tmp, "obj", "teapot.obj", "pano_teapot_mono_64x32", 64, 32, False, (0.0, 60.0, 120.0))
+
+
+def gen_step_all(tmp):
+    gen_render(tmp, "obj", "cornellbox_suzanne.obj", "render_cornell_obj_64_plane_step2_2pass", 64, 64, True, 2, (0, 0, 20), (0, 0, 0),
+               step=2)
+    gen_render(tmp, "obj", "cornellbox_suzanne.obj", "render_cornell_obj_60x48_noplane_step4", 60, 48, False, 1, (0, 0, 20), (0, 0, 0),
+               step=4)
+
+
+def gen_boundary(tmp):
+    """Camera::GenerateEnvRay / GenerateStereoEnvRay (camera.cc:242-329) and Plane::intersect (prim-plane.cc:8-44) probes."""
+    rng = np.random.default_rng(11)
+    W, H = 96, 64
+    eye, la = (0.5, 1.0, 4.0), (0.0, 0.5, 0.0)
+    uv = np.column_stack([rng.random(64) * W, rng.random(64) * H])
+    uv[:6] = [(0, 0), (W - 1, H - 1), (W / 2, H / 2), (W / 2, H / 2 - 1), (17, 31.999), (17, 32)]
+    out = os.path.join(tmp, "env.bin")
+    p = subprocess.run([DRIVER, "envrays", str(W), str(H), "45", *map(str, eye), *map(str, la), "0", "1", "0", "0", "0", "0", "0", out],
+                       input="\n".join("%r %r" % (float(u), float(v)) for u, v in uv), text=True, cwd=REF, capture_output=True)
+    assert p.returncode == 0, p.stderr
+    env = np.fromfile(out, "<f8").reshape(-1, 12)
+    pl = (0.25, 1.0, -0.125, 0.75)
+    rays = np.zeros((96, 7))
+    rays[:, 0:3] = rng.normal(size=(96, 3)) * 3
+    rays[:, 3:6] = rng.normal(size=(96, 3))
+    rays[:, 6] = np.where(rng.random(96) < 0.5, 1.0e30, rng.random(96) * 6)
+    rays[0, 3:6] = (1, -0.25, 0.0)          # parallel to the plane: |v.n| below the epsilon
+    rays[1, 3:6] = 0                        # zero direction: normalize() leaves it alone
+    rays[2, 3:6] *= 1e-9                    # shorter than normalize()'s 1e-6 guard
+    rp, op = os.path.join(tmp, "pl.rays"), os.path.join(tmp, "pl.out")
+    rays.tofile(rp)
+    run(["plane", *pl, rp, op])
+    np.savez_compressed(os.path.join(OUT, "boundary.npz"), W=W, H=H, eye=np.array(eye), lookat=np.array(la), uv=uv, env=env,
+                        plane=np.array(pl), plane_rays=rays, plane_out=np.fromfile(op, "<f8").reshape(-1, 22))
+    print("boundary", env.shape, int(np.fromfile(op, "<f8").reshape(-1, 22)[:, 0].sum()), "plane hits")
 
 
 def gen_camera(tmp):
@@ -222,12 +260,22 @@ def main():
             gen_mesh(tmp, "vox", "tiny.vox", "objload_vox_default", cwd=objs)
             gen_mesh(tmp, "vox", "tiny_rgba.vox", "objload_vox_rgba", cwd=objs)
         return
+    if sys.argv[1:] == ["step"]:  # only the Render(step > 1) goldens (render.cc:684-696)
+        with tempfile.TemporaryDirectory() as tmp:
+            gen_step_all(tmp)
+        return
+    if sys.argv[1:] == ["boundary"]:
+        with tempfile.TemporaryDirectory() as tmp:
+            gen_boundary(tmp)
+        return
     if sys.argv[1:] == ["pano"]:  # only the RenderPanoramic goldens (keeps the other fixtures' bytes untouched)
         with tempfile.TemporaryDirectory() as tmp:
             gen_pano_all(tmp)
         return
     with tempfile.TemporaryDirectory() as tmp:
         gen_pano_all(tmp)
+        gen_step_all(tmp)
+        gen_boundary(tmp)
         gen_camera(tmp)
         mc = gen_mesh(tmp, "obj", "cornellbox_suzanne.obj", "cornell_obj")
         gen_mesh(tmp, "eson", "cornellbox_suzanne.eson", "cornell_eson")

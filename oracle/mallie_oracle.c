@@ -953,6 +953,47 @@ int mo_render(const mo_scene *s, const double frame[12], int W, int H, int x0, i
   return err;
 }
 
+/* One Render() call with its `step` argument (render.cc:657-696): one path per step x step block -- the block's top-left
+ * pixel -- in scanline order, then the block fill, which increments count once per colour channel (3 per pixel); with
+ * step == 1 count is incremented once (render.cc:677-679).  W and H must be multiples of step (the reference's fill
+ * writes outside the image otherwise).  RNG modes as mo_render, start states indexed by the block's top-left pixel. */
+int mo_render_step(const mo_scene *s, const double frame[12], int W, int H, int step, int maxPathLength,
+                   const float *plane, int rng_mode, uint32_t stream_state[4], const uint32_t *rng_states, uint64_t seed,
+                   uint32_t pass_base, float *image, int32_t *count, uint32_t *states_out, mo_stats *stats) {
+  if (!s || !frame || !image || W <= 0 || H <= 0 || step < 1 || maxPathLength < 1) return -1;
+  if (W % step || H % step) return -1;
+  if (rng_mode == MO_RNG_STREAM && !stream_state) return -1;
+  if (rng_mode == MO_RNG_TABLE && !rng_states) return -1;
+  path_counters total;
+  memset(&total, 0, sizeof(total));
+  memset(image, 0, sizeof(float) * 3 * (size_t)W * H); /* render.cc:641 */
+  for (int y = 0; y < H; y += step) {
+    for (int x = 0; x < W; x += step) {
+      size_t px = (size_t)y * W + x;
+      uint32_t st[4], *rng = st;
+      if (rng_mode == MO_RNG_STREAM) rng = stream_state;
+      else if (rng_mode == MO_RNG_TABLE) memcpy(st, &rng_states[px * 4], 16);
+      else mo_hash_state(seed, pass_base, (uint32_t)px, st);
+      if (states_out) memcpy(&states_out[px * 4], rng, 16);
+      double rad[3];
+      if (path_trace(s, frame, plane, maxPathLength, x, y, rng, rad, &total, NULL, NULL)) return -3;
+      for (int c = 0; c < 3; c++) image[3 * px + c] = (float)rad[c];
+      if (step == 1 && count) count[px]++;
+    }
+    if (step > 1) {
+      for (int x = 0; x < W; x += step)
+        for (int v = 0; v < step; v++)
+          for (int u = 0; u < step; u++)
+            for (int k = 0; k < 3; k++) {
+              image[((size_t)(y + v) * W * 3 + (size_t)(x + u) * 3) + k] = image[3 * ((size_t)y * W + x) + k];
+              if (count) count[(size_t)(y + v) * W + (x + u)]++;
+            }
+    }
+  }
+  if (stats) merge_stats(stats, &total);
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 /* RenderPanoramic (render.cc:710-763) = PathTraceEnv (render.cc:518-590) over equirectangular rays    */
 /* ------------------------------------------------------------------------------------------------ */

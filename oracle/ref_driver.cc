@@ -26,6 +26,7 @@
 #include "scene.h"
 #include "render.h"
 #include "camera.h"
+#include "prim-plane.h"
 
 namespace {
 
@@ -174,7 +175,7 @@ int cmd_camera(int argc, char **argv) {
   return 0;
 }
 
-// render <kind> <file> <scale> <W> <H> <plane> <passes> <eye[3]> <lookat[3]> <up[3]> <quat[4]> <out_prefix>
+// render <kind> <file> <scale> <W> <H> <plane> <passes> <eye[3]> <lookat[3]> <up[3]> <quat[4]> <out_prefix> [step]
 //   writes <out>.pass<k>.f32 (3*W*H float32, the image exactly as Render() left it after pass k) and
 //   <out>.count.i32 (W*H int32 after the last pass).  Run with OMP_NUM_THREADS=1.
 int cmd_render(int argc, char **argv) {
@@ -193,10 +194,11 @@ int cmd_render(int argc, char **argv) {
   }
   for (int k = 0; k < 4; k++) config.quat[k] = atof(argv[18 + k]);
   std::string out = argv[22];
+  const int step = argc > 23 ? atoi(argv[23]) : 1; // Render()'s last argument (render.cc:597)
   std::vector<float> image(3 * (size_t)config.width * config.height);
   std::vector<int> count((size_t)config.width * config.height, 0);
   for (int p = 0; p < passes; p++) {
-    mallie::Render(scene, config, image, count, config.eye, config.lookat, config.up, config.quat, 1);
+    mallie::Render(scene, config, image, count, config.eye, config.lookat, config.up, config.quat, step);
     char suffix[64];
     snprintf(suffix, sizeof(suffix), ".pass%d.f32", p);
     FILE *fp = xopen(out + suffix, "wb");
@@ -241,10 +243,71 @@ int cmd_panoramic(int argc, char **argv) {
   return 0;
 }
 
+
+// envrays <W> <H> <fov> <eye[3]> <lookat[3]> <up[3]> <quat[4]> <out.bin>: for "u v" pairs on stdin, appends
+// Camera::GenerateEnvRay(u, v) and Camera::GenerateStereoEnvRay(u, v) (camera.cc:242-329) as org+dir (2 x 6 f64)
+int cmd_envrays(int argc, char **argv) {
+  if (argc < 19) die("envrays W H fov eye[3] lookat[3] up[3] quat[4] out");
+  int W = atoi(argv[2]), H = atoi(argv[3]);
+  double fov = atof(argv[4]);
+  double eye[3], lookat[3], up[3], quat[4];
+  for (int k = 0; k < 3; k++) { eye[k] = atof(argv[5 + k]); lookat[k] = atof(argv[8 + k]); up[k] = atof(argv[11 + k]); }
+  for (int k = 0; k < 4; k++) quat[k] = atof(argv[14 + k]);
+  mallie::Camera cam(eye, lookat, up);
+  double o[3], c[3], du[3], dv[3];
+  cam.BuildCameraFrame(o, c, du, dv, fov, quat, W, H);
+  FILE *fo = xopen(argv[18], "wb");
+  double u, v;
+  while (scanf("%lf %lf", &u, &v) == 2) {
+    Ray a = cam.GenerateEnvRay(u, v), b = cam.GenerateStereoEnvRay(u, v);
+    double d[12] = {a.org[0], a.org[1], a.org[2], a.dir[0], a.dir[1], a.dir[2],
+                    b.org[0], b.org[1], b.org[2], b.dir[0], b.dir[1], b.dir[2]};
+    wr(fo, d, sizeof(d));
+  }
+  fclose(fo);
+  return 0;
+}
+
+// plane <a> <b> <c> <d> <rays.bin> <out.bin>: Plane::intersect (prim-plane.cc:8-44) for rays of 7 f64 (org, dir, the
+// Intersection::t to start from); per ray 20 f64: hit, t, position, geometricNormal, normal, tangent, binormal,
+// texcoord, then materialID and faceID as doubles... (the record starts zeroed, faceID 7 to show it is left alone)
+int cmd_plane(int argc, char **argv) {
+  if (argc < 8) die("plane a b c d rays.bin out.bin");
+  mallie::Plane pl;
+  pl.set((float)atof(argv[2]), (float)atof(argv[3]), (float)atof(argv[4]), (float)atof(argv[5]));
+  FILE *fi = xopen(argv[6], "rb");
+  fseek(fi, 0, SEEK_END); long sz = ftell(fi); rewind(fi);
+  size_t n = sz / 56;
+  std::vector<double> rays(7 * n);
+  if (fread(&rays[0], 56, n, fi) != n) die("short read");
+  fclose(fi);
+  FILE *fo = xopen(argv[7], "wb");
+  for (size_t i = 0; i < n; i++) {
+    Ray ray;
+    memset(&ray, 0, sizeof(ray));
+    ray.org = real3(rays[7 * i + 0], rays[7 * i + 1], rays[7 * i + 2]);
+    ray.dir = real3(rays[7 * i + 3], rays[7 * i + 4], rays[7 * i + 5]);
+    Intersection is;
+    memset(&is, 0, sizeof(is));
+    is.t = rays[7 * i + 6];
+    is.faceID = 7;
+    bool hit = pl.intersect(&is, ray);
+    double d[22] = {hit ? 1.0 : 0.0, is.t, is.position[0], is.position[1], is.position[2], is.geometricNormal[0],
+                    is.geometricNormal[1], is.geometricNormal[2], is.normal[0], is.normal[1], is.normal[2], is.tangent[0],
+                    is.tangent[1], is.tangent[2], is.binormal[0], is.binormal[1], is.binormal[2], is.texcoord[0],
+                    is.texcoord[1], (double)is.materialID, (double)is.faceID, is.u + is.v};
+    wr(fo, d, sizeof(d));
+  }
+  fclose(fo);
+  return 0;
+}
+
 } // namespace
 
 int main(int argc, char **argv) {
   if (argc < 2) die("usage: ref_driver mesh|trace|camera|render ...");
+  if (!strcmp(argv[1], "envrays")) return cmd_envrays(argc, argv);
+  if (!strcmp(argv[1], "plane")) return cmd_plane(argc, argv);
   if (!strcmp(argv[1], "mesh")) return cmd_mesh(argc, argv);
   if (!strcmp(argv[1], "trace")) return cmd_trace(argc, argv);
   if (!strcmp(argv[1], "camera")) return cmd_camera(argc, argv);

@@ -6,6 +6,9 @@
 //   facade_driver mesh   <obj|eson|vox> <file> <scale> <out_prefix>          (CPU only: loader + BVH build)
 //   facade_driver render <obj|eson|vox> <file> <W> <H> <plane> <passes> <maxPathLength> <seed> <out.f32>   (GPU)
 //   facade_driver trace  <obj|eson|vox> <file> <rays.bin> <out.bin>                                          (GPU)
+//   facade_driver envrays <W> <H> <eye[3]> <lookat[3]> <uv.bin> <out.bin>     (CPU: Camera::GenerateEnvRay / StereoEnvRay)
+//   facade_driver plane  <a> <b> <c> <d> <rays.bin> <out.bin>                  (CPU: Plane::intersect)
+//   facade_driver step   <obj|eson|vox> <file> <W> <H> <plane> <calls> <maxPathLength> <seed> <step> <out.bin>   (GPU)
 #include <string>
 #include <thread>
 #include <vector>
@@ -18,6 +21,7 @@
 #include "scene.h"
 #include "render.h"
 #include "camera.h"
+#include "prim-plane.h"
 
 static bool init(mallie::Scene &scene, const char *kind, const char *file, double scale) {
   std::string obj, eson, vox, mat;
@@ -81,6 +85,62 @@ int main(int argc, char **argv) {
     std::vector<float> image2(image.size()); std::vector<int> count2(count.size(), 0);
     if (!mallie::RenderPasses(scene, config, image2, count2, config.eye, config.lookat, config.up, config.quat, passes)) return 6;
     if (memcmp(&image2[0], &accum[0], 4 * accum.size()) != 0) { fprintf(stderr, "RenderPasses != Render+AccumImage\n"); return 7; }
+    return 0;
+  }
+  if (!strcmp(argv[1], "envrays") && argc >= 12) { // the two equirectangular ray generators on a list of (u, v)
+    const int W = atoi(argv[2]), H = atoi(argv[3]);
+    double eye[3], lookat[3], up[3] = {0, 1, 0}, quat[4] = {0, 0, 0, 0}, fr[12];
+    for (int k = 0; k < 3; k++) { eye[k] = atof(argv[4 + k]); lookat[k] = atof(argv[7 + k]); }
+    mallie::Camera cam(eye, lookat, up);
+    cam.BuildCameraFrame(fr, fr + 3, fr + 6, fr + 9, 45.0, quat, W, H);
+    FILE *fi = fopen(argv[10], "rb");
+    FILE *fo = fopen(argv[11], "wb");
+    double uv[2];
+    while (fread(uv, 8, 2, fi) == 2) {
+      const Ray m = cam.GenerateEnvRay(uv[0], uv[1]), s = cam.GenerateStereoEnvRay(uv[0], uv[1]);
+      wr(fo, &m.org, 24); wr(fo, &m.dir, 24); wr(fo, &s.org, 24); wr(fo, &s.dir, 24);
+    }
+    fclose(fi); fclose(fo);
+    return 0;
+  }
+  if (!strcmp(argv[1], "plane") && argc >= 8) { // Plane::intersect on rays of (org, dir, starting t)
+    mallie::Plane pl;
+    pl.set((float)atof(argv[2]), (float)atof(argv[3]), (float)atof(argv[4]), (float)atof(argv[5]));
+    FILE *fi = fopen(argv[6], "rb");
+    FILE *fo = fopen(argv[7], "wb");
+    double r[7];
+    while (fread(r, 8, 7, fi) == 7) {
+      Ray ray;
+      memset(&ray, 0, sizeof(ray));
+      ray.org = real3(r[0], r[1], r[2]);
+      ray.dir = real3(r[3], r[4], r[5]);
+      Intersection is;
+      memset(&is, 0, sizeof(is));
+      is.t = r[6];
+      is.faceID = 7;
+      const double hit = pl.intersect(&is, ray) ? 1.0 : 0.0, mat = (double)is.materialID, face = (double)is.faceID, uv = is.u + is.v;
+      wr(fo, &hit, 8); wr(fo, &is.t, 8); wr(fo, &is.position, 24); wr(fo, &is.geometricNormal, 24); wr(fo, &is.normal, 24);
+      wr(fo, &is.tangent, 24); wr(fo, &is.binormal, 24); wr(fo, is.texcoord, 16); wr(fo, &mat, 8); wr(fo, &face, 8); wr(fo, &uv, 8);
+    }
+    fclose(fi); fclose(fo);
+    return 0;
+  }
+  if (!strcmp(argv[1], "step") && argc >= 12) { // Render(..., step): `calls` consecutive calls, image of the last + count
+    mallie::Scene scene;
+    if (!init(scene, argv[2], argv[3], 1.0)) return 3;
+    mallie::RenderConfig config;
+    config.width = atoi(argv[4]); config.height = atoi(argv[5]); config.plane = atoi(argv[6]) != 0;
+    const int calls = atoi(argv[7]), step = atoi(argv[10]);
+    config.eye[0] = 0; config.eye[1] = 0; config.eye[2] = 20;
+    mallie::SetMaxPathLength(atoi(argv[8]));
+    mallie::SetRenderSeed(strtoull(argv[9], NULL, 10));
+    std::vector<float> image(3 * (size_t)config.width * config.height);
+    std::vector<int> count((size_t)config.width * config.height, 0);
+    for (int p = 0; p < calls; p++)
+      mallie::Render(scene, config, image, count, config.eye, config.lookat, config.up, config.quat, step);
+    FILE *fp = fopen(argv[11], "wb");
+    wr(fp, &image[0], 4 * image.size()); wr(fp, &count[0], 4 * count.size());
+    fclose(fp);
     return 0;
   }
   if (!strcmp(argv[1], "panoramic") && argc >= 9) {   // what main_console.cc:95-111 does for one frame

@@ -99,6 +99,108 @@ def test_scene_init_failure_is_reported_like_the_reference(driver, tmp_path):
     assert r.returncode == 3 and "Mallie:err\tmsg:Failed to load .obj file" in r.stdout
 
 
+@pytest.mark.parametrize("obj", ["bad_index.obj", "no_vertices.obj"])
+def test_obj_with_out_of_range_face_indices_is_refused(driver, tmp_path, obj):
+    """A face naming a v / vn / vt entry the file does not have: the reference's loader reads out of bounds there; this
+    reader refuses the file the way Scene::Init reports any failed load."""
+    objs = os.path.join(ROOT, "tests", "golden", "objs")
+    r = subprocess.run([driver, "mesh", "obj", obj, "1.0", str(tmp_path / "x")], cwd=objs, capture_output=True, text=True)
+    assert r.returncode == 3 and "Mallie:err\tmsg:Failed to load .obj file" in r.stdout
+    assert "face index out of range" in r.stderr
+
+
+def test_env_rays_and_plane_intersect_match_the_reference(driver, tmp_path):
+    """Camera::GenerateEnvRay / GenerateStereoEnvRay (camera.cc:242-329) and Plane::intersect (prim-plane.cc:8-44) of the
+    facade, host code: bit for bit what the reference's own objects return for the same probes (tests/golden/boundary.npz,
+    produced by oracle/ref_driver.cc from the unmodified sources)."""
+    g = O.load_golden("boundary")
+    uvp, outp = str(tmp_path / "uv.bin"), str(tmp_path / "env.bin")
+    g["uv"].astype("<f8").tofile(uvp)
+    r = subprocess.run([driver, "envrays", str(int(g["W"])), str(int(g["H"]))] + [repr(float(x)) for x in g["eye"]] +
+                       [repr(float(x)) for x in g["lookat"]] + [uvp, outp], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert np.fromfile(outp, "<f8").reshape(-1, 12).tobytes() == g["env"].tobytes()
+    rp, op = str(tmp_path / "pl.rays"), str(tmp_path / "pl.out")
+    g["plane_rays"].astype("<f8").tofile(rp)
+    r = subprocess.run([driver, "plane"] + [repr(float(x)) for x in g["plane"]] + [rp, op], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.fromfile(op, "<f8").reshape(-1, 22)
+    assert got.tobytes() == g["plane_out"].tobytes()
+    assert 0 < got[:, 0].sum() < len(got) and np.all(got[:, 20] == 7)  # hits and misses; faceID is left alone
+
+
+@pytest.fixture(scope="module")
+def console(tmp_path_factory):
+    """tests/cpp/console_driver.cc: a caller shaped like main_console.cc:57-79,104-111, against the forwarding headers."""
+    out = str(tmp_path_factory.mktemp("console") / "console_driver")
+    libdir = os.path.dirname(M.lib_path())
+    cmd = ["g++", "-O1", "-std=c++11", "-pthread", "-I", os.path.join(ROOT, "include", "mallie"),
+           os.path.join(ROOT, "tests", "cpp", "console_driver.cc"), "-L", libdir, "-lmallie_mgpu",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return out
+
+
+def test_console_shaped_caller_compiles_and_reports_a_missing_scene(console, tmp_path):
+    r = subprocess.run([console, "obj", "no_such_file.obj", "64", "48", "1", "frame", str(tmp_path / "o.ppm")],
+                       capture_output=True, text=True)
+    assert r.returncode == 3 and "Mallie:err\tmsg:Failed to load .obj file" in r.stdout
+
+
+def _read_ppm(path):
+    raw = open(path, "rb").read()
+    head, w_h, mx, body = raw.split(b"\n", 3)
+    w, h = [int(x) for x in w_h.split()]
+    assert head == b"P6" and mx == b"255" and len(body) == 3 * w * h
+    return np.frombuffer(body, "u1").reshape(h, w, 3)
+
+
+@pytest.mark.gpu
+def test_console_shaped_caller_on_gpu(console, tmp_path):
+    """The console driver's two frames (main_console.cc:57-79: Render + HDRToLDR; :104-111: stereo RenderPanoramic) through
+    the facade: the 8-bit frames equal the oracle's image put through the oracle's HDRToLDR."""
+    obj = str(tmp_path / "cornell_like.obj")
+    _write_cornell_obj(obj)
+    g = O.load_golden("cornell_obj")
+    osc = O.OracleScene(g["verts"].astype(np.float64), g["faces"], np.full(len(g["faces"]), 0xFFFFFFFF, "u4"), g["normals"], None)
+    W, H = 96, 64
+    out = str(tmp_path / "frame.ppm")
+    r = subprocess.run([console, "obj", obj, str(W), str(H), "1", "frame", out], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0 and "[Mallie] Console mode" in r.stdout and "[Mallie] Output" in r.stdout, r.stdout + r.stderr
+    frame = O.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    oimg, ocnt, _, _ = osc.render(frame, W, H, 16, 1, osc.plane(), O.RNG_HASH, seed=1)  # the facade's defaults: seed 1, 16 segments
+    assert np.array_equal(_read_ppm(out), O.tonemap(oimg, ocnt, 0).reshape(H, W, 3))
+    out = str(tmp_path / "pano.ppm")
+    r = subprocess.run([console, "obj", obj, str(W), str(H), "0", "pano", out], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    origin = O.camera_frame((0.0, 1.0, 4.0), (0, 0, 0), width=W, height=H)[:3]
+    oimg, ocnt, _, _ = osc.render_panoramic(origin, W, H, 1, 16, 10, O.RNG_HASH, seed=1)
+    assert np.array_equal(_read_ppm(out), O.tonemap(oimg, ocnt, 0).reshape(H, W, 3))
+
+
+@pytest.mark.gpu
+def test_facade_render_with_a_step_on_gpu(driver, tmp_path):
+    """mallie::Render(..., step = 4) through the facade (render.cc:684-696): block-filled image and count += 3 per call,
+    equal to the oracle's Render(step) with the facade's seeding (pass counter advancing per call)."""
+    obj = str(tmp_path / "cornell_like.obj")
+    _write_cornell_obj(obj)
+    g = O.load_golden("cornell_obj")
+    osc = O.OracleScene(g["verts"].astype(np.float64), g["faces"], np.full(len(g["faces"]), 0xFFFFFFFF, "u4"), g["normals"], None)
+    W, H, calls, mpl, seed, step = 96, 64, 2, 6, 5, 4
+    out = str(tmp_path / "step.bin")
+    r = subprocess.run([driver, "step", "obj", obj, str(W), str(H), "1", str(calls), str(mpl), str(seed), str(step), out],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = np.fromfile(out, "<f4")
+    img, count = raw[: 3 * W * H].reshape(H, W, 3), raw[3 * W * H:].view("<i4").reshape(H, W)
+    frame = O.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    ocount = np.zeros((H, W), "<i4")
+    for p in range(calls):
+        oimg, ocount, _, _ = osc.render_step(frame, W, H, step, mpl, osc.plane(), O.RNG_HASH, seed=seed, pass_base=p, count=ocount)
+    assert img.tobytes() == oimg.tobytes() and np.array_equal(count, ocount) and int(count.max()) == 3 * calls
+
+
 def _write_cornell_obj(path):
     """An .obj written from the committed mesh arrays (the GPU box has no reference tree)."""
     g = O.load_golden("cornell_obj")

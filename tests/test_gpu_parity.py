@@ -310,6 +310,33 @@ def test_render_replays_reference_stream(name):
     assert_images_match(img0, r["images"][0], name + " pass0")
 
 
+@pytest.mark.parametrize("name", ["render_cornell_obj_64_plane_step2_2pass", "render_cornell_obj_60x48_noplane_step4"])
+def test_render_step_replays_reference_stream(name):
+    """Render(step > 1) (render.cc:657-696) on the GPU: the reference's own images call after call (start states of the
+    block paths captured from the oracle's run in the reference's serial stream), count += 3 per pixel and call; the same
+    in HASH mode against the oracle; and sizes that are not multiples of the step are refused."""
+    r = O.load_golden(name)
+    osc, sc = O.scene_from_golden("cornell_obj"), gpu_scene("cornell_obj")
+    W, H, passes, step = int(r["W"]), int(r["H"]), int(r["passes"]), int(r["step"])
+    frame = M.camera_frame(r["eye"], r["lookat"], r["up"], r["quat"], 45.0, W, H)
+    plane = osc.plane() if int(r["plane"]) else None
+    state = np.array(O.REFERENCE_SEED, "<u4")
+    count = np.zeros((H, W), "<i4")
+    for p in range(passes):
+        _, _, ost, states = osc.render_step(frame, W, H, step, 16, plane, O.RNG_STREAM, stream_state=state, want_states=True)
+        img, count, st = sc.render_step(frame, W, H, step, 16, plane, M.RNG_TABLE, rng_states=states, count=count)
+        assert img.tobytes() == r["images"][p].tobytes(), (name, p)
+        assert st["paths"] == (W // step) * (H // step) == ost["paths"] and st["trace_calls"] == ost["trace_calls"]
+        assert_same_work(st, ost)
+    assert np.array_equal(count, r["count"])
+    oimg, ocount, _, _ = osc.render_step(frame, W, H, step, 5, plane, O.RNG_HASH, seed=9, pass_base=3)
+    img, gcount, _ = sc.render_step(frame, W, H, step, 5, plane, M.RNG_HASH, seed=9, pass_base=3)
+    assert img.tobytes() == oimg.tobytes() and np.array_equal(gcount, ocount)
+    with pytest.raises(M.MgpuError) as e:
+        sc.render_step(M.camera_frame(r["eye"], r["lookat"], width=W + 1, height=H), W + 1, H, step, 5, plane)
+    assert e.value.status == -6  # MGPU_ERR_UNSUPPORTED: the reference's block fill would write outside the image
+
+
 def test_path_probe_every_iteration_vs_oracle():
     """Iteration-level parity of PathTrace: origin, direction, hit distance, shading normal, material and running
     throughput / radiance of every loop iteration, device vs oracle, for a lattice of pixels and three scenes.  IEEE
@@ -838,31 +865,37 @@ def test_odd_strip_layouts_reassemble_to_the_full_frame(strip_h, parts):
 
 
 def test_cost_ordered_hand_out_is_a_permutation_and_changes_nothing(monkeypatch):
-    """The second launch of a layout hands tiles out by the first one's cost (mgpu_debug_tile_order): the order is a
-    permutation with the expensive tiles first, and the image equals the image-order launch's bit for bit."""
+    """Nine launches of one layout with the passes moving on (a progressive renderer): the hand-out order is renewed on
+    launches 0, 1, 4, 8 from the costs the launch before recorded (mgpu_debug_tile_order), it is a permutation with the
+    expensive tiles first, the cost table holds one launch's costs, and every image equals the image-order launch's."""
     import torch
     sc = gpu_scene("cornell_obj")
+    monkeypatch.setenv("MGPU_TILE_ORDER", "0")  # read when a scene is created
+    plain = gpu_scene("cornell_obj")
+    monkeypatch.delenv("MGPU_TILE_ORDER")
     W, H, mpl, passes = 512, 384, 5, 4
     frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
     plane = sc.plane()
-    imgs = []
-    for i in range(3):
-        buf = torch.full((H, W, 3), float("nan"), dtype=torch.float32, device="cuda")
-        sc.render_strips_device(frame, W, H, buf.data_ptr(), H, maxPathLength=mpl, passes=passes, plane=plane, seed=5)
-        imgs.append(buf.cpu().numpy())
     nt = (W // 8) * (H // 8)
-    cost, order = sc.tile_order(nt)
-    assert np.array_equal(np.sort(order), np.arange(nt))
-    assert cost.min() >= 64 * 17  # 64 paths of at least one ray (1 node + 16) each, recorded for pass 0
-    c = cost[order].astype(np.float64)  # this launch's costs along the order derived from the previous launch's
-    assert c[: nt // 8].mean() > 3 * c[-nt // 8:].mean()
-    monkeypatch.setenv("MGPU_TILE_ORDER", "0")
-    buf = torch.full((H, W, 3), float("nan"), dtype=torch.float32, device="cuda")
-    sc.render_strips_device(frame, W, H, buf.data_ptr(), H, maxPathLength=mpl, passes=passes, plane=plane, seed=5)
-    ref = buf.cpu().numpy()
-    assert not np.isnan(ref).any()
-    for im in imgs:
-        assert im.tobytes() == ref.tobytes()
+    for i in range(9):
+        buf = torch.full((H, W, 3), float("nan"), dtype=torch.float32, device="cuda")
+        ref = torch.full((H, W, 3), float("nan"), dtype=torch.float32, device="cuda")
+        sc.render_strips_device(frame, W, H, buf.data_ptr(), H, maxPathLength=mpl, passes=passes, plane=plane, seed=5,
+                                pass_base=i * passes)
+        plain.render_strips_device(frame, W, H, ref.data_ptr(), H, maxPathLength=mpl, passes=passes, plane=plane, seed=5,
+                                   pass_base=i * passes)
+        a, b = buf.cpu().numpy(), ref.cpu().numpy()
+        assert not np.isnan(b).any() and a.tobytes() == b.tobytes(), i
+        cost, order = sc.tile_order(nt)
+        assert np.array_equal(np.sort(order), np.arange(nt)), i
+        if i in (0, 3, 7):  # the launch before a renewal records: one launch's costs, every tile at least 64 one-ray paths
+            assert cost.min() >= 64 * 17 and cost.max() < 64 * 17 * 400, i
+        else:               # the others leave the table as the last sort zeroed it
+            assert cost.max() == 0, i
+        if i in (1, 4, 8):  # just renewed from the previous launch's costs: expensive tiles first
+            sc2_cost = prev_cost[order].astype(np.float64)
+            assert sc2_cost[: nt // 8].mean() > 3 * sc2_cost[-nt // 8:].mean(), i
+        prev_cost = cost
 
 
 def test_tonemap_matches_driver_transforms():

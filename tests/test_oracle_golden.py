@@ -96,6 +96,23 @@ def test_render_reference_stream_bit_exact(name):
     assert np.array_equal(count, r["count"])
 
 
+@pytest.mark.parametrize("name", ["render_cornell_obj_64_plane_step2_2pass", "render_cornell_obj_60x48_noplane_step4"])
+def test_render_step_reference_stream_bit_exact(name):
+    """Render(step > 1) (render.cc:657-696): one path per block, block fill, count += 3 per pixel and call -- the oracle in
+    the reference's serial stream against the reference's own images, call after call."""
+    r = O.load_golden(name)
+    osc = O.scene_from_golden("cornell_obj")
+    W, H, passes, step = int(r["W"]), int(r["H"]), int(r["passes"]), int(r["step"])
+    frame = O.camera_frame(r["eye"], r["lookat"], r["up"], r["quat"], 45.0, W, H)
+    plane = osc.plane() if int(r["plane"]) else None
+    state = np.array(O.REFERENCE_SEED, "<u4")
+    count = np.zeros((H, W), "<i4")
+    for p in range(passes):
+        img, count, _, _ = osc.render_step(frame, W, H, step, 16, plane, O.RNG_STREAM, stream_state=state, count=count)
+        assert img.tobytes() == r["images"][p].tobytes(), (name, p)
+    assert np.array_equal(count, r["count"]) and int(count.min()) == 3 * passes
+
+
 def test_render_512_digest():
     r = O.load_golden("render_cornell_obj_512_plane_digest")
     sc = O.scene_from_golden("cornell_obj")
