@@ -146,6 +146,16 @@ int mgpu_render_step(MgpuScene *scene, const double origin[3], const double corn
                      const uint32_t *rng_states, uint64_t seed, uint32_t pass_base, float *image_out, int32_t *count_out,
                      MgpuStats *stats);
 
+/* ShowNormal / ShowUV (render.cc:458-516), the reference's two debug integrators (no caller there; they share Render()'s
+ * per-pixel prologue): one jittered primary ray per pixel of the whole frame, Scene::Trace against the mesh only, and the
+ * pixel is the hit's shading normal * 0.5 + 0.5 (MGPU_AOV_NORMAL) or (0.1 * texcoord[0], 0, 0) (MGPU_AOV_UV; a mesh without
+ * facevarying_uvs gives 0 -- the reference reads an unset field there); black on a miss.  image_out (3*W*H float32, host)
+ * is overwritten, count_out (nullable) incremented by 1.  RNG modes as mgpu_render, one start state per pixel. */
+enum { MGPU_AOV_NORMAL = 0, MGPU_AOV_UV = 1 };
+int mgpu_render_aov(MgpuScene *scene, const double origin[3], const double corner[3], const double du[3], const double dv[3],
+                    int W, int H, int kind, int rng_mode, const uint32_t *rng_states, uint64_t seed, uint32_t pass_base,
+                    float *image_out, int32_t *count_out, MgpuStats *stats);
+
 /* Device-resident variant used by the multi-GPU strip renderer and the benchmark: nothing crosses PCIe.
  * The pixel set is a list of row strips: local row j (0 <= j < n_rows) is frame row
  *     y = y_first + (j / strip_h) * y_period + (j % strip_h)

@@ -1015,6 +1015,89 @@ int mgpu_render_step(MgpuScene *s, const double origin[3], const double corner[3
   return MGPU_OK;
 }
 
+int mgpu_render_aov(MgpuScene *s, const double origin[3], const double corner[3], const double du[3], const double dv[3],
+                    int W, int H, int kind, int rng_mode, const uint32_t *rng_states, uint64_t seed, uint32_t pass_base,
+                    float *image_out, int32_t *count_out, MgpuStats *stats) {
+  if (!s || !origin || !corner || !du || !dv || !image_out) return fail(MGPU_ERR_INVALID, "NULL argument");
+  if (W <= 0 || H <= 0 || (uint64_t)W * (uint64_t)H > 0xFFFFFFFFull) return fail(MGPU_ERR_INVALID, "bad frame size");
+  if (kind != MGPU_AOV_NORMAL && kind != MGPU_AOV_UV) return fail(MGPU_ERR_INVALID, "bad AOV kind %d", kind);
+  if (rng_mode == MGPU_RNG_STREAM) return fail(MGPU_ERR_UNSUPPORTED, "MGPU_RNG_STREAM: use MGPU_RNG_TABLE with captured start states");
+  if (rng_mode != MGPU_RNG_TABLE && rng_mode != MGPU_RNG_HASH) return fail(MGPU_ERR_INVALID, "bad rng_mode %d", rng_mode);
+  if (rng_mode == MGPU_RNG_TABLE && !rng_states) return fail(MGPU_ERR_INVALID, "MGPU_RNG_TABLE needs rng_states");
+  std::lock_guard<std::mutex> host_lock(s->host_mutex);
+  const double t0 = now_ms();
+  int rc = set_device(s);
+  if (rc) return rc;
+  if (stats) memset(stats, 0, sizeof(*stats));
+  const size_t npix = (size_t)W * H, img_bytes = sizeof(float) * 3 * npix;
+  if (img_bytes > s->host_img_bytes) {
+    if (s->p_host_img) {
+      (void)hipFree(s->p_host_img);
+      s->device_bytes -= s->host_img_bytes;
+      s->p_host_img = nullptr;
+      s->host_img_bytes = 0;
+    }
+    rc = dev_alloc(s, (void **)&s->p_host_img, img_bytes);
+    if (rc) return rc;
+    s->host_img_bytes = img_bytes;
+  }
+  uint32_t *d_states = nullptr;
+  auto cleanup = [&]() {
+    if (d_states) (void)hipFree(d_states);
+  };
+#define TRY_A(expr)                                                             \
+  do {                                                                          \
+    hipError_t e_ = (expr);                                                     \
+    if (e_ != hipSuccess) {                                                     \
+      cleanup();                                                                \
+      return fail(MGPU_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    }                                                                           \
+  } while (0)
+  if (rng_mode == MGPU_RNG_TABLE) {
+    TRY_A(hipMalloc((void **)&d_states, npix * 16));
+    TRY_A(hipMemcpy(d_states, rng_states, npix * 16, hipMemcpyHostToDevice));
+  }
+  size_t blocks = (npix + kBlock - 1) / kBlock;
+  if (blocks > (size_t)s->num_cu * 8) blocks = (size_t)s->num_cu * 8;
+  rc = ensure_overflow(s, blocks * kBlock);
+  if (rc) {
+    cleanup();
+    return rc;
+  }
+  AovParams P;
+  memcpy(P.frame + 0, origin, 24);
+  memcpy(P.frame + 3, corner, 24);
+  memcpy(P.frame + 6, du, 24);
+  memcpy(P.frame + 9, dv, 24);
+  P.W = W; P.H = H; P.mode = kind; P.rng_mode = rng_mode;
+  P.rng_states = d_states;
+  P.seed = seed;
+  P.pass_base = pass_base;
+  P.image = (float *)s->p_host_img;
+  P.count = nullptr;
+  P.stats = s->p_stats;
+  TRY_A(hipMemsetAsync(s->p_stats, 0, sizeof(unsigned long long) * kStatWords, 0));
+  TRY_A(hipEventRecord(s->ev0, 0));
+  launch_render_aov(s->cap, dim3((unsigned)blocks), 0, s->d, P);
+  TRY_A(hipGetLastError());
+  TRY_A(hipEventRecord(s->ev1, 0));
+  TRY_A(hipMemcpy(image_out, s->p_host_img, img_bytes, hipMemcpyDeviceToHost));
+  unsigned long long w[kStatWords];
+  TRY_A(hipMemcpy(w, s->p_stats, sizeof(w), hipMemcpyDeviceToHost));
+  cleanup();
+  if (count_out)
+    for (size_t i = 0; i < npix; i++) count_out[i] += 1;
+  if (stats) {
+    read_stats(w, stats);
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    stats->kernel_ms = ms;
+    stats->total_ms = now_ms() - t0;
+  }
+  return MGPU_OK;
+#undef TRY_A
+}
+
 int mgpu_render_panoramic_device(MgpuScene *s, const double origin[3], int W, int H, int x0, int y0, int x1, int y1,
                                  int maxPathLength, int samples, int stereo, int rng_mode, const uint32_t *d_rng_states,
                                  uint64_t seed, uint32_t pass_base, float *d_image, int32_t *d_count, void *stream,

@@ -402,6 +402,86 @@ __global__ __launch_bounds__(kBlock, MGPU_RENDER_MIN_WAVES) void k_render(DScene
 }
 
 // =====================================================================================================================
+// k_render_aov: ShowNormal / ShowUV (render.cc:458-516), the reference's two debug integrators: per pixel two draws of
+// jitter, the primary ray, ONE Scene::Trace (mesh only), colour from the hit's shading normal (n * 0.5 + 0.5) or its
+// texture coordinate (0.1 * s, 0, 0), black on a miss.  Primary rays of neighbouring pixels are coherent, which is the
+// case the ray-per-lane traversal is best at: one lane per pixel, waves walk the frame in strides of the grid.
+// =====================================================================================================================
+template <int CAP>
+__global__ __launch_bounds__(kBlock) void k_render_aov(DScene sc, AovParams P) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_stack[kBlock / 64][CAP][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t slot = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  Stack<CAP, true> stk;
+  stk.lds = &s_stack[wave][0][lane];
+  stk.overflow = sc.stack_overflow ? sc.stack_overflow + slot * sc.overflow_cap : nullptr;
+  Counters c{};
+  const size_t npix = (size_t)P.W * (size_t)P.H;
+  for (size_t px = slot; px < npix; px += (size_t)gridDim.x * kBlock) {
+    uint32_t s4[4];
+    if (P.rng_mode == MGPU_RNG_TABLE) {
+      const uint4 q = reinterpret_cast<const uint4 *>(P.rng_states)[px];
+      s4[0] = q.x; s4[1] = q.y; s4[2] = q.z; s4[3] = q.w;
+    } else {
+      hash_state(P.seed, P.pass_base, (uint32_t)px, s4);
+    }
+    Rng rng{s4[0], s4[1], s4[2], s4[3]};
+    const int gx = (int)(px % (size_t)P.W), gy = (int)(px / (size_t)P.W);
+    const float ju = (float)(rng_next(rng) - 0.5);
+    const float jv = (float)(rng_next(rng) - 0.5);
+    const V3 org = v3(P.frame[0], P.frame[1], P.frame[2]);
+    const V3 dir = camera_dir(P.frame, (double)((float)gx + ju), (double)((float)gy + jv));
+    Hit h;
+    traverse<CAP, true>(sc, stk, org, dir, h, c);
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+    if (h.t < kDblMax) { // bvh_accel.cc:838
+      if (P.mode == 0) { // BuildIntersection's shading normal (bvh_accel.cc:731-752)
+        V3 n;
+        if (sc.has_fv_normals) {
+          const double *nn = sc.slot_normal + 9 * (size_t)h.slot;
+          const double w = 1.0 - h.u - h.v;
+          n = v3(w * nn[0] + h.u * nn[3] + h.v * nn[6], w * nn[1] + h.u * nn[4] + h.v * nn[7], w * nn[2] + h.u * nn[5] + h.v * nn[8]);
+        } else {
+          const double *gn = sc.slot_normal + 3 * (size_t)h.slot;
+          n = v3(gn[0], gn[1], gn[2]);
+        }
+        r0 = n.x * 0.5 + 0.5;
+        r1 = n.y * 0.5 + 0.5;
+        r2 = n.z * 0.5 + 0.5;
+      } else if (sc.fv_uvs) { // texcoord[0] (bvh_accel.cc:754-768); without uvs the reference reads an unset field: 0 here
+        const double *uv = sc.fv_uvs + 6 * (size_t)sc.tris[h.slot].face;
+        r0 = 0.1 * ((1.0 - h.u - h.v) * uv[0] + h.u * uv[2] + h.v * uv[4]);
+      }
+    }
+    P.image[3 * px + 0] = (float)r0;
+    P.image[3 * px + 1] = (float)r1;
+    P.image[3 * px + 2] = (float)r2;
+    if (P.count) P.count[px] += 1;
+  }
+  unsigned long long rn = c.rays, nn = c.nodes, tn = c.tris;
+  for (int off = 32; off; off >>= 1) {
+    rn += __shfl_down(rn, off);
+    nn += __shfl_down(nn, off);
+    tn += __shfl_down(tn, off);
+  }
+  if (lane == 0 && P.stats) {
+    atomicAdd(&P.stats[kStatRays], rn);
+    atomicAdd(&P.stats[kStatNodes], nn);
+    atomicAdd(&P.stats[kStatTris], tn);
+    atomicAdd(&P.stats[kStatTraceCalls], rn);
+    atomicAdd(&P.stats[kStatPaths], rn);
+  }
+}
+
+void launch_render_aov(int cap, dim3 grid, hipStream_t s, const DScene &sc, const AovParams &p) {
+  switch (cap) {
+  case 16: hipLaunchKernelGGL(k_render_aov<16>, grid, dim3(kBlock), 0, s, sc, p); break;
+  case 24: hipLaunchKernelGGL(k_render_aov<24>, grid, dim3(kBlock), 0, s, sc, p); break;
+  default: hipLaunchKernelGGL(k_render_aov<32>, grid, dim3(kBlock), 0, s, sc, p); break;
+  }
+}
+
+// =====================================================================================================================
 // launchers
 // =====================================================================================================================
 // =====================================================================================================================

@@ -87,6 +87,18 @@ struct EnvParams {
   uint32_t lds_nodes_bytes, lds_tris_bytes; // LDS_SCENE variant: bytes of nodes / triangles staged into LDS
 };
 hipError_t launch_render_env(int cap, bool lds_scene, dim3 grid, hipStream_t s, const DScene &sc, const EnvParams &p);
+// k_render_aov (mgpu_kernels.hip): ShowNormal (mode 0) / ShowUV (mode 1), one primary ray per pixel of the whole frame
+struct AovParams {
+  double frame[12];
+  int W, H, mode, rng_mode;
+  const uint32_t *rng_states; // device, 4 words per pixel, or null
+  unsigned long long seed;
+  uint32_t pass_base;
+  float *image;   // device, 3 * W * H, overwritten
+  int32_t *count; // device or null, += 1
+  unsigned long long *stats;
+};
+void launch_render_aov(int cap, dim3 grid, hipStream_t s, const DScene &sc, const AovParams &p);
 // k_trace_sm (mgpu_trace_sm.hip): persistent, wave-scheduled batched trace; `counter` = one zeroed device word
 hipError_t launch_trace_sm(dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, uint32_t n,
                            MgpuIntersection *out, uint8_t *hit, uint32_t *counter, unsigned long long *stats,

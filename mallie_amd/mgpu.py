@@ -87,6 +87,8 @@ def load_library():
     L.mgpu_debug_words.restype = i32
     L.mgpu_render_step.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, u64, u32, vp, vp, vp]
     L.mgpu_render_step.restype = i32
+    L.mgpu_render_aov.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, u64, u32, vp, vp, vp]
+    L.mgpu_render_aov.restype = i32
     L.mgpu_occupancy_read.argtypes = [vp, vp]
     L.mgpu_occupancy_read.restype = i32
     L.mgpu_render_panoramic.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, u64, u32, vp, vp,
@@ -285,6 +287,16 @@ class Scene:
                                           x0, y0, x1, y1, maxPathLength, passes, _p(plane), rng_mode, _p(rng_states),
                                           seed, pass_base, _p(image), _p(count), C.byref(st)), "mgpu_render")
         return image, count, st.as_dict()
+
+    def render_aov(self, frame, W, H, kind, rng_mode=RNG_HASH, rng_states=None, seed=1, pass_base=0):
+        """mgpu_render_aov: ShowNormal (kind 0) / ShowUV (kind 1) of the whole frame -> (image, stats)."""
+        frame = _c(frame, "<f8")
+        image = np.zeros((H, W, 3), "<f4")
+        st = Stats()
+        _check(load_library().mgpu_render_aov(self.h, _p(frame[0:3]), _p(frame[3:6]), _p(frame[6:9]), _p(frame[9:12]), W, H,
+                                              kind, rng_mode, _p(_c(rng_states, "<u4")), seed, pass_base, _p(image), None,
+                                              C.byref(st)), "mgpu_render_aov")
+        return image, st.as_dict()
 
     def render_step(self, frame, W, H, step, maxPathLength=16, plane=None, rng_mode=RNG_HASH, rng_states=None, seed=1,
                     pass_base=0, count=None):

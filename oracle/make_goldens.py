@@ -189,6 +189,23 @@ def gen_step_all(tmp):
                step=4)
 
 
+def gen_aov(tmp):
+    """ShowNormal / ShowUV (render.cc:458-516) through oracle/_ref/ref_aov_driver (which #includes the unmodified render.cc)."""
+    drv = os.path.join(HERE, "_ref", "ref_aov_driver")
+    for name, fname, W, H, eye, la, mode in [("aov_cornell_normal_64x48", "cornellbox_suzanne.obj", 64, 48, (0, 0, 20), (0, 0, 0), "normal"),
+                                             ("aov_teapot_normal_72x40", "teapot.obj", 72, 40, (0, 40, 250), (0, 40, 0), "normal"),
+                                             ("aov_teapot_uv_64x48", "teapot.obj", 64, 48, (0, 40, 250), (0, 40, 0), "uv"),
+                                             ("aov_cornell_uv_32x24", "cornellbox_suzanne.obj", 32, 24, (0, 0, 20), (0, 0, 0), "uv")]:
+        out = os.path.join(tmp, name + ".f32")
+        p = subprocess.run([drv, "obj", fname, str(W), str(H), *map(str, eye), *map(str, la), mode, out], cwd=REF,
+                           env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        img = np.fromfile(out, "<f4").reshape(H, W, 3)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), image=img, W=W, H=H, eye=np.array(eye, "f8"), lookat=np.array(la, "f8"),
+                            mode=0 if mode == "normal" else 1, scene=name.split("_")[1])
+        print(name, float(img.mean()), int((img != 0).any(-1).sum()), "non-black pixels")
+
+
 def gen_boundary(tmp):
     """Camera::GenerateEnvRay / GenerateStereoEnvRay (camera.cc:242-329) and Plane::intersect (prim-plane.cc:8-44) probes."""
     rng = np.random.default_rng(11)
@@ -264,6 +281,10 @@ def main():
         with tempfile.TemporaryDirectory() as tmp:
             gen_step_all(tmp)
         return
+    if sys.argv[1:] == ["aov"]:
+        with tempfile.TemporaryDirectory() as tmp:
+            gen_aov(tmp)
+        return
     if sys.argv[1:] == ["boundary"]:
         with tempfile.TemporaryDirectory() as tmp:
             gen_boundary(tmp)
@@ -276,6 +297,7 @@ def main():
         gen_pano_all(tmp)
         gen_step_all(tmp)
         gen_boundary(tmp)
+        gen_aov(tmp)
         gen_camera(tmp)
         mc = gen_mesh(tmp, "obj", "cornellbox_suzanne.obj", "cornell_obj")
         gen_mesh(tmp, "eson", "cornellbox_suzanne.eson", "cornell_eson")

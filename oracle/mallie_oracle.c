@@ -953,6 +953,53 @@ int mo_render(const mo_scene *s, const double frame[12], int W, int H, int x0, i
   return err;
 }
 
+/* ShowNormal (mode 0, render.cc:458-485) / ShowUV (mode 1, render.cc:487-516) for every pixel, in scanline order: two
+ * draws of jitter, the primary ray, Scene::Trace (mesh only, no plane), colour from the hit's shading normal
+ * (n * 0.5 + 0.5) or its texture coordinate (0.1 * s, 0, 0); black on a miss.  A mesh without facevarying_uvs leaves
+ * Intersection::texcoord uninitialised in the reference; it reads as 0 here.  RNG modes as mo_render (one pass). */
+int mo_render_aov(const mo_scene *s, const double frame[12], int W, int H, int mode, int rng_mode, uint32_t stream_state[4],
+                  const uint32_t *rng_states, uint64_t seed, uint32_t pass_base, float *image, uint32_t *states_out,
+                  mo_stats *stats) {
+  if (!s || !frame || !image || W <= 0 || H <= 0 || mode < 0 || mode > 1) return -1;
+  if (rng_mode == MO_RNG_STREAM && !stream_state) return -1;
+  if (rng_mode == MO_RNG_TABLE && !rng_states) return -1;
+  uint64_t nodes = 0, tris = 0, depth = 0, rays = 0;
+  for (int y = 0; y < H; y++)
+    for (int x = 0; x < W; x++) {
+      size_t px = (size_t)y * W + x;
+      uint32_t st[4], *rng = st;
+      if (rng_mode == MO_RNG_STREAM) rng = stream_state;
+      else if (rng_mode == MO_RNG_TABLE) memcpy(st, &rng_states[px * 4], 16);
+      else mo_hash_state(seed, pass_base, (uint32_t)px, st);
+      if (states_out) memcpy(&states_out[px * 4], rng, 16);
+      float ju = (float)(mo_xorshift128(rng) - 0.5);
+      float jv = (float)(mo_xorshift128(rng) - 0.5);
+      double ray[6];
+      mo_generate_ray(frame, (double)((float)x + ju), (double)((float)y + jv), ray);
+      isect_t is;
+      memset(&is, 0, sizeof(is));
+      int hit = traverse(s, &is, v3_load(&ray[0]), v3_load(&ray[3]), &nodes, &tris, &depth);
+      if (hit < 0) return -3;
+      rays++;
+      double rad[3] = {0.0, 0.0, 0.0};
+      if (hit) {
+        if (mode == 0) {
+          rad[0] = is.normal.x * 0.5 + 0.5;
+          rad[1] = is.normal.y * 0.5 + 0.5;
+          rad[2] = is.normal.z * 0.5 + 0.5;
+        } else {
+          rad[0] = 0.1 * is.texcoord[0];
+        }
+      }
+      for (int c = 0; c < 3; c++) image[3 * px + c] = (float)rad[c];
+    }
+  if (stats) {
+    stats->trace_calls += rays; stats->real_rays += rays; stats->nodes += nodes; stats->tris += tris; stats->paths += rays;
+    if (depth > stats->max_stack) stats->max_stack = depth;
+  }
+  return 0;
+}
+
 /* One Render() call with its `step` argument (render.cc:657-696): one path per step x step block -- the block's top-left
  * pixel -- in scanline order, then the block fill, which increments count once per colour channel (3 per pixel); with
  * step == 1 count is incremented once (render.cc:677-679).  W and H must be multiples of step (the reference's fill

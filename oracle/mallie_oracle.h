@@ -64,6 +64,11 @@ enum { MO_RNG_STREAM = 0, MO_RNG_TABLE = 1, MO_RNG_HASH = 2 };
 
 typedef struct mo_scene mo_scene;
 
+/* ---- ShowNormal / ShowUV (render.cc:458-516) ------------------------------------------------------------ */
+int mo_render_aov(const mo_scene *s, const double frame[12], int W, int H, int mode, int rng_mode, uint32_t stream_state[4],
+                  const uint32_t *rng_states, uint64_t seed, uint32_t pass_base, float *image, uint32_t *states_out,
+                  mo_stats *stats);
+
 /* ---- Render(step) ------------------------------------------------------------------------------------ */
 /* One Render() call with its `step` argument (render.cc:657-696); see mallie_oracle.c. Returns 0 on success. */
 int mo_render_step(const mo_scene *s, const double frame[12], int W, int H, int step, int maxPathLength,

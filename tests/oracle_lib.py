@@ -67,6 +67,8 @@ def lib():
         L.mo_render.restype = i32
         L.mo_render_step.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, u64, u32, vp, vp, vp, vp]
         L.mo_render_step.restype = i32
+        L.mo_render_aov.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, u64, u32, vp, vp, vp]
+        L.mo_render_aov.restype = i32
         L.mo_render_panoramic.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, u64, u32, vp, vp,
                                           vp, C.POINTER(Stats), i32]
         L.mo_render_panoramic.restype = i32
@@ -179,6 +181,19 @@ class OracleScene:
             raise RuntimeError("mo_render failed: %d" % rc)
         return image, count, st.as_dict(), states_out
 
+
+    def render_aov(self, frame, W, H, mode, rng_mode=RNG_HASH, stream_state=None, rng_states=None, seed=1, pass_base=0,
+                   want_states=False):
+        """mo_render_aov: ShowNormal (mode 0) / ShowUV (mode 1) for every pixel -> (image, stats, start states or None)."""
+        image = np.zeros((H, W, 3), "<f4")
+        rng_states = _c(rng_states, "<u4")
+        states_out = np.zeros((H, W, 4), "<u4") if want_states else None
+        st = Stats()
+        rc = lib().mo_render_aov(self.h, _p(_c(frame, "<f8")), W, H, mode, rng_mode, _p(stream_state), _p(rng_states), seed,
+                                 pass_base, _p(image), _p(states_out), C.byref(st))
+        if rc:
+            raise RuntimeError("mo_render_aov failed: %d" % rc)
+        return image, st.as_dict(), states_out
 
     def render_step(self, frame, W, H, step, maxPathLength=16, plane=None, rng_mode=RNG_HASH, stream_state=None,
                     rng_states=None, seed=1, pass_base=0, count=None, want_states=False):

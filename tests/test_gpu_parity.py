@@ -337,6 +337,29 @@ def test_render_step_replays_reference_stream(name):
     assert e.value.status == -6  # MGPU_ERR_UNSUPPORTED: the reference's block fill would write outside the image
 
 
+@pytest.mark.parametrize("name", ["aov_cornell_normal_64x48", "aov_teapot_normal_72x40", "aov_teapot_uv_64x48"])
+def test_show_normal_and_show_uv_replay_reference_stream(name):
+    """ShowNormal / ShowUV (render.cc:458-516) on the GPU: the images the reference's own functions produce (start states
+    captured from the oracle's run in the reference's serial stream), the same work counters, and HASH mode at a larger
+    size against the oracle."""
+    r = O.load_golden(name)
+    mesh = "teapot_obj" if "teapot" in name else "cornell_obj"
+    osc, sc = O.scene_from_golden(mesh), gpu_scene(mesh)
+    W, H, kind = int(r["W"]), int(r["H"]), int(r["mode"])
+    frame = M.camera_frame(r["eye"], r["lookat"], width=W, height=H)
+    oimg, ost, states = osc.render_aov(frame, W, H, kind, O.RNG_STREAM, stream_state=np.array(O.REFERENCE_SEED, "<u4"),
+                                       want_states=True)
+    img, st = sc.render_aov(frame, W, H, kind, M.RNG_TABLE, rng_states=states)
+    assert img.tobytes() == r["image"].tobytes() == oimg.tobytes()
+    assert st["real_rays"] == ost["real_rays"] == W * H and st["nodes"] == ost["nodes"] and st["tris"] == ost["tris"]
+    W, H = 640, 360
+    frame = M.camera_frame(r["eye"], r["lookat"], width=W, height=H)
+    oimg, ost, _ = osc.render_aov(frame, W, H, kind, O.RNG_HASH, seed=4, pass_base=2)
+    img, st = sc.render_aov(frame, W, H, kind, M.RNG_HASH, seed=4, pass_base=2)
+    assert img.tobytes() == oimg.tobytes() and st["nodes"] == ost["nodes"] and st["tris"] == ost["tris"]
+    assert (img != 0).any()
+
+
 def test_path_probe_every_iteration_vs_oracle():
     """Iteration-level parity of PathTrace: origin, direction, hit distance, shading normal, material and running
     throughput / radiance of every loop iteration, device vs oracle, for a lattice of pixels and three scenes.  IEEE

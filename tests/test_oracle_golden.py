@@ -113,6 +113,21 @@ def test_render_step_reference_stream_bit_exact(name):
     assert np.array_equal(count, r["count"]) and int(count.min()) == 3 * passes
 
 
+@pytest.mark.parametrize("name", ["aov_cornell_normal_64x48", "aov_teapot_normal_72x40", "aov_teapot_uv_64x48",
+                                  "aov_cornell_uv_32x24"])
+def test_show_normal_and_show_uv_reference_stream_bit_exact(name):
+    """ShowNormal / ShowUV (render.cc:458-516): the oracle in the reference's serial stream against images produced by the
+    reference's own functions (oracle/ref_aov_driver.cc #includes the unmodified render.cc)."""
+    r = O.load_golden(name)
+    osc = O.scene_from_golden("teapot_obj" if "teapot" in name else "cornell_obj")
+    W, H = int(r["W"]), int(r["H"])
+    frame = O.camera_frame(r["eye"], r["lookat"], width=W, height=H)
+    img, st, _ = osc.render_aov(frame, W, H, int(r["mode"]), O.RNG_STREAM, stream_state=np.array(O.REFERENCE_SEED, "<u4"))
+    assert img.tobytes() == r["image"].tobytes() and st["real_rays"] == W * H
+    if "teapot" in name:
+        assert (img != 0).any()
+
+
 def test_render_512_digest():
     r = O.load_golden("render_cornell_obj_512_plane_digest")
     sc = O.scene_from_golden("cornell_obj")
