@@ -238,6 +238,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the occupancy pass, the read-back timing and extra_configs")
+    ap.add_argument("--exchange", choices=("rccl", "torch"), default="rccl",
+                    help="N > 1: rccl = the C ABI's multi-GPU frame (RCCL called directly), torch = torch.distributed gather")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames enqueued concurrently (own stream and buffers each); default 1 on one GPU -- kernel time "
                          "then is what rocprofv3 shows -- and 3 on N > 1, where the RCCL gather and the end of a launch "
@@ -281,6 +283,46 @@ def main():
     fif = args.frames_in_flight if args.frames_in_flight > 0 else (1 if world == 1 else 3)
     fr = FrameRenderer(scene, frame, W, H, mpl, spp, plane, cfg["seed"], rank, world, dev, frames_in_flight=fif,
                        force_collective=force_gather)
+    # N > 1: the exchange goes through the C ABI's multi-GPU frame (mgpu_frame_*: RCCL called directly, every strip received
+    # at its final rows of rank 0's frame); torch.distributed only carries the 128-byte communicator id and the barriers.
+    # --exchange torch keeps the torch.distributed gather of mallie_amd/frame.py.  All ranks take the same path.
+    cframe, exchange = None, "none"
+    if world == 1 and os.environ.get("MGPU_FRAME_FORCE_EXCHANGE"):  # debugging aid: the C ABI's exchange path on one GPU
+        cframe = M.Frame.create_rank(scene, local_rank, 0, 1, None, W, H, strip_h=8, frames_in_flight=fif)
+        exchange = "mgpu_frame_* forced on one GPU (RCCL send/recv to self)"
+    if world > 1:
+        exchange = "torch.distributed gather + re-interleave (mallie_amd/frame.py)"
+        if args.exchange == "rccl":
+            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+            ok = torch.ones(1, dtype=torch.int32, device=dev)
+            try:
+                if rank == 0:
+                    uid.copy_(torch.from_numpy(M.frame_unique_id()))
+                dist.broadcast(uid, src=0)
+                cframe = M.Frame.create_rank(scene, local_rank, rank, world, uid.cpu().numpy(), W, H, strip_h=8, frames_in_flight=fif)
+            except Exception as e:  # noqa: BLE001 -- whatever it is, every rank must learn about it
+                sys.stderr.write("rank %d: mgpu_frame_create_rank failed (%r), falling back to the torch gather\n" % (rank, e))
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                exchange = "mgpu_frame_* (C ABI): grouped ncclSend/ncclRecv, strips received at their final rows"
+            elif cframe is not None:
+                cframe.close()
+                cframe = None
+
+    pending = []
+
+    def render_frame(k):
+        if cframe is not None:
+            pending.append(cframe.render(frame, mpl, spp, plane, seed=cfg["seed"], pass_base=k * spp))
+        else:
+            fr.render(pass_base=k * spp)
+
+    def finish_frames():
+        if cframe is not None:
+            for slot in sorted(set(pending[-fif:])):
+                cframe.wait(slot)
+            del pending[:]
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -289,14 +331,16 @@ def main():
             torch.cuda.synchronize(dev)
 
     for k in range(args.warmup):
-        fr.render(pass_base=k * spp)
+        render_frame(k)
+    finish_frames()
     sync_all()
     flush_c_stdio()  # the communicators exist by now: whatever RCCL had to say goes out before the measurement
     scene.stats_read(reset=True)
     scene.timing_enable(True)
     t0 = time.perf_counter()
     for k in range(args.steps):
-        fr.render(pass_base=k * spp)  # frame k = passes [k*spp, (k+1)*spp): the next 16 samples per pixel, not the same ones
+        render_frame(k)  # frame k = passes [k*spp, (k+1)*spp): the next 16 samples per pixel, not the same ones
+    finish_frames()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier(device_ids=[local_rank])
@@ -359,7 +403,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workloads.describe(cfg, len(faces)) + "; 1 step = 1 frame = the next %d passes per pixel "
                                    "(pass_base advances by %d per step)" % (spp, spp),
-                       "parallelism": "replicated scene, interleaved 8-row strips x%d, 1 RCCL gather/frame" % world
+                       "parallelism": "replicated scene, interleaved 8-row strips x%d, 1 RCCL exchange/frame: %s" % (world, exchange)
                                       if world > 1 else "single GPU, persistent-threads kernel",
                        "frames_in_flight": fif,
                        "rays_per_frame": int(rays / args.steps), "trace_calls_per_frame": int(trace_calls / args.steps),
@@ -415,6 +459,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, frame, plane, mpl, last_pass_base, gpu_frame)
     else:
         out = None
+    if cframe is not None:
+        cframe.close()
     if world > 1 or force_gather:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()

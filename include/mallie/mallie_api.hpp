@@ -10,6 +10,8 @@
 //  * mallie::Render cannot reproduce the reference's per-OpenMP-thread RNG stream (render.cc:116-168): paths are seeded
 //    per (pixel, pass) instead (MGPU_RNG_HASH, seed settable with mallie::SetRenderSeed), or from a caller-supplied
 //    table of start states (mallie::SetRenderRngTable).  Given the same start states the image is the reference's.
+//  * MALLIE_GPUS=n in the environment makes mallie::Render / RenderPasses use n GPUs of the node (scene replicated,
+//    interleaved 8-row strips, one RCCL exchange per frame; mgpu_frame_* in include/mgpu.h).  The image does not depend on n.
 //  * kMaxPathLength (render.cc:52) is a run-time setting here: mallie::SetMaxPathLength (default 16 = reference).
 //  * Render() with step > 1 (progressive block fill, render.cc:684-696) needs a frame whose sizes are multiples of the
 //    step: for other sizes the reference writes outside the image, and this implementation reports an error instead.
@@ -203,6 +205,9 @@ public:
 
   // Extensions used by mallie::Render and tests.
   MgpuScene *DeviceScene() { return accel_.DeviceScene(&mesh_, &materials_); }
+  // a further copy of the scene in the HBM of `device` (multi-GPU rendering, MALLIE_GPUS); the caller releases it with
+  // mgpu_scene_destroy
+  MgpuScene *CreateDeviceScene(int device);
   const Mesh &GetMesh() const { return mesh_; }
   BVHAccel &GetAccel() { return accel_; }
 

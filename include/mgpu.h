@@ -175,6 +175,36 @@ int mgpu_render_strips_device(MgpuScene *scene, const double frame[12], int W, i
                               const float plane[4], int rng_mode, const uint32_t *d_rng_states, uint64_t seed,
                               uint32_t pass_base, float *d_image, int32_t *d_count, void *stream, MgpuStats *stats);
 
+/* -- Multi-GPU frames: the image is cut into interleaved strips of `strip_h` rows, rank r owns strips
+ *    r, r + world, ...; the scene is replicated (one MgpuScene per GPU, created by the caller with mgpu_scene_create on
+ *    that device); every GPU renders its strips (Render() semantics, MGPU_RNG_HASH seeding, so the frame does not depend on
+ *    the GPU count) and ONE exchange step per frame -- grouped ncclSend / ncclRecv over RCCL / xGMI, each strip received
+ *    at its final rows -- assembles the float RGB frame in rank 0's HBM.  RCCL is loaded on first use (dlopen), and not
+ *    at all for one GPU.  Up to 4 frames may be in flight (own streams and buffers each): mgpu_frame_render only
+ *    enqueues, mgpu_frame_wait blocks until a slot's frame is complete. -------------------------------------------------- */
+typedef struct MgpuFrame MgpuFrame;
+/* One process driving n GPUs (ncclCommInitAll): scenes[r] lives on devices[r] and becomes rank r. */
+int mgpu_frame_create(MgpuScene *const *scenes, const int *devices, int n, int W, int H, int strip_h, int frames_in_flight,
+                      MgpuFrame **out);
+/* One process per GPU (ncclCommInitRank): `id` = the 128 bytes mgpu_frame_unique_id produced on ONE rank, distributed by the
+ * caller (MPI, torch.distributed, a file ...); may be NULL when world == 1.  Collective: every rank must call it. */
+int mgpu_frame_unique_id(unsigned char id[128]);
+int mgpu_frame_create_rank(MgpuScene *scene, int device, int rank, int world, const unsigned char id[128], int W, int H,
+                           int strip_h, int frames_in_flight, MgpuFrame **out);
+int mgpu_frame_destroy(MgpuFrame *frame);
+/* Enqueues one frame of `passes` passes (camera frame as mgpu_camera_frame; plane NULL = off; rng_mode MGPU_RNG_HASH) on
+ * the next slot and returns that slot's index.  Collective across the ranks of a multi-process frame. */
+int mgpu_frame_render(MgpuFrame *frame, const double cam[12], int maxPathLength, int passes, const float plane[4],
+                      int rng_mode, uint64_t seed, uint32_t pass_base, int *slot_out);
+/* Waits for the frame of `slot`.  On the process that holds rank 0: *device_image (nullable) receives the device pointer
+ * of the H x W x 3 float frame (valid until the slot is used again), host_image (nullable) a copy of it. */
+int mgpu_frame_wait(MgpuFrame *frame, int slot, float *host_image, float **device_image);
+/* Makes `stream` (a hipStream_t on rank 0's device) wait for the slot's frame without blocking the host. */
+int mgpu_frame_done_event_wait(MgpuFrame *frame, int slot, void *stream);
+/* Rows of a W x H frame that rank `rank` of `world` owns with strips of strip_h rows (-1 on bad arguments). */
+int mgpu_frame_rows(int H, int strip_h, int world, int rank);
+const char *mgpu_frame_last_error(void);
+
 /* -- RenderPanoramic (render.cc:710-763; PathTraceEnv render.cc:518-590; Camera::GenerateEnvRay / GenerateStereoEnvRay
  *    camera.cc:242-329) -- what the reference's console driver renders (main_console.cc:111) --------------------------- */
 /* One RenderPanoramic() call on the window [x0,x1) x [y0,y1) of a W x H equirectangular frame: every window pixel of

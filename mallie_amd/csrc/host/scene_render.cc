@@ -142,6 +142,25 @@ void Scene::BoundingBox(real3 &bmin, real3 &bmax) {
   }
 }
 
+MgpuScene *Scene::CreateDeviceScene(int device) {
+  const std::vector<BVHNode> &nodes = accel_.GetNodes();
+  const std::vector<unsigned int> &indices = accel_.GetIndices();
+  if (nodes.empty() || !mesh_.vertices) return NULL;
+  std::vector<double> diffuse;
+  for (size_t i = 0; i < materials_.size(); i++)
+    for (int k = 0; k < 3; k++) diffuse.push_back(materials_[i].diffuse[k]);
+  MgpuScene *s = NULL;
+  const int rc = mgpu_scene_create(mesh_.vertices, mesh_.numVertices, mesh_.faces, mesh_.numFaces, mesh_.materialIDs,
+                                   mesh_.facevarying_normals, mesh_.facevarying_uvs,
+                                   reinterpret_cast<const MgpuNode *>(&nodes[0]), nodes.size(), &indices[0],
+                                   diffuse.empty() ? NULL : &diffuse[0], diffuse.size() / 3, device, &s);
+  if (rc != MGPU_OK) {
+    printf("Mallie:err\tmsg:GPU scene upload to device %d failed: %s\n", device, mgpu_last_error());
+    return NULL;
+  }
+  return s;
+}
+
 real3 Scene::GetBackgroundRadiance(real3 &dir) {
   (void)dir;
   return real3(0.75, 0.75, 0.75); // scene.cc:335-338
@@ -168,6 +187,62 @@ int gMaxPathLength = 16;
 unsigned long long gSeed = 1;
 unsigned int gPassCounter = 0;
 const unsigned int *gRngTable = NULL;
+
+// MALLIE_GPUS=n: the frame object that spreads Render() over n GPUs, kept while scene and frame size stay the same
+struct MultiGpu {
+  const Scene *scene;
+  int n, W, H;
+  std::vector<MgpuScene *> scenes; // [0] belongs to the Scene, the others are ours
+  MgpuFrame *frame;
+  MultiGpu() : scene(NULL), n(0), W(0), H(0), frame(NULL) {}
+  void release() {
+    if (frame) mgpu_frame_destroy(frame);
+    frame = NULL;
+    for (size_t i = 1; i < scenes.size(); i++) mgpu_scene_destroy(scenes[i]);
+    scenes.clear();
+    scene = NULL;
+  }
+};
+MultiGpu gMulti;
+
+int wanted_gpus() {
+  const char *e = getenv("MALLIE_GPUS");
+  if (!e) return 1;
+  int n = atoi(e);
+  const int have = mgpu_device_count();
+  if (n > have) n = have;
+  return n < 1 ? 1 : n;
+}
+
+MgpuFrame *multi_frame(Scene &scene, int n, int W, int H) {
+  if (gMulti.frame && gMulti.scene == &scene && gMulti.n == n && gMulti.W == W && gMulti.H == H &&
+      gMulti.scenes[0] == scene.DeviceScene())
+    return gMulti.frame;
+  gMulti.release();
+  MgpuScene *first = scene.DeviceScene();
+  if (!first) return NULL;
+  gMulti.scenes.push_back(first);
+  std::vector<int> devices(1, 0);
+  for (int d = 1; d < n; d++) {
+    MgpuScene *r = scene.CreateDeviceScene(d);
+    if (!r) {
+      gMulti.release();
+      return NULL;
+    }
+    gMulti.scenes.push_back(r);
+    devices.push_back(d);
+  }
+  if (mgpu_frame_create(&gMulti.scenes[0], &devices[0], n, W, H, 8, 1, &gMulti.frame) != MGPU_OK) {
+    printf("Mallie:err\tmsg:multi-GPU frame: %s\n", mgpu_frame_last_error());
+    gMulti.release();
+    return NULL;
+  }
+  gMulti.scene = &scene;
+  gMulti.n = n;
+  gMulti.W = W;
+  gMulti.H = H;
+  return gMulti.frame;
+}
 
 void plane_from_bbox(const double bmin[3], const double bmax[3], float pl[4]) {
   // render.cc:622-626: float zmin, float zsize, d = -(zmin - zsize * 0.0001f)
@@ -225,6 +300,27 @@ static bool render_impl(Scene &scene, const RenderConfig &config, std::vector<fl
     return false;
   }
   MgpuStats st;
+  memset(&st, 0, sizeof(st));
+  const int gpus = (step == 1 && !table) ? wanted_gpus() : 1;
+  const char *force_frame = getenv("MGPU_FRAME_FORCE_EXCHANGE"); // one GPU through the multi-GPU machinery (tests)
+  if (gpus > 1 || (step == 1 && !table && force_frame && atoi(force_frame) != 0)) { // the same frame from n GPUs: strips, one RCCL exchange, assembled on device 0 (include/mgpu.h, mgpu_frame_*)
+    MgpuFrame *mf = multi_frame(scene, gpus, width, height);
+    if (!mf) return false;
+    const double cam[12] = {origin[0], origin[1], origin[2], corner[0], corner[1], corner[2],
+                            du[0],     du[1],     du[2],     dv[0],     dv[1],     dv[2]};
+    int slot = 0;
+    int rc = mgpu_frame_render(mf, cam, gMaxPathLength, passes, gPlane ? pl : NULL, MGPU_RNG_HASH, gSeed, gPassCounter, &slot);
+    if (rc == MGPU_OK) rc = mgpu_frame_wait(mf, slot, &image[0], NULL);
+    if (rc != MGPU_OK) {
+      printf("Mallie:err\tmsg:multi-GPU Render failed: %s\n", mgpu_frame_last_error());
+      return false;
+    }
+    for (size_t i = 0; i < (size_t)width * height; i++) count[i] += passes;
+    gPassCounter += (unsigned int)passes;
+    printf("\r[Mallie] Render on %d GPUs", gpus);
+    fflush(stdout);
+    return true;
+  }
   const int rc = step == 1
                      ? mgpu_render(dev, origin, corner, du, dv, width, height, 0, 0, width, height, gMaxPathLength, passes,
                                    gPlane ? pl : NULL, table ? MGPU_RNG_TABLE : MGPU_RNG_HASH, gRngTable, gSeed, gPassCounter,

@@ -89,6 +89,23 @@ def load_library():
     L.mgpu_render_step.restype = i32
     L.mgpu_render_aov.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, u64, u32, vp, vp, vp]
     L.mgpu_render_aov.restype = i32
+    L.mgpu_frame_create.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.POINTER(vp)]
+    L.mgpu_frame_create.restype = i32
+    L.mgpu_frame_create_rank.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, i32, C.POINTER(vp)]
+    L.mgpu_frame_create_rank.restype = i32
+    L.mgpu_frame_unique_id.argtypes = [vp]
+    L.mgpu_frame_unique_id.restype = i32
+    L.mgpu_frame_destroy.argtypes = [vp]
+    L.mgpu_frame_destroy.restype = i32
+    L.mgpu_frame_render.argtypes = [vp, vp, i32, i32, vp, i32, u64, u32, C.POINTER(i32)]
+    L.mgpu_frame_render.restype = i32
+    L.mgpu_frame_wait.argtypes = [vp, i32, vp, C.POINTER(vp)]
+    L.mgpu_frame_wait.restype = i32
+    L.mgpu_frame_done_event_wait.argtypes = [vp, i32, vp]
+    L.mgpu_frame_done_event_wait.restype = i32
+    L.mgpu_frame_rows.argtypes = [i32, i32, i32, i32]
+    L.mgpu_frame_rows.restype = i32
+    L.mgpu_frame_last_error.restype = C.c_char_p
     L.mgpu_occupancy_read.argtypes = [vp, vp]
     L.mgpu_occupancy_read.restype = i32
     L.mgpu_render_panoramic.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, u64, u32, vp, vp,
@@ -201,6 +218,88 @@ def plane_from_bbox(bmin, bmax):
     pl = np.zeros(4, "<f4")
     load_library().mgpu_plane_from_bbox(_p(_c(bmin, "<f8")), _p(_c(bmax, "<f8")), _p(pl))
     return pl
+
+
+def frame_rows(H, strip_h, world, rank):
+    """Rows of an H-row frame owned by `rank` of `world` with strips of strip_h rows (mgpu_frame_rows)."""
+    return load_library().mgpu_frame_rows(H, strip_h, world, rank)
+
+
+def frame_unique_id():
+    """128-byte RCCL communicator id for Frame.create_rank: make it on ONE rank and hand it to the others."""
+    buf = np.zeros(128, "u1")
+    rc = load_library().mgpu_frame_unique_id(_p(buf))
+    if rc:
+        raise MgpuError(rc, "mgpu_frame_unique_id", load_library().mgpu_frame_last_error().decode())
+    return buf
+
+
+class Frame:
+    """Multi-GPU frames behind the C ABI (mgpu_frame_*): interleaved row strips, one RCCL exchange per frame, the float
+    frame assembled in rank 0's HBM.  Frame(scenes, devices, ...) drives several GPUs from this process;
+    Frame.create_rank(scene, device, rank, world, id, ...) is one rank of a process-per-GPU job."""
+
+    def __init__(self, scenes=None, devices=None, W=0, H=0, strip_h=8, frames_in_flight=1, _handle=None, _keep=None):
+        self.W, self.H = W, H
+        self._keep = _keep if _keep is not None else list(scenes)
+        if _handle is not None:
+            self.h = _handle
+            return
+        L = load_library()
+        hs = (C.c_void_p * len(scenes))(*[s.h for s in scenes])
+        dv = (C.c_int * len(scenes))(*devices)
+        h = C.c_void_p()
+        rc = L.mgpu_frame_create(hs, dv, len(scenes), W, H, strip_h, frames_in_flight, C.byref(h))
+        if rc:
+            raise MgpuError(rc, "mgpu_frame_create", L.mgpu_frame_last_error().decode())
+        self.h = h
+
+    @classmethod
+    def create_rank(cls, scene, device, rank, world, uid, W, H, strip_h=8, frames_in_flight=1):
+        L = load_library()
+        h = C.c_void_p()
+        rc = L.mgpu_frame_create_rank(scene.h, device, rank, world, _p(_c(uid, "u1")) if uid is not None else None, W, H, strip_h,
+                                      frames_in_flight, C.byref(h))
+        if rc:
+            raise MgpuError(rc, "mgpu_frame_create_rank", L.mgpu_frame_last_error().decode())
+        return cls(W=W, H=H, _handle=h, _keep=[scene])
+
+    def close(self):
+        if getattr(self, "h", None):
+            load_library().mgpu_frame_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, cam, maxPathLength, passes, plane=None, seed=1, pass_base=0, rng_mode=RNG_HASH):
+        """Enqueues one frame; returns the slot to wait for."""
+        slot = C.c_int(-1)
+        L = load_library()
+        rc = L.mgpu_frame_render(self.h, _p(_c(cam, "<f8")), maxPathLength, passes, _p(_c(plane, "<f4")), rng_mode, seed, pass_base,
+                                 C.byref(slot))
+        if rc:
+            raise MgpuError(rc, "mgpu_frame_render", L.mgpu_frame_last_error().decode())
+        return slot.value
+
+    def wait(self, slot, to_host=False):
+        """Blocks until the slot's frame is complete. Returns the device pointer of rank 0's frame (0 on other ranks), or a
+        host array (H x W x 3 float32) with to_host=True."""
+        L = load_library()
+        dev = C.c_void_p()
+        host = np.zeros((self.H, self.W, 3), "<f4") if to_host else None
+        rc = L.mgpu_frame_wait(self.h, slot, _p(host), C.byref(dev))
+        if rc:
+            raise MgpuError(rc, "mgpu_frame_wait", L.mgpu_frame_last_error().decode())
+        return host if to_host else (dev.value or 0)
+
+    def stream_wait(self, slot, stream):
+        rc = load_library().mgpu_frame_done_event_wait(self.h, slot, C.c_void_p(stream))
+        if rc:
+            raise MgpuError(rc, "mgpu_frame_done_event_wait", load_library().mgpu_frame_last_error().decode())
 
 
 class Scene:

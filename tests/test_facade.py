@@ -255,6 +255,27 @@ def test_facade_render_and_trace_on_gpu(driver, tmp_path):
 
 
 @pytest.mark.gpu
+def test_facade_render_through_the_multi_gpu_frame(driver, tmp_path):
+    """mallie::Render / RenderPasses through the multi-GPU frame object (what MALLIE_GPUS=n selects), forced on the one GPU
+    there is: strips, ncclSend / ncclRecv to their final rows, read-back -- the image must be the single-GPU image (the driver
+    itself checks RenderPasses against Render + AccumImage, this test checks it against the oracle)."""
+    obj = str(tmp_path / "cornell_like.obj")
+    _write_cornell_obj(obj)
+    W, H, passes, mpl, seed = 96, 61, 3, 6, 5
+    out = str(tmp_path / "img.f32")
+    r = subprocess.run([driver, "render", "obj", obj, str(W), str(H), "1", str(passes), str(mpl), str(seed), out],
+                       capture_output=True, text=True, cwd=str(tmp_path), env=dict(os.environ, MGPU_FRAME_FORCE_EXCHANGE="1", MALLIE_GPUS="8"))
+    assert r.returncode == 0 and "Render on 1 GPUs" in r.stdout, r.stdout + r.stderr
+    raw = np.fromfile(out, "<f4")
+    img, count = raw[: 3 * W * H].reshape(H, W, 3), raw[3 * W * H:].view("<i4").reshape(H, W)
+    g = O.load_golden("cornell_obj")
+    osc = O.OracleScene(g["verts"].astype(np.float64), g["faces"], np.full(len(g["faces"]), 0xFFFFFFFF, "u4"), g["normals"], None)
+    frame = O.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    oimg, _, _, _ = osc.render(frame, W, H, mpl, passes, osc.plane(), O.RNG_HASH, seed=seed)
+    assert img.tobytes() == oimg.tobytes() and np.all(count == passes)
+
+
+@pytest.mark.gpu
 def test_facade_renders_a_vox_scene_with_its_palette(driver, tmp_path):
     """Scene::Init(.vox) -> mallie::Render on the GPU: the palette materials colour the paths (R, G, B differ) and the
     image equals the oracle's for the same arrays, materials and seeding."""

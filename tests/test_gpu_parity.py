@@ -861,6 +861,33 @@ print("RCCL_PATH_OK")
     assert r.returncode == 0 and "RCCL_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+@pytest.mark.parametrize("force", [0, 1])
+def test_c_abi_frame_on_one_gpu(force, monkeypatch):
+    """mgpu_frame_* (the multi-GPU frame behind the C ABI) on the one GPU there is: world = 1 through the plain path, and
+    with MGPU_FRAME_FORCE_EXCHANGE=1 through the N > 1 machinery -- ncclCommInitAll, a group of ncclSend / ncclRecv of every
+    strip to its final rows, communicator stream, events -- with three frames in flight on a ragged frame height.  Every
+    frame must equal the single-launch frame of the same passes byte for byte."""
+    import torch
+    if force:
+        monkeypatch.setenv("MGPU_FRAME_FORCE_EXCHANGE", "1")
+    sc = gpu_scene("cornell_obj")
+    W, H, mpl, passes = 320, 203, 5, 3
+    cam = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    plane = sc.plane()
+    fr = M.Frame([sc], [0], W, H, strip_h=8, frames_in_flight=3)
+    slots = [fr.render(cam, mpl, passes, plane, seed=7, pass_base=k * passes) for k in range(3)]
+    assert sorted(slots) == [0, 1, 2]
+    frames = [fr.wait(s, to_host=True) for s in slots]
+    slots2 = [fr.render(cam, mpl, passes, plane, seed=7, pass_base=(3 + k) * passes) for k in range(2)]  # slots are reused
+    frames += [fr.wait(s, to_host=True) for s in slots2]
+    for k, img in enumerate(frames):
+        ref = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        sc.render_strips_device(cam, W, H, ref.data_ptr(), H, maxPathLength=mpl, passes=passes, plane=plane, seed=7,
+                                pass_base=k * passes)
+        assert img.tobytes() == ref.cpu().numpy().tobytes(), k
+    fr.close()
+
+
 @pytest.mark.parametrize("strip_h,parts", [(5, 3), (8, 2), (13, 4), (1, 2)])
 def test_odd_strip_layouts_reassemble_to_the_full_frame(strip_h, parts):
     """mgpu_render_strips_device with strips that are not multiples of the 8-row work tiles, a frame height that is not a

@@ -14,6 +14,18 @@ import oracle_lib as O
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def test_frame_strip_ownership_matches_the_python_partition():
+    """mgpu_frame_rows (the C ABI's multi-GPU frame) and mallie_amd.frame.strip_rows (the torch.distributed path) cut a
+    frame the same way, for ragged heights and strip heights too."""
+    from mallie_amd.frame import strip_rows
+    for H in (1, 7, 8, 9, 135, 1080, 2160, 1081):
+        for sh in (1, 5, 8, 13):
+            for world in (1, 2, 3, 4, 8):
+                rows = [M.frame_rows(H, sh, world, r) for r in range(world)]
+                assert rows == [len(strip_rows(H, world, r, sh)) for r in range(world)] and sum(rows) == H
+    assert M.frame_rows(10, 8, 2, 2) == -1 and M.frame_rows(10, 0, 2, 0) == -1
+
+
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "mgpu.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
