@@ -203,6 +203,11 @@ int mgpu_frame_wait(MgpuFrame *frame, int slot, float *host_image, float **devic
 int mgpu_frame_done_event_wait(MgpuFrame *frame, int slot, void *stream);
 /* Rows of a W x H frame that rank `rank` of `world` owns with strips of strip_h rows (-1 on bad arguments). */
 int mgpu_frame_rows(int H, int strip_h, int world, int rank);
+/* The exchange plan of rank `owner`: one piece per strip, in strip order -- offset in the owner's local strip buffer,
+ * offset in the whole frame, number of floats.  The sender walks it with ncclSend, rank 0 with ncclRecv.  Returns the
+ * number of pieces (the arrays receive at most max_pieces of them; any may be NULL), -1 on bad arguments. */
+int mgpu_frame_plan(int W, int H, int strip_h, int world, int owner, size_t *local_off, size_t *frame_off, size_t *count,
+                    int max_pieces);
 const char *mgpu_frame_last_error(void);
 
 /* -- RenderPanoramic (render.cc:710-763; PathTraceEnv render.cc:518-590; Camera::GenerateEnvRay / GenerateStereoEnvRay

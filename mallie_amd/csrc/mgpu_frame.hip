@@ -124,6 +124,22 @@ int rows_of(int H, int strip_h, int world, int rank) {
   return n;
 }
 
+// The exchange plan, one (offset, count) pair in floats per strip of rank `owner`, in strip order: offsets into the owner's
+// local strip buffer (sender side) and into the whole frame (receiver side).  Both sides walk this one list, so the
+// sends of a rank and the receives rank 0 posts for it match in number, order and size by construction.
+struct Piece {
+  size_t local_off, frame_off, count;
+};
+void plan_of(int W, int H, int strip_h, int world, int owner, std::vector<Piece> &out) {
+  out.clear();
+  size_t off = 0;
+  for (int y0 = owner * strip_h; y0 < H; y0 += world * strip_h) {
+    const size_t cnt = (size_t)3 * W * ((H - y0 < strip_h) ? (H - y0) : strip_h);
+    out.push_back(Piece{off, (size_t)3 * W * y0, cnt});
+    off += cnt;
+  }
+}
+
 int create_common(MgpuFrame *f) {
   for (Member &m : f->members) {
     FHIP(hipSetDevice(m.device));
@@ -150,6 +166,19 @@ const char *mgpu_frame_last_error(void) { return g_ferr; }
 int mgpu_frame_rows(int H, int strip_h, int world, int rank) {
   if (H < 0 || strip_h <= 0 || world <= 0 || rank < 0 || rank >= world) return -1;
   return rows_of(H, strip_h, world, rank);
+}
+
+int mgpu_frame_plan(int W, int H, int strip_h, int world, int owner, size_t *local_off, size_t *frame_off, size_t *count,
+                    int max_pieces) {
+  if (W <= 0 || H <= 0 || strip_h <= 0 || world <= 0 || owner < 0 || owner >= world) return -1;
+  std::vector<Piece> plan;
+  plan_of(W, H, strip_h, world, owner, plan);
+  for (int i = 0; i < (int)plan.size() && i < max_pieces; ++i) {
+    if (local_off) local_off[i] = plan[i].local_off;
+    if (frame_off) frame_off[i] = plan[i].frame_off;
+    if (count) count[i] = plan[i].count;
+  }
+  return (int)plan.size();
 }
 
 int mgpu_frame_unique_id(unsigned char id[128]) {
@@ -305,20 +334,16 @@ int mgpu_frame_render(MgpuFrame *f, const double cam[12], int maxPathLength, int
     FNCCL(g_rccl.GroupStart());
     for (Member &m : f->members) {
       Slot &s = m.slot[k];
+      std::vector<Piece> plan;
       if (m.rank != 0 || f->force_exchange) { // sends: this rank's strips, in strip order
-        size_t off = 0;
-        for (int y0 = m.rank * sh; y0 < H; y0 += world * sh) {
-          const size_t cnt = (size_t)3 * W * ((H - y0 < sh) ? (H - y0) : sh);
-          FNCCL(g_rccl.Send(s.local + off, cnt, ncclFloat, 0, m.comm, m.comm_stream));
-          off += cnt;
-        }
+        plan_of(W, H, sh, world, m.rank, plan);
+        for (const Piece &p : plan) FNCCL(g_rccl.Send(s.local + p.local_off, p.count, ncclFloat, 0, m.comm, m.comm_stream));
       }
       if (m.rank == 0) { // receives: every other rank's strips (its own too when the exchange is forced), at their final rows
-        for (int r = f->force_exchange ? 0 : 1; r < world; ++r)
-          for (int y0 = r * sh; y0 < H; y0 += world * sh) {
-            const size_t cnt = (size_t)3 * W * ((H - y0 < sh) ? (H - y0) : sh);
-            FNCCL(g_rccl.Recv(s.frame + (size_t)3 * W * y0, cnt, ncclFloat, r, m.comm, m.comm_stream));
-          }
+        for (int r = f->force_exchange ? 0 : 1; r < world; ++r) {
+          plan_of(W, H, sh, world, r, plan);
+          for (const Piece &p : plan) FNCCL(g_rccl.Recv(s.frame + p.frame_off, p.count, ncclFloat, r, m.comm, m.comm_stream));
+        }
       }
     }
     FNCCL(g_rccl.GroupEnd());

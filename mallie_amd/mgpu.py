@@ -105,6 +105,8 @@ def load_library():
     L.mgpu_frame_done_event_wait.restype = i32
     L.mgpu_frame_rows.argtypes = [i32, i32, i32, i32]
     L.mgpu_frame_rows.restype = i32
+    L.mgpu_frame_plan.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, i32]
+    L.mgpu_frame_plan.restype = i32
     L.mgpu_frame_last_error.restype = C.c_char_p
     L.mgpu_occupancy_read.argtypes = [vp, vp]
     L.mgpu_occupancy_read.restype = i32
@@ -223,6 +225,17 @@ def plane_from_bbox(bmin, bmax):
 def frame_rows(H, strip_h, world, rank):
     """Rows of an H-row frame owned by `rank` of `world` with strips of strip_h rows (mgpu_frame_rows)."""
     return load_library().mgpu_frame_rows(H, strip_h, world, rank)
+
+
+def frame_plan(W, H, strip_h, world, owner):
+    """(local offsets, frame offsets, counts) in floats of rank `owner`'s strips, as the exchange walks them (mgpu_frame_plan)."""
+    L = load_library()
+    n = L.mgpu_frame_plan(W, H, strip_h, world, owner, None, None, None, 0)
+    if n < 0:
+        raise ValueError("bad frame geometry")
+    lo, fo, cnt = np.zeros(n, "<u8"), np.zeros(n, "<u8"), np.zeros(n, "<u8")
+    L.mgpu_frame_plan(W, H, strip_h, world, owner, _p(lo), _p(fo), _p(cnt), n)
+    return lo, fo, cnt
 
 
 def frame_unique_id():

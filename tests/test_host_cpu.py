@@ -26,6 +26,30 @@ def test_frame_strip_ownership_matches_the_python_partition():
     assert M.frame_rows(10, 8, 2, 2) == -1 and M.frame_rows(10, 0, 2, 0) == -1
 
 
+def test_frame_exchange_plan_reassembles_any_frame():
+    """The exchange plan of the C ABI's multi-GPU frame (mgpu_frame_plan; both the ncclSend and the ncclRecv loops walk it):
+    executed here with numpy copies for world sizes 2..8 on ragged frames, it moves every rank's local strips to exactly the
+    rows the torch.distributed path (mallie_amd/frame.py) assigns to that rank, and tiles the frame without gaps or overlap."""
+    from mallie_amd.frame import strip_rows
+    rng = np.random.default_rng(3)
+    for W, H, sh in ((7, 61, 8), (16, 64, 8), (5, 203, 13), (3, 9, 1), (4, 1080, 8)):
+        frame = rng.random((H, W, 3)).astype("<f4")
+        for world in (2, 3, 4, 8):
+            out = np.full(H * W * 3, np.nan, "<f4")
+            covered = np.zeros(H * W * 3, bool)
+            for r in range(world):
+                rows = strip_rows(H, world, r, sh)
+                local = frame[rows].reshape(-1)                      # what rank r's kernel leaves in its strip buffer
+                lo, fo, cnt = M.frame_plan(W, H, sh, world, r)
+                assert int(cnt.sum()) == local.size == 3 * W * M.frame_rows(H, sh, world, r)
+                for a, b, c in zip(lo, fo, cnt):
+                    a, b, c = int(a), int(b), int(c)
+                    assert not covered[b:b + c].any()
+                    covered[b:b + c] = True
+                    out[b:b + c] = local[a:a + c]                    # ncclSend(local + a, c) -> ncclRecv(frame + b, c)
+            assert covered.all() and out.tobytes() == frame.tobytes(), (W, H, sh, world)
+
+
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "mgpu.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
