@@ -715,11 +715,12 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   if (kern != 0 && passes > 1) {
     size_t budget = (size_t)1 << 30;
     if (const char *e = getenv("MGPU_PLANES_MAX_MB")) budget = (size_t)(atoll(e) < 1 ? 1 : atoll(e)) << 20;
-    const size_t fit = budget / (n_floats * sizeof(float));
+    const size_t plane_floats = (size_t)tiles * 192; // tile-major planes: 64 pixel slots per 8x8 tile (edge tiles padded)
+    const size_t fit = budget / (plane_floats * sizeof(float));
     if ((size_t)group > fit) group = fit < 1 ? 1 : (int)fit;
     // the work cursor addresses (tile, pass) items with 28 bits per XCD part
     while (group > 1 && tiles * (uint64_t)group >= ((uint64_t)1 << 28)) group = (group + 1) / 2;
-    const size_t need = n_floats * (size_t)group;
+    const size_t need = plane_floats * (size_t)group;
     if (need > R.planes_floats) {
       if (R.p_planes) {
         HIP_TRY(hipDeviceSynchronize());
@@ -733,7 +734,7 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
       R.planes_floats = need;
     }
     P.out = R.p_planes;
-    P.pass_stride = n_floats;
+    P.pass_stride = plane_floats;
   }
   P.stats = s->p_stats;
   P.lds_nodes_bytes = (uint32_t)(sizeof(MgpuNode) * s->nn);
@@ -824,7 +825,7 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
       HIP_TRY(launch_render_sm(s->cap, kern == 2, block, dim3((unsigned)blocks), st, shmem, dsc, P));
     }
     if (g0 + g < passes) { // not the last group: fold it into the image now, the planes are reused
-      launch_accumulate(st, R.p_planes, n_floats, g, n_floats, d_image, d_count, g0 > 0);
+      launch_accumulate_tiled(st, R.p_planes, (size_t)tiles * 192, g, n_floats, win_w, d_image, d_count, g0 > 0);
       HIP_TRY(hipGetLastError());
     }
   }
@@ -835,7 +836,7 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   if (kern != 0) {
     if (passes > 1) {
       const int last = passes - ((passes - 1) / group) * group;
-      launch_accumulate(st, R.p_planes, n_floats, last, n_floats, d_image, d_count, passes > group);
+      launch_accumulate_tiled(st, R.p_planes, (size_t)tiles * 192, last, n_floats, win_w, d_image, d_count, passes > group);
       HIP_TRY(hipGetLastError());
     } else if (d_count) {
       launch_accumulate(st, nullptr, 0, 1, n_floats, d_image, d_count, false); // single pass: only count[px] += 1

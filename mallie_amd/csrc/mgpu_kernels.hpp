@@ -105,6 +105,9 @@ hipError_t launch_trace_sm(dim3 grid, hipStream_t s, const DScene &sc, const Mgp
                            const uint32_t *select);
 void launch_accumulate(hipStream_t s, const float *planes, size_t plane_stride, int passes, size_t n_floats, float *image,
                        int32_t *count, bool resume);
+// the same for tile-major planes (k_render_sm with several passes): plane_stride = tiles * 192 floats
+void launch_accumulate_tiled(hipStream_t s, const float *planes, size_t plane_stride, int passes, size_t n_floats, int win_w,
+                             float *image, int32_t *count, bool resume);
 // tile_order[0..n) = tile indices by descending cost (256 log buckets); zeroes cost[]. One workgroup.
 void launch_order_tiles(hipStream_t s, uint32_t *cost, uint32_t n_tiles, uint32_t *order);
 // slot-ordered DTri records + per-slot shading normals (9 doubles with face-varying normals, else the geometric normal)

@@ -640,7 +640,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
           }
           if (path_done) {
             // image[...] = radiance (double -> float, render.cc:673-675); passes are summed later, in order
-            float *dst = P.out + (size_t)pass * P.pass_stride + 3 * ((size_t)ly * (size_t)win_w + lx);
+            // Several passes: planes are TILE-major (a tile's 64 pixels = 768 contiguous bytes = six whole 128-byte lines that
+            // only this (tile, pass) item writes; in image order a tile row is 96 bytes straddling lines shared with the
+            // neighbouring tiles, i.e. with other waves on other XCDs, and HBM saw 2.1x the bytes).  One pass: the image itself.
+            float *dst = P.pass_stride ? P.out + (size_t)pass * P.pass_stride + ((size_t)(ly >> 3) * tiles_x + (lx >> 3)) * 192u +
+                                             (size_t)(((ly & 7u) << 3) + (lx & 7u)) * 3u
+                                       : P.out + 3 * ((size_t)ly * (size_t)win_w + lx);
             dst[0] = (float)rad0;
             dst[1] = (float)rad1;
             dst[2] = (float)rad2;
@@ -902,6 +907,54 @@ __global__ __launch_bounds__(256) void k_accumulate(const float *__restrict__ pl
     image[i] = acc;
   }
   if (count && i < n_floats / 3) count[i] += passes;
+}
+
+// Planes in tile-major order (what k_render_sm writes for several passes, see there): image float f of the window
+// (row-major, 3 * win_w per row) lives at ((y / 8) * tiles_x + x / 8) * 192 + ((y % 8) * 8 + x % 8) * 3 + channel of
+// every plane.  VEC = 4: windows whose width is a multiple of 8 -- four consecutive image floats then lie in one 96-byte
+// tile row and the loads stay 16 bytes wide; VEC = 1 otherwise.  Same additions per float, same order.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_accumulate_tiled(const float *__restrict__ planes, size_t plane_stride, int passes,
+                                                           size_t n_floats, uint32_t win_w, uint32_t tiles_x,
+                                                           float *__restrict__ image, int32_t *__restrict__ count, bool resume) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t f = i * VEC;
+  if (f < n_floats) {
+    const size_t row_floats = (size_t)3 * win_w;
+    const uint32_t y = (uint32_t)(f / row_floats), c = (uint32_t)(f - (size_t)y * row_floats);
+    const uint32_t x = c / 3u, ch = c - 3u * x;
+    const size_t off = ((size_t)(y >> 3) * tiles_x + (x >> 3)) * 192u + (size_t)(((y & 7u) << 3) + (x & 7u)) * 3u + ch;
+    if (VEC == 4) {
+      float4 acc = resume ? *reinterpret_cast<const float4 *>(image + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int p = 0; p < passes; ++p) {
+        const float4 v = *reinterpret_cast<const float4 *>(planes + (size_t)p * plane_stride + off);
+        acc.x += v.x;
+        acc.y += v.y;
+        acc.z += v.z;
+        acc.w += v.w;
+      }
+      *reinterpret_cast<float4 *>(image + f) = acc;
+    } else {
+      float acc = resume ? image[f] : 0.f;
+      for (int p = 0; p < passes; ++p) acc += planes[(size_t)p * plane_stride + off];
+      image[f] = acc;
+    }
+    if (count) // n_floats / 3 pixel counters dealt to the n_floats / VEC threads that hold image floats
+      for (size_t k = i; k < n_floats / 3; k += (n_floats + VEC - 1) / VEC) count[k] += passes;
+  }
+}
+
+void launch_accumulate_tiled(hipStream_t s, const float *planes, size_t plane_stride, int passes, size_t n_floats, int win_w,
+                             float *image, int32_t *count, bool resume) {
+  const uint32_t tiles_x = (uint32_t)(win_w + 7) >> 3;
+  if (win_w % 8 == 0 && ((uintptr_t)image & 15) == 0 && ((uintptr_t)planes & 15) == 0 && plane_stride % 4 == 0) {
+    const size_t n4 = n_floats / 4; // 3 * win_w * rows with win_w % 8 == 0 is a multiple of 4
+    hipLaunchKernelGGL(k_accumulate_tiled<4>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, planes, plane_stride, passes,
+                       n_floats, (uint32_t)win_w, tiles_x, image, count, resume);
+  } else {
+    hipLaunchKernelGGL(k_accumulate_tiled<1>, dim3((unsigned)((n_floats + 255) / 256)), dim3(256), 0, s, planes, plane_stride,
+                       passes, n_floats, (uint32_t)win_w, tiles_x, image, count, resume);
+  }
 }
 
 // The same sums four floats per thread (16-byte loads; the additions per float and their order are unchanged): for plane
