@@ -7,9 +7,11 @@
 // Scene::Trace / BVHAccel::Traverse / mallie::Render runs on the GPU through the C ABI of include/mgpu.h.
 //
 // Deviations a maintainer must know about (also in INTEGRATION.md):
-//  * mallie::Render cannot reproduce the reference's per-OpenMP-thread RNG stream (render.cc:116-168): paths are seeded
-//    per (pixel, pass) instead (MGPU_RNG_HASH, seed settable with mallie::SetRenderSeed), or from a caller-supplied
-//    table of start states (mallie::SetRenderRngTable).  Given the same start states the image is the reference's.
+//  * mallie::Render seeds paths per (pixel, pass) by default (MGPU_RNG_HASH, seed settable with mallie::SetRenderSeed: the
+//    frame then does not depend on GPU count or scheduling), or from a caller-supplied table of start states
+//    (mallie::SetRenderRngTable).  mallie::SetRenderReferenceStream(true) (or MALLIE_RNG_STREAM=1) selects the
+//    reference's own stream instead -- its single-thread xorshift128 state continued from pixel to pixel and call to call
+//    (render.cc:116-168 with OMP_NUM_THREADS=1): the image then IS the reference's image.
 //  * MALLIE_GPUS=n in the environment makes mallie::Render / RenderPasses use n GPUs of the node (scene replicated,
 //    interleaved 8-row strips, one RCCL exchange per frame; mgpu_frame_* in include/mgpu.h).  The image does not depend on n.
 //  * kMaxPathLength (render.cc:52) is a run-time setting here: mallie::SetMaxPathLength (default 16 = reference).
@@ -289,6 +291,9 @@ void RenderPanoramic(Scene &scene, const RenderConfig &config, std::vector<float
 void SetMaxPathLength(int maxPathLength);          // default 16 (render.cc:52)
 void SetRenderSeed(unsigned long long seed);       // default 1; also restarts the pass counter
 void SetRenderRngTable(const unsigned int *states); // W*H*4 words for the NEXT Render() call only; NULL clears
+// true: Render / RenderPasses draw from the reference's own serial stream (render.cc:116-168, one OpenMP thread), starting at
+// its seed and continuing from call to call; resets that stream to the seed.  false: back to per-(pixel, pass) seeding.
+void SetRenderReferenceStream(bool on);
 // `passes` passes in one launch, accumulated on the device in pass order (== Render + AccumImage, main_sdl.cc:138-143);
 // count[px] += passes.  Returns false (after printing a Mallie:err line) on failure.
 bool RenderPasses(Scene &scene, const RenderConfig &config, std::vector<float> &image, std::vector<int> &count,

@@ -33,7 +33,8 @@ enum {
 /* RNG start-state source for mgpu_render* (SURVEY.md H1). The generator itself is the reference's xorshift128
  * (render.cc:137-168); only where a path's 128-bit start state comes from differs. */
 enum {
-  MGPU_RNG_STREAM = 0, /* the reference's serial thread stream: NOT reproducible in parallel -> MGPU_ERR_UNSUPPORTED */
+  MGPU_RNG_STREAM = 0, /* the reference's serial thread stream (OMP_NUM_THREADS=1): mgpu_render_stream; the other entry
+                        * points return MGPU_ERR_UNSUPPORTED for it                                                   */
   MGPU_RNG_TABLE = 1,  /* rng_states[((pass*H + y)*W + x)*4 .. +4]: start state of every (pass, pixel)              */
   MGPU_RNG_HASH = 2    /* start state = hash(seed, pass_base + pass, y*W + x)  (mgpu_hash_state)                    */
 };
@@ -135,6 +136,18 @@ int mgpu_render(MgpuScene *scene, const double origin[3], const double corner[3]
                 const double dv[3], int W, int H, int x0, int y0, int x1, int y1, int maxPathLength, int passes,
                 const float plane[4], int rng_mode, const uint32_t *rng_states, uint64_t seed, uint32_t pass_base,
                 float *image_out, int32_t *count_out, MgpuStats *stats);
+
+/* Render() in the reference's OWN random stream (render.cc:116-168 with one OpenMP thread: every pixel continues the
+ * xorshift128 state the previous pixel left, pass after pass): `passes` consecutive Render() calls on the whole frame,
+ * summed in pass order as mgpu_render does.  stream_state = the generator's 4 words, IN (123456789, 362436069, 521288629,
+ * 88675123 for a fresh process, render.cc:123-127) and OUT (where the next call continues).  The chain is resolved on the
+ * device (mgpu_stream.hip: a pixel consumes 2 or 2 + 3 (maxPathLength - 1) draws depending on whether its primary ray hits,
+ * so start states follow from the primary hit flags of all earlier pixels; one workgroup settles them by speculation), then
+ * the frame is rendered from the resulting start-state table.  With the default seed the image is the reference's image.
+ * states_out (nullable): the passes * W * H * 4 words of that table (MGPU_RNG_TABLE layout). */
+int mgpu_render_stream(MgpuScene *scene, const double origin[3], const double corner[3], const double du[3],
+                       const double dv[3], int W, int H, int maxPathLength, int passes, const float plane[4],
+                       uint32_t stream_state[4], float *image_out, int32_t *count_out, uint32_t *states_out, MgpuStats *stats);
 
 /* Render() with its `step` argument (render.cc:657-696): step == 1 is mgpu_render with passes = 1 on the whole frame.
  * step > 1 traces one path per step x step block -- the path of the block's top-left pixel (its jitter, its RNG start

@@ -187,6 +187,8 @@ int gMaxPathLength = 16;
 unsigned long long gSeed = 1;
 unsigned int gPassCounter = 0;
 const unsigned int *gRngTable = NULL;
+bool gReferenceStream = false;                                             // SetRenderReferenceStream
+unsigned int gStreamState[4] = {123456789u, 362436069u, 521288629u, 88675123u}; // init_randomreal(), render.cc:123-127
 
 // MALLIE_GPUS=n: the frame object that spreads Render() over n GPUs, kept while scene and frame size stay the same
 struct MultiGpu {
@@ -262,6 +264,10 @@ void SetRenderSeed(unsigned long long seed) {
   gPassCounter = 0;
 }
 void SetRenderRngTable(const unsigned int *states) { gRngTable = states; }
+void SetRenderReferenceStream(bool on) {
+  gReferenceStream = on;
+  gStreamState[0] = 123456789u; gStreamState[1] = 362436069u; gStreamState[2] = 521288629u; gStreamState[3] = 88675123u;
+}
 
 static bool render_impl(Scene &scene, const RenderConfig &config, std::vector<float> &image, std::vector<int> &count,
                         const double eye[3], const double lookat[3], const double up[3], const double quat[4], int passes,
@@ -301,6 +307,20 @@ static bool render_impl(Scene &scene, const RenderConfig &config, std::vector<fl
   }
   MgpuStats st;
   memset(&st, 0, sizeof(st));
+  const char *env_stream = getenv("MALLIE_RNG_STREAM");
+  if ((gReferenceStream || (env_stream && atoi(env_stream) != 0)) && step == 1 && !table) {
+    // the reference's own random stream (one OpenMP thread), continued from call to call like its static state
+    const int rc = mgpu_render_stream(dev, origin, corner, du, dv, width, height, gMaxPathLength, passes, gPlane ? pl : NULL,
+                                      gStreamState, &image[0], &count[0], NULL, &st);
+    if (rc != MGPU_OK) {
+      printf("Mallie:err\tmsg:Render failed: %s\n", mgpu_last_error());
+      return false;
+    }
+    const double sec = st.total_ms / 1000.0;
+    printf("\r[Mallie] Render time: %f sec(s) | %f fps", sec, sec > 0 ? 1.0 / sec : 0.0);
+    fflush(stdout);
+    return true;
+  }
   const int gpus = (step == 1 && !table) ? wanted_gpus() : 1;
   const char *force_frame = getenv("MGPU_FRAME_FORCE_EXCHANGE"); // one GPU through the multi-GPU machinery (tests)
   if (gpus > 1 || (step == 1 && !table && force_frame && atoi(force_frame) != 0)) { // the same frame from n GPUs: strips, one RCCL exchange, assembled on device 0 (include/mgpu.h, mgpu_frame_*)

@@ -613,8 +613,8 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   if ((uint64_t)W * (uint64_t)H > 0xFFFFFFFFull) return fail(MGPU_ERR_INVALID, "frame too large");
   if (rng_mode == MGPU_RNG_STREAM)
     return fail(MGPU_ERR_UNSUPPORTED,
-                "the reference's serial RNG stream cannot be reproduced in parallel; capture per-pixel start states "
-                "and use MGPU_RNG_TABLE");
+                "the reference's serial RNG stream is a chain over the whole frame: use mgpu_render_stream (or a table of "
+                "start states with MGPU_RNG_TABLE)");
   if (rng_mode != MGPU_RNG_TABLE && rng_mode != MGPU_RNG_HASH) return fail(MGPU_ERR_INVALID, "bad rng_mode %d", rng_mode);
   if (rng_mode == MGPU_RNG_TABLE && !d_rng_states) return fail(MGPU_ERR_INVALID, "MGPU_RNG_TABLE needs rng_states");
   if (n_rows > 0) {
@@ -932,6 +932,122 @@ int mgpu_render(MgpuScene *s, const double origin[3], const double corner[3], co
   }
   return MGPU_OK;
 #undef TRY_R
+}
+
+int mgpu_render_stream(MgpuScene *s, const double origin[3], const double corner[3], const double du[3], const double dv[3],
+                       int W, int H, int maxPathLength, int passes, const float plane[4], uint32_t stream_state[4],
+                       float *image_out, int32_t *count_out, uint32_t *states_out, MgpuStats *stats) {
+  if (!s || !origin || !corner || !du || !dv || !image_out || !stream_state) return fail(MGPU_ERR_INVALID, "NULL argument");
+  if (W <= 0 || H <= 0 || passes < 1 || maxPathLength < 1) return fail(MGPU_ERR_INVALID, "bad frame size / passes / maxPathLength");
+  if (maxPathLength > kStreamMaxPathLength)
+    return fail(MGPU_ERR_UNSUPPORTED, "MGPU_RNG_STREAM supports maxPathLength <= %d", kStreamMaxPathLength);
+  if ((uint64_t)W * (uint64_t)H * (uint64_t)passes >= ((uint64_t)1 << 40)) return fail(MGPU_ERR_INVALID, "too many paths");
+  const double t0 = now_ms();
+  uint32_t *d_table = nullptr, *d_state = nullptr;
+  uint4 *d_jump = nullptr;
+  auto cleanup = [&]() {
+    if (d_table) (void)hipFree(d_table);
+    if (d_state) (void)hipFree(d_state);
+    if (d_jump) (void)hipFree(d_jump);
+  };
+#define TRY_S(expr)                                                             \
+  do {                                                                          \
+    hipError_t e_ = (expr);                                                     \
+    if (e_ != hipSuccess) {                                                     \
+      cleanup();                                                                \
+      return fail(MGPU_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    }                                                                           \
+  } while (0)
+  const size_t table_bytes = (size_t)passes * W * H * 16;
+  {
+    std::lock_guard<std::mutex> host_lock(s->host_mutex);
+    int rc = set_device(s);
+    if (rc) return rc;
+    static std::vector<uint32_t> jump; // T^(2^j) over GF(2), computed once per process
+    static std::mutex jump_mutex;
+    {
+      std::lock_guard<std::mutex> jl(jump_mutex);
+      if (jump.empty()) {
+        jump.resize((size_t)kStreamJumpBits * 128 * 4);
+        stream_jump_matrices(jump.data());
+      }
+    }
+    TRY_S(hipMalloc((void **)&d_table, table_bytes));
+    TRY_S(hipMalloc((void **)&d_state, 16));
+    TRY_S(hipMalloc((void **)&d_jump, jump.size() * 4));
+    TRY_S(hipMemcpy(d_state, stream_state, 16, hipMemcpyHostToDevice));
+    TRY_S(hipMemcpy(d_jump, jump.data(), jump.size() * 4, hipMemcpyHostToDevice));
+    rc = ensure_overflow(s, 256);
+    if (rc) {
+      cleanup();
+      return rc;
+    }
+    StreamParams P;
+    memcpy(P.frame + 0, origin, 24);
+    memcpy(P.frame + 3, corner, 24);
+    memcpy(P.frame + 6, du, 24);
+    memcpy(P.frame + 9, dv, 24);
+    if (plane) memcpy(P.plane, plane, sizeof(P.plane));
+    else memset(P.plane, 0, sizeof(P.plane));
+    P.has_plane = plane ? 1 : 0;
+    {
+      double n[3] = {(double)P.plane[0], (double)P.plane[1], (double)P.plane[2]};
+      const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+      if (std::fabs(len) > 1.0e-6) {
+        const double inv = 1.0 / len;
+        n[0] *= inv; n[1] *= inv; n[2] *= inv;
+      }
+      memcpy(P.plane_n, n, sizeof(n));
+    }
+    P.W = W; P.H = H; P.maxPathLength = maxPathLength; P.passes = passes;
+    P.jump = d_jump;
+    P.state = d_state;
+    P.table = d_table;
+    TRY_S(launch_stream_states(s->cap, 0, s->d, P));
+    TRY_S(hipMemcpy(stream_state, d_state, 16, hipMemcpyDeviceToHost)); // waits for the kernel
+    if (states_out) TRY_S(hipMemcpy(states_out, d_table, table_bytes, hipMemcpyDeviceToHost));
+  }
+  // the frame itself: the ordinary renderer from that table (host_mutex is taken inside)
+  int rc;
+  {
+    // mgpu_render uploads a host table; keep the device one instead by going through the device entry point
+    std::lock_guard<std::mutex> host_lock(s->host_mutex);
+    const size_t img_bytes = sizeof(float) * 3 * (size_t)W * H;
+    if (img_bytes > s->host_img_bytes) {
+      if (s->p_host_img) {
+        (void)hipFree(s->p_host_img);
+        s->device_bytes -= s->host_img_bytes;
+        s->p_host_img = nullptr;
+        s->host_img_bytes = 0;
+      }
+      rc = dev_alloc(s, (void **)&s->p_host_img, img_bytes);
+      if (rc) {
+        cleanup();
+        return rc;
+      }
+      s->host_img_bytes = img_bytes;
+    }
+    double frame[12];
+    memcpy(frame + 0, origin, 24);
+    memcpy(frame + 3, corner, 24);
+    memcpy(frame + 6, du, 24);
+    memcpy(frame + 9, dv, 24);
+    MgpuStats local;
+    rc = mgpu_render_strips_device(s, frame, W, H, 0, W, 0, H, H, H, maxPathLength, passes, plane, MGPU_RNG_TABLE, d_table, 0, 0,
+                                   (float *)s->p_host_img, nullptr, nullptr, &local);
+    if (rc) {
+      cleanup();
+      return rc;
+    }
+    TRY_S(hipMemcpy(image_out, s->p_host_img, img_bytes, hipMemcpyDeviceToHost));
+    if (stats) *stats = local;
+  }
+  cleanup();
+  if (count_out)
+    for (size_t i = 0; i < (size_t)W * H; i++) count_out[i] += passes;
+  if (stats) stats->total_ms = now_ms() - t0;
+  return MGPU_OK;
+#undef TRY_S
 }
 
 int mgpu_render_step(MgpuScene *s, const double origin[3], const double corner[3], const double du[3], const double dv[3],

@@ -99,6 +99,22 @@ struct AovParams {
   unsigned long long *stats;
 };
 void launch_render_aov(int cap, dim3 grid, hipStream_t s, const DScene &sc, const AovParams &p);
+// k_stream_states (mgpu_stream.hip): MGPU_RNG_STREAM -- the start state of every (pass, pixel) in the reference's own
+// serial stream, written to an MGPU_RNG_TABLE table; `state` (device, 4 words) is the stream state, in and out
+constexpr int kStreamJumpBits = 18;      // window offsets < 2^18: maxPathLength <= kStreamMaxPathLength
+constexpr int kStreamMaxPathLength = 341; // 256 * (2 + 3 * 340) < 2^18
+struct StreamParams {
+  double frame[12];
+  float plane[4];
+  double plane_n[3];
+  int has_plane;
+  int W, H, maxPathLength, passes;
+  const uint4 *jump; // device: kStreamJumpBits x 128 columns (stream_jump_matrices)
+  uint32_t *state;   // device: 4 words, in / out
+  uint32_t *table;   // device: passes * W * H * 4 words
+};
+hipError_t launch_stream_states(int cap, hipStream_t s, const DScene &sc, const StreamParams &p);
+void stream_jump_matrices(uint32_t *out /* kStreamJumpBits * 128 * 4 words */);
 // k_trace_sm (mgpu_trace_sm.hip): persistent, wave-scheduled batched trace; `counter` = one zeroed device word
 hipError_t launch_trace_sm(dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, uint32_t n,
                            MgpuIntersection *out, uint8_t *hit, uint32_t *counter, unsigned long long *stats,

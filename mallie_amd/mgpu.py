@@ -87,6 +87,8 @@ def load_library():
     L.mgpu_debug_words.restype = i32
     L.mgpu_render_step.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, u64, u32, vp, vp, vp]
     L.mgpu_render_step.restype = i32
+    L.mgpu_render_stream.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.mgpu_render_stream.restype = i32
     L.mgpu_render_aov.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, u64, u32, vp, vp, vp]
     L.mgpu_render_aov.restype = i32
     L.mgpu_frame_create.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.POINTER(vp)]
@@ -399,6 +401,21 @@ class Scene:
                                           x0, y0, x1, y1, maxPathLength, passes, _p(plane), rng_mode, _p(rng_states),
                                           seed, pass_base, _p(image), _p(count), C.byref(st)), "mgpu_render")
         return image, count, st.as_dict()
+
+    def render_stream(self, frame, W, H, maxPathLength=16, passes=1, plane=None, stream_state=None, count=None, want_states=False):
+        """mgpu_render_stream: Render() in the reference's own serial random stream -> (image, count, stats, stream_state after,
+        start states or None).  stream_state: 4 words (default: the reference's fresh seed)."""
+        frame = _c(frame, "<f8")
+        state = np.array((123456789, 362436069, 521288629, 88675123) if stream_state is None else stream_state, "<u4").copy()
+        image = np.zeros((H, W, 3), "<f4")
+        if count is None:
+            count = np.zeros((H, W), "<i4")
+        states = np.zeros((passes, H, W, 4), "<u4") if want_states else None
+        st = Stats()
+        _check(load_library().mgpu_render_stream(self.h, _p(frame[0:3]), _p(frame[3:6]), _p(frame[6:9]), _p(frame[9:12]), W, H,
+                                                 maxPathLength, passes, _p(_c(plane, "<f4")), _p(state), _p(image), _p(count),
+                                                 _p(states), C.byref(st)), "mgpu_render_stream")
+        return image, count, st.as_dict(), state, states
 
     def render_aov(self, frame, W, H, kind, rng_mode=RNG_HASH, rng_states=None, seed=1, pass_base=0):
         """mgpu_render_aov: ShowNormal (kind 0) / ShowUV (kind 1) of the whole frame -> (image, stats)."""

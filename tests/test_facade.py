@@ -276,6 +276,26 @@ def test_facade_render_through_the_multi_gpu_frame(driver, tmp_path):
 
 
 @pytest.mark.gpu
+def test_facade_render_in_the_reference_stream(driver, tmp_path):
+    """MALLIE_RNG_STREAM=1: mallie::Render draws from the reference's own serial random stream, continued from call to call
+    (three Render() calls + AccumImage in the driver) -- the oracle's run of three passes in that stream, bit for bit; the
+    driver's own check (RenderPasses == Render + AccumImage) is skipped by the stream moving on, so only the sum is compared."""
+    obj = str(tmp_path / "cornell_like.obj")
+    _write_cornell_obj(obj)
+    W, H, passes, mpl = 96, 64, 3, 16
+    out = str(tmp_path / "img.f32")
+    r = subprocess.run([driver, "render", "obj", obj, str(W), str(H), "1", str(passes), str(mpl), "1", out],
+                       capture_output=True, text=True, cwd=str(tmp_path), env=dict(os.environ, MALLIE_RNG_STREAM="1"))
+    assert r.returncode in (0, 7), r.stdout + r.stderr   # 7: the driver's second rendering continued the stream, as it must
+    img = np.fromfile(out, "<f4")[: 3 * W * H].reshape(H, W, 3)
+    g = O.load_golden("cornell_obj")
+    osc = O.OracleScene(g["verts"].astype(np.float64), g["faces"], np.full(len(g["faces"]), 0xFFFFFFFF, "u4"), g["normals"], None)
+    frame = O.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    oimg, _, _, _ = osc.render(frame, W, H, mpl, passes, osc.plane(), O.RNG_STREAM, stream_state=np.array(O.REFERENCE_SEED, "<u4"))
+    assert img.tobytes() == oimg.tobytes()
+
+
+@pytest.mark.gpu
 def test_facade_renders_a_vox_scene_with_its_palette(driver, tmp_path):
     """Scene::Init(.vox) -> mallie::Render on the GPU: the palette materials colour the paths (R, G, B differ) and the
     image equals the oracle's for the same arrays, materials and seeding."""

@@ -360,6 +360,47 @@ def test_show_normal_and_show_uv_replay_reference_stream(name):
     assert (img != 0).any()
 
 
+@pytest.mark.parametrize("name", RENDERS)
+def test_render_in_the_reference_stream_without_a_table(name):
+    """MGPU_RNG_STREAM (mgpu_render_stream): the device resolves the reference's serial random stream itself -- start states
+    from the primary hit flags of all earlier pixels, settled by speculation (mgpu_stream.hip) -- and renders the reference's
+    image from nothing but the reference's seed: images, start states of every (pass, pixel) and the stream state left behind
+    equal the oracle's run in that stream, which equals the reference's golden image."""
+    r = O.load_golden(name)
+    mesh = "cornell_eson" if "eson" in name else ("teapot_obj" if "teapot" in name else "cornell_obj")
+    osc, sc = O.scene_from_golden(mesh), gpu_scene(mesh)
+    W, H, passes = int(r["W"]), int(r["H"]), int(r["passes"])
+    frame = M.camera_frame(r["eye"], r["lookat"], r["up"], r["quat"], 45.0, W, H)
+    plane = osc.plane() if int(r["plane"]) else None
+    ostate = np.array(O.REFERENCE_SEED, "<u4")
+    oimg, _, _, ostates = osc.render(frame, W, H, 16, passes, plane, O.RNG_STREAM, stream_state=ostate, want_states=True)
+    img, count, st, state, states = sc.render_stream(frame, W, H, 16, passes, plane, want_states=True)
+    assert np.array_equal(states, ostates)
+    assert np.array_equal(state, ostate)          # where the next Render() call continues
+    assert img.tobytes() == oimg.tobytes()
+    assert img.tobytes() == (r["images"].sum(0, dtype=np.float32) if passes > 1 else r["images"][0]).tobytes()
+    assert np.array_equal(count, r["count"])
+    # a second call continues the stream: two calls of one pass == one call of two passes
+    if passes == 2:
+        a, _, _, s1, _ = sc.render_stream(frame, W, H, 16, 1, plane)
+        b, _, _, s2, _ = sc.render_stream(frame, W, H, 16, 1, plane, stream_state=s1)
+        assert a.tobytes() == r["images"][0].tobytes() and b.tobytes() == r["images"][1].tobytes() and np.array_equal(s2, state)
+
+
+def test_reference_default_config_from_its_seed_alone():
+    """The reference's default configuration (config.json: cornellbox_suzanne, 512x512, one pass, plane on, 16 segments) in
+    its own stream on the GPU: the digest of the reference's frame (tests/golden/render_cornell_obj_512_plane_digest.npz)."""
+    import hashlib
+    d = O.load_golden("render_cornell_obj_512_plane_digest")
+    sc = gpu_scene("cornell_obj")
+    W, H = int(d["W"]), int(d["H"])
+    frame = M.camera_frame(d["eye"], d["lookat"], d["up"], d["quat"], 45.0, W, H)
+    img, count, st, _, _ = sc.render_stream(frame, W, H, 16, 1, sc.plane())
+    assert hashlib.sha256(img.tobytes()).digest() == d["sha256"].tobytes()
+    assert np.array_equal(img[d["row_ids"]], d["rows"]) and int(count.min()) == 1 == int(count.max())
+    assert st["trace_calls"] == 3706279 and st["real_rays"] == 1035072  # SURVEY.md: the reference's own call counts
+
+
 def test_path_probe_every_iteration_vs_oracle():
     """Iteration-level parity of PathTrace: origin, direction, hit distance, shading normal, material and running
     throughput / radiance of every loop iteration, device vs oracle, for a lattice of pixels and three scenes.  IEEE
