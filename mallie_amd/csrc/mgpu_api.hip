@@ -1251,6 +1251,8 @@ int mgpu_render_panoramic_device(MgpuScene *s, const double origin[3], int W, in
   if (blocks < 1) blocks = 1;
   rc = ensure_overflow(s, blocks * block);
   if (rc) return rc;
+  rc = ensure_woverflow(s, blocks * block);
+  if (rc) return rc;
   EnvParams P;
   P.lds_nodes_bytes = (uint32_t)(sizeof(MgpuNode) * s->nn);
   P.lds_tris_bytes = (uint32_t)(sizeof(DTri) * s->nf);

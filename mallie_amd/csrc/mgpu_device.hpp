@@ -396,6 +396,112 @@ __device__ __forceinline__ int wide_node_step(const WNode *__restrict__ wn, cons
   return res;
 }
 
+// ---- shared leaves: the TRI step of the wave-scheduled kernels with 2^sh lanes per open leaf --------------------------
+// With at most 64 >> sh lanes holding an open leaf (mT = their mask, cT = their number), 2^sh lanes work on each: lane L
+// serves the (L >> sh)-th open leaf and tests its triangles first + (L & (m - 1)), + m, ... with the OWNER's ray (fetched
+// across lanes), idle and NODE / SHADE lanes included -- their own state is untouched.  The m partial results are merged by
+// the rule the reference's in-order loop obeys for ordinary numbers -- smallest t, the LATER triangle on equal t
+// (TriangleIsect rejects only `t > tBest`, bvh_accel.cc:631) -- and the owner applies the same `t > bt` test to the merged
+// candidate.  A NaN t (which that loop would accept, and after which it accepts everything) cannot be merged this way: a
+// step that produces one changes nothing and returns false, and the caller redoes it in order with the owners alone.
+// Called by the whole wave.  tbl: 64 bytes of LDS of this wave.  `owner`: this lane holds an open leaf [tri_cur, tri_end).
+// On true the owners' (bt, bu, bv, bslot) are updated and tri_cur has advanced by up to MAX_TRIPS << sh triangles;
+// my_trips = loop trips this lane made as a worker.
+template <bool LDS_TRIS, int MAX_TRIPS>
+__device__ __forceinline__ bool shared_leaves_step(unsigned long long mT, int cT, int sh, int lane, unsigned char *tbl, bool owner,
+                                                   const unsigned char *lds_tris, const DTri *tris, V3 org, V3 dir,
+                                                   uint32_t &tri_cur, uint32_t tri_end, double &bt, double &bu, double &bv,
+                                                   uint32_t &bslot, uint32_t &n_tris, uint32_t &my_trips) {
+  const int m = 1 << sh;
+  const uint32_t rank = (uint32_t)__popcll(mT & ((1ull << lane) - 1ull));
+  if (owner) tbl[rank] = (unsigned char)lane;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int grp = lane >> sh, sub = lane & (m - 1);
+  const bool serving = grp < cT;
+  const int own = serving ? (int)tbl[grp] : lane;
+  const V3 o = v3(__shfl(org.x, own), __shfl(org.y, own), __shfl(org.z, own));
+  const V3 d = v3(__shfl(dir.x, own), __shfl(dir.y, own), __shfl(dir.z, own));
+  const uint32_t first = (uint32_t)__shfl((int)tri_cur, own), last = (uint32_t)__shfl((int)tri_end, own);
+  double lt = __builtin_inf(), lu = 0.0, lv = 0.0;
+  uint32_t ls = kNoHit;
+  if (serving) {
+    uint32_t i = first + (uint32_t)sub;
+#pragma unroll 1
+    for (int rep = 0; rep < MAX_TRIPS && i < last; ++rep, i += (uint32_t)m) {
+      double2 a0, a1, a2, a3;
+      double e2z;
+      if (LDS_TRIS) {
+        const unsigned char *tp = lds_tris + (size_t)i * 80;
+        a0 = *reinterpret_cast<const double2 *>(tp);
+        a1 = *reinterpret_cast<const double2 *>(tp + 16);
+        a2 = *reinterpret_cast<const double2 *>(tp + 32);
+        a3 = *reinterpret_cast<const double2 *>(tp + 48);
+        e2z = *reinterpret_cast<const double *>(tp + 64);
+      } else {
+        const DTri *tp = tris + i;
+        a0 = reinterpret_cast<const double2 *>(tp)[0];
+        a1 = reinterpret_cast<const double2 *>(tp)[1];
+        a2 = reinterpret_cast<const double2 *>(tp)[2];
+        a3 = reinterpret_cast<const double2 *>(tp)[3];
+        e2z = tp->e2[2];
+      }
+      ++n_tris;
+      // TriangleIsect, bvh_accel.cc:595-638
+      const V3 p0 = v3(a0.x, a0.y, a1.x), e1 = v3(a1.y, a2.x, a2.y), e2 = v3(a3.x, a3.y, e2z);
+      const V3 p = cross(d, e2);
+      const double det = dot(e1, p);
+      if (!(fabs(det) < kDblEps1024)) {
+        const double invDet = inv_det_w(det);
+        const V3 sv = o - p0;
+        const V3 q = cross(sv, e1);
+        const double u = dot(sv, p) * invDet;
+        const double v = dot(q, d) * invDet;
+        const double t = dot(e2, q) * invDet;
+        const bool rej = (u < 0.0 || u > 1.0) || (v < 0.0 || u + v > 1.0) || (t < 0.0 || t > lt);
+        if (!rej) {
+          lt = t;
+          lu = u;
+          lv = v;
+          ls = i;
+        }
+      }
+    }
+  }
+  my_trips = serving ? min(((last - first) + (uint32_t)(m - 1 - sub)) >> sh, (uint32_t)MAX_TRIPS) : 0u;
+  if (__ballot(lt != lt) != 0ull) { // a NaN candidate somewhere: nothing is merged, nothing has changed
+    n_tris -= my_trips;              // (the caller's in-order pass counts these tests)
+    return false;
+  }
+  for (int x = 1; x < m; x <<= 1) {
+    const double pt = __shfl_xor(lt, x), pu = __shfl_xor(lu, x), pv = __shfl_xor(lv, x);
+    const uint32_t ps = (uint32_t)__shfl_xor((int)ls, x);
+    // the partner wins with a smaller t, or with an equal t and the later triangle (kNoHit never wins: its t is +inf, and an
+    // equal +inf from a real triangle loses nothing -- the owner's `t > bt` test rejects it either way)
+    const bool take = ps != kNoHit && (ls == kNoHit || pt < lt || (pt == lt && ps > ls));
+    if (take) {
+      lt = pt;
+      lu = pu;
+      lv = pv;
+      ls = ps;
+    }
+  }
+  const int from = (int)(rank << sh); // the lanes of this owner's group all hold the merged candidate
+  const double ct = __shfl(lt, from), cu = __shfl(lu, from), cv = __shfl(lv, from);
+  const uint32_t cs = (uint32_t)__shfl((int)ls, from);
+  if (owner) {
+    if (cs != kNoHit && !(ct > bt)) {
+      bt = ct;
+      bu = cu;
+      bv = cv;
+      bslot = cs;
+    }
+    tri_cur += min(tri_end - tri_cur, (uint32_t)(MAX_TRIPS << sh));
+  }
+  return true;
+}
+
 // ---- BVHAccel::Traverse (bvh_accel.cc:773-844) without the final BuildIntersection ----------------------------------
 // while-while form: every lane pops and box-tests nodes until it holds a leaf (or runs dry), then the wave tests leaf
 // triangles together.  Pop order, the near/far push order and the in-leaf triangle order are the reference's, so

@@ -25,8 +25,14 @@
 #ifndef MGPU_ENV_START_FORCE
 #define MGPU_ENV_START_FORCE 16
 #endif
+// NODE runs when cN * MGPU_ENV_NODE_WEIGHT >= cT * MGPU_ENV_TRI_WEIGHT.  Before leaves were shared between lanes NODE was
+// preferred 4:1 (1: 25.9, 2: 25.8, 4: 24.2 ms on the 2048x1024 stereo panorama); with shared leaves a TRI step is cheap at a
+// low lane count, and the balance is measured again below.
 #ifndef MGPU_ENV_NODE_WEIGHT
-#define MGPU_ENV_NODE_WEIGHT 4 // NODE runs when cN * weight >= cT (1: 25.9, 2: 25.8, 4: 24.2 ms on the 2048x1024 stereo panorama)
+#define MGPU_ENV_NODE_WEIGHT 1
+#endif
+#ifndef MGPU_ENV_TRI_WEIGHT
+#define MGPU_ENV_TRI_WEIGHT 4
 #endif
 
 namespace mgpu {
@@ -45,6 +51,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ EnvParams s_P; // launch parameters live in LDS, not in scalar registers (see k_render_sm)
   __shared__ unsigned long long s_cnt[5];
+  __shared__ unsigned char s_owner[BLOCK]; // TRI step with shared leaves: lane of the k-th open leaf, per wave
   if (threadIdx.x == 0) s_P = P_arg;
   if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0ull;
   __syncthreads();
@@ -55,6 +62,13 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
   Stack<CAP, OVF> stk;
   stk.lds = s_stack + ((size_t)wave * CAP) * 64 + lane;
   stk.overflow = (OVF && sc.stack_overflow) ? sc.stack_overflow + slot * sc.overflow_cap : nullptr;
+  // BVH in HBM: the wide traversal (mgpu_device.hpp, wide_node_step) with its far-child stack
+  using WS = WStack<kWideStackLds>;
+  WS wstk;
+  if (!LDS_SCENE) {
+    wstk.bind(smem + (size_t)wave * WS::kWaveBytes, lane);
+    wstk.overflow = sc.wstack_overflow ? sc.wstack_overflow + slot * sc.woverflow_cap : nullptr;
+  }
   // LDS_SCENE: nodes + triangles staged once per workgroup next to the stacks (as k_render_sm does)
   const unsigned char *lds_nodes = smem + (size_t)(BLOCK / 64) * CAP * 64 * sizeof(uint32_t);
   const unsigned char *lds_tris = lds_nodes + (size_t)P.lds_nodes_bytes;
@@ -89,7 +103,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
   double ix = 0, iy = 0, iz = 0;
   bool sx = false, sy = false, sz = false;
   bool ray_plain = false; // the ray may take the min/max form of the slab test (mgpu_device.hpp, slab_hit)
-  int sp = -1;
+  int sp = -1;           // LDS_SCENE: index of the stack top; wide form: far children on the stack
+  uint32_t cur = kWNone; // wide form: record to enter next
   double bt = kDblMax, bu = 0, bv = 0;
   uint32_t bslot = kNoHit;
   uint32_t tri_cur = 0, tri_end = 0;
@@ -104,7 +119,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
     // lanes parked between paths (deferred start, see below) do not count towards the quorum; enough of them force a step
     const int cReal = __popcll(__ballot(st == ES_SHADE && have_ray));
     const bool run_shade = (cReal >= MGPU_ENV_SHADE_MIN) || (cN == 0 && cT == 0) || (cS - cReal >= MGPU_ENV_START_FORCE);
-    if (!run_shade && cN * (LDS_SCENE ? MGPU_ENV_NODE_WEIGHT : 1) >= cT) { // BVH in HBM: plain majority, as k_render_sm
+    if (!run_shade && cN * MGPU_ENV_NODE_WEIGHT >= cT * MGPU_ENV_TRI_WEIGHT) {
       // ================================ NODE step ================================
       const bool all_plain = __ballot(st == ES_NODE && !ray_plain) == 0ull; // wave-uniform
       if (st == ES_NODE) {
@@ -151,13 +166,29 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
             if (st != ES_NODE || sp < 0) break;
           }
         };
-        if (all_plain) node_pops(std::true_type{});
-        else node_pops(std::false_type{});
-        if (st == ES_NODE && sp < 0) st = ES_SHADE;
+        if constexpr (LDS_SCENE) {
+          if (all_plain) node_pops(std::true_type{});
+          else node_pops(std::false_type{});
+          if (st == ES_NODE && sp < 0) st = ES_SHADE;
+        } else {
+          int r;
+          if (all_plain)
+            r = wide_node_step<true, 3, kWideStackLds>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, bt, cur, sp, tri_cur, tri_end, n_nodes);
+          else
+            r = wide_node_step<false, 3, kWideStackLds>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, bt, cur, sp, tri_cur, tri_end, n_nodes);
+          if (r == WT_TRI) st = ES_TRI;
+          else if (r == WT_DONE) st = ES_SHADE;
+        }
       }
     } else if (!run_shade) {
       // ================================ TRI step =================================
-      if (st == ES_TRI) {
+      bool shared_done = false;
+      if (cT <= 32) { // 2 or 4 lanes per open leaf (mgpu_device.hpp, shared_leaves_step)
+        uint32_t my_trips = 0;
+        shared_done = shared_leaves_step<LDS_SCENE, 16>(mT, cT, cT <= 16 ? 2 : 1, lane, s_owner + wave * 64, st == ES_TRI, lds_tris,
+                                                        sc.tris, org, dir, tri_cur, tri_end, bt, bu, bv, bslot, n_tris, my_trips);
+      }
+      if (!shared_done && st == ES_TRI) {
 #pragma unroll 1
         for (int rep = 0; rep < 16; ++rep) {
           double2 a0, a1, a2, a3;
@@ -200,8 +231,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
           ++tri_cur;
           if (tri_cur == tri_end) break;
         }
-        if (tri_cur == tri_end) st = (sp < 0) ? ES_SHADE : ES_NODE;
       }
+      if (st == ES_TRI && tri_cur == tri_end) st = (LDS_SCENE ? sp < 0 : sp == 0) ? ES_SHADE : ES_NODE;
     } else {
       // ================================ SHADE step ===============================
       const bool shade_lane = (st == ES_SHADE);
@@ -356,7 +387,12 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
           ray_plain = sc.boxes_ordered && inv_ok && origin_is_finite(org);
           bt = kDblMax; bu = 0.0; bv = 0.0; bslot = kNoHit;
           sp = 0;
-          stk.put(0, 0u);
+          if constexpr (LDS_SCENE) {
+            stk.put(0, 0u);
+          } else {
+            cur = sc.wroot; // the super root (child 0 = the tree's root)
+            n_nodes -= 1u;
+          }
           have_ray = true;
           ++n_rays;
           st = ES_NODE;
@@ -393,15 +429,15 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
 
 template <int CAP, bool OVF, bool LDS_SCENE, int BLOCK>
 static hipError_t launch_one(dim3 grid, hipStream_t s, const DScene &sc, const EnvParams &p) {
-  size_t shmem = (size_t)(BLOCK / 64) * CAP * 64 * sizeof(uint32_t);
+  size_t shmem = LDS_SCENE ? (size_t)(BLOCK / 64) * CAP * 64 * sizeof(uint32_t) : (size_t)(BLOCK / 64) * WStack<kWideStackLds>::kWaveBytes;
   if (LDS_SCENE) {
     shmem += (size_t)p.lds_nodes_bytes + (size_t)p.lds_tris_bytes;
-    static bool attr_done = false; // one device per process in practice; the attribute is per function
-    if (!attr_done) {
+    static size_t granted = 0; // one device per process in practice; the attribute is per function (dynamic + static <= 160 KB)
+    if (shmem > granted) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render_env<CAP, OVF, LDS_SCENE, BLOCK>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
       if (e != hipSuccess) return e;
-      attr_done = true;
+      granted = shmem;
     }
   }
   hipLaunchKernelGGL((k_render_env<CAP, OVF, LDS_SCENE, BLOCK>), grid, dim3(BLOCK), shmem, s, sc, p);
@@ -415,11 +451,7 @@ hipError_t launch_render_env(int cap, bool lds_scene, dim3 grid, hipStream_t s, 
     if (cap == 24) return launch_one<24, false, true, 1024>(grid, s, sc, p);
     return hipErrorInvalidConfiguration;
   }
-  if (cap == 16 && !ovf) return launch_one<16, false, false, kEnvBlock>(grid, s, sc, p);
-  if (cap == 24 && !ovf) return launch_one<24, false, false, kEnvBlock>(grid, s, sc, p);
-  if (cap == 32 && !ovf) return launch_one<32, false, false, kEnvBlock>(grid, s, sc, p);
-  if (cap == 32 && ovf) return launch_one<32, true, false, kEnvBlock>(grid, s, sc, p);
-  return hipErrorInvalidConfiguration;
+  return launch_one<1, false, false, kEnvBlock>(grid, s, sc, p); // BVH in HBM: the wide form, one variant
 }
 
 } // namespace mgpu

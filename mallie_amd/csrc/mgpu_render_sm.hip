@@ -345,112 +345,16 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
     } else if (!run_shade) {
       // ================================ TRI step =================================
       MGPU_TICK();
-      // Shared leaves: with at most 32 (16) lanes holding an open leaf, 2 (4) lanes work on each -- lane L serves the
-      // (L / m)-th open leaf and tests its triangles first + L % m, + m, ... with the owner's ray (fetched across lanes),
-      // idle and NODE / SHADE lanes included; their own state is untouched.  The m partial results are merged by the rule
-      // the reference's in-order loop obeys for ordinary numbers -- smallest t, the LATER triangle on equal t
-      // (TriangleIsect rejects only `t > tBest`, bvh_accel.cc:631) -- and the owner applies the same `t > bt` test to the
-      // merged candidate.  A NaN t (which that loop would accept, and after which it accepts everything) cannot be
-      // merged this way: a step that produces one is thrown away and redone in order by the owners alone.
       bool shared_done = false;
       const bool occ_sample = occ_sampled();
       const uint32_t occ_t0 = MGPU_OCC ? tri_cur : 0u;
 #if MGPU_SHARED_LEAVES
-      if (cT <= 32) {
-        const int sh = cT <= MGPU_SHARE8_MAX ? 3 : (cT <= 16 ? 2 : 1), m = 1 << sh;
-        const uint32_t rank = (uint32_t)__popcll(mT & ((1ull << lane) - 1ull));
-        unsigned char *tbl = s_owner + wave * 64;
-        if (st == ST_TRI) tbl[rank] = (unsigned char)lane;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int grp = lane >> sh, sub = lane & (m - 1);
-        const bool serving = grp < cT;
-        const int own = serving ? (int)tbl[grp] : lane;
-        const V3 o = v3(__shfl(org.x, own), __shfl(org.y, own), __shfl(org.z, own));
-        const V3 d = v3(__shfl(dir.x, own), __shfl(dir.y, own), __shfl(dir.z, own));
-        const uint32_t first = (uint32_t)__shfl((int)tri_cur, own), last = (uint32_t)__shfl((int)tri_end, own);
-        double lt = __builtin_inf(), lu = 0.0, lv = 0.0;
-        uint32_t ls = kNoHit;
-        if (serving) {
-          uint32_t i = first + (uint32_t)sub;
-#pragma unroll 1
-          for (int rep = 0; rep < MGPU_TRIS_PER_STEP && i < last; ++rep, i += (uint32_t)m) {
-#ifdef MGPU_UTIL
-            if (lane == __ffsll((long long)__ballot(1)) - 1) u_tri_it++;
-#endif
-            double2 a0, a1, a2, a3;
-            double e2z;
-            if (LDS_SCENE) {
-              const unsigned char *tp = lds_tris + (size_t)i * 80;
-              a0 = *reinterpret_cast<const double2 *>(tp);
-              a1 = *reinterpret_cast<const double2 *>(tp + 16);
-              a2 = *reinterpret_cast<const double2 *>(tp + 32);
-              a3 = *reinterpret_cast<const double2 *>(tp + 48);
-              e2z = *reinterpret_cast<const double *>(tp + 64);
-            } else {
-              const DTri *tp = sc.tris + i;
-              a0 = reinterpret_cast<const double2 *>(tp)[0];
-              a1 = reinterpret_cast<const double2 *>(tp)[1];
-              a2 = reinterpret_cast<const double2 *>(tp)[2];
-              a3 = reinterpret_cast<const double2 *>(tp)[3];
-              e2z = tp->e2[2];
-            }
-            ++n_tris;
-            const V3 p0 = v3(a0.x, a0.y, a1.x), e1 = v3(a1.y, a2.x, a2.y), e2 = v3(a3.x, a3.y, e2z);
-            const V3 p = cross(d, e2);
-            const double det = dot(e1, p);
-            if (!(fabs(det) < kDblEps1024)) {
-              const double invDet = inv_det_w(det);
-              const V3 sv = o - p0;
-              const V3 q = cross(sv, e1);
-              const double u = dot(sv, p) * invDet;
-              const double v = dot(q, d) * invDet;
-              const double t = dot(e2, q) * invDet;
-              const bool rej = (u < 0.0 || u > 1.0) || (v < 0.0 || u + v > 1.0) || (t < 0.0 || t > lt);
-              if (!rej) {
-                lt = t;
-                lu = u;
-                lv = v;
-                ls = i;
-              }
-            }
-          }
-        }
-        if (__ballot(lt != lt) == 0ull) { // no NaN candidate anywhere: merge
-          for (int x = 1; x < m; x <<= 1) {
-            const double pt = __shfl_xor(lt, x), pu = __shfl_xor(lu, x), pv = __shfl_xor(lv, x);
-            const uint32_t ps = (uint32_t)__shfl_xor((int)ls, x);
-            // partner wins with a smaller t, or with an equal t and the later triangle (kNoHit never wins: its t is +inf
-            // and an equal +inf from a real triangle loses nothing -- the owner's `t > bt` test rejects it either way)
-            const bool take = ps != kNoHit && (ls == kNoHit || pt < lt || (pt == lt && ps > ls));
-            if (take) {
-              lt = pt;
-              lu = pu;
-              lv = pv;
-              ls = ps;
-            }
-          }
-          const int from = (int)(rank << sh); // lane 0 of this owner's group holds the merged candidate (as do the others)
-          const double ct = __shfl(lt, from), cu = __shfl(lu, from), cv = __shfl(lv, from);
-          const uint32_t cs = (uint32_t)__shfl((int)ls, from);
-          if (st == ST_TRI) {
-            if (cs != kNoHit && !(ct > bt)) {
-              bt = ct;
-              bu = cu;
-              bv = cv;
-              bslot = cs;
-            }
-            const uint32_t done = min(tri_end - tri_cur, (uint32_t)(MGPU_TRIS_PER_STEP * m));
-            tri_cur += done;
-          }
-          shared_done = true;
-          if (occ_sample) // iterations of this lane as one of the m workers of its leaf
-            occ_book(serving ? min(((last - first) + (uint32_t)(m - 1 - sub)) >> sh, (uint32_t)MGPU_TRIS_PER_STEP) : 0u,
-                     MGPU_TRIS_PER_STEP, 2);
-        } else {
-          if (serving) n_tris -= min(((last - first) + (uint32_t)(m - 1 - sub)) >> sh, (uint32_t)MGPU_TRIS_PER_STEP); // not counted twice
-        }
+      if (cT <= 32) { // mgpu_device.hpp, shared_leaves_step: 2, 4 (or 8) lanes per open leaf
+        uint32_t my_trips = 0;
+        shared_done = shared_leaves_step<LDS_SCENE, MGPU_TRIS_PER_STEP>(mT, cT, cT <= MGPU_SHARE8_MAX ? 3 : (cT <= 16 ? 2 : 1), lane,
+                                                                       s_owner + wave * 64, st == ST_TRI, lds_tris, sc.tris, org, dir,
+                                                                       tri_cur, tri_end, bt, bu, bv, bslot, n_tris, my_trips);
+        if (shared_done && occ_sample) occ_book(my_trips, MGPU_TRIS_PER_STEP, 2);
       }
 #endif
       if (!shared_done && st == ST_TRI) {

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
   if (select && *select != kTraceSelectSm) return; // k_trace_probe chose the other kernel for this batch
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ unsigned long long s_cnt[3];
+  __shared__ unsigned char s_owner[kTraceBlock]; // TRI step with shared leaves: lane of the k-th open leaf, per wave
   using WS = WStack<kWideStackLds>;
   // per wave: the far-child stack's LDS part, then (all waves) the record staging: 16 records of 23 8-byte pieces + their
   // 16 ray indices per wave
@@ -97,7 +98,13 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
       }
     } else if (!run_emit) {
       // ================================ TRI step =================================
-      if (st == TS_TRI) {
+      bool shared_done = false;
+      if (cT <= 32) { // 2 or 4 lanes per open leaf (mgpu_device.hpp, shared_leaves_step)
+        uint32_t my_trips = 0;
+        shared_done = shared_leaves_step<false, 16>(mT, cT, cT <= 16 ? 2 : 1, lane, s_owner + wave * 64, st == TS_TRI, nullptr, sc.tris,
+                                                    org, dir, tri_cur, tri_end, bt, bu, bv, bslot, n_tris, my_trips);
+      }
+      if (!shared_done && st == TS_TRI) {
 #pragma unroll 1
         for (int rep = 0; rep < 16; ++rep) {
           const DTri *tp = sc.tris + tri_cur;
@@ -129,8 +136,8 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
           ++tri_cur;
           if (tri_cur == tri_end) break;
         }
-        if (tri_cur == tri_end) st = (sp == 0) ? TS_EMIT : TS_NODE; // cur == kWNone: the next NODE step pops
       }
+      if (st == TS_TRI && tri_cur == tri_end) st = (sp == 0) ? TS_EMIT : TS_NODE; // cur == kWNone: the next NODE step pops
     } else {
       // ================================ EMIT step ================================
       const bool emit_lane = (st == TS_EMIT);
