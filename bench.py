@@ -70,12 +70,17 @@ def pmc_for(workload, lib_path):
             d = json.load(f)
     except (OSError, ValueError):
         return None, "no profiles/pmc_current.json"
-    if d.get("so_sha256") != so_sha256(lib_path):
-        return None, "profiles/pmc_current.json was collected on another build of the library (sha256 differs)"
+    from mallie_amd import build as _b
+    if d.get("so_sha256") == so_sha256(lib_path):
+        stamp = "library sha256 %s" % d["so_sha256"][:16]
+    elif d.get("source_sha256") and d.get("source_sha256") == _b.source_digest() and not _b.is_stale():
+        stamp = "source digest %s (same sources and flags, library rebuilt elsewhere)" % d["source_sha256"][:16]
+    else:
+        return None, "profiles/pmc_current.json was collected on another build of the library (sha256 of library and sources differ)"
     w = d.get("workloads", {}).get(workload)
     if not w:
         return None, "profiles/pmc_current.json has no entry for %s" % workload
-    return w, "profiles/pmc_current.json (rocprofv3 --pmc, separate passes), library sha256 %s" % d["so_sha256"][:16]
+    return w, "profiles/pmc_current.json (rocprofv3 --pmc, separate passes), %s" % stamp
 
 
 def hbm_bytes(p):

@@ -17,8 +17,11 @@ SOURCES = ["mgpu_kernels.hip", "mgpu_render_sm.hip", "mgpu_trace_sm.hip", "mgpu_
 HEADERS = ["mgpu_device.hpp", "mgpu_kernels.hpp", "host/mesh_io.hpp", os.path.join("..", "..", "include", "mgpu.h"),
            os.path.join("..", "..", "include", "mallie", "mallie_api.hpp")]
 # -ffp-contract=off: the parity contract (no FMA contraction on device or host), see csrc/mgpu_device.hpp
+# -ffile-prefix-map: __FILE__ (error messages) does not carry the checkout's path.  The binary still depends on that path
+# (clang's per-file ids of internal device symbols); rebuilt in the same place it is bit-identical, and bench.py matches the
+# committed PMC passes to it by its sha256 or, failing that, by source_digest() below
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
-         "-Wno-unused-function"]
+         "-Wno-unused-function", "-ffile-prefix-map=%s=." % os.path.dirname(HERE)]
 
 
 def hipcc():
@@ -26,6 +29,19 @@ def hipcc():
         if cand and os.path.exists(cand):
             return cand
     raise RuntimeError("hipcc not found (need ROCm; this package has no CPU build)")
+
+
+def source_digest():
+    """sha256 over the library's sources, headers and compiler flags (paths excluded): identifies the kernels a binary was
+    built from wherever it was built (the binary's own sha256 depends on the checkout path through clang's per-file ids)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        h.update(os.path.basename(f).encode())
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(x for x in FLAGS if not x.startswith("-ffile-prefix-map")).encode())
+    return h.hexdigest()
 
 
 def is_stale():

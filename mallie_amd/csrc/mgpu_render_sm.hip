@@ -813,51 +813,56 @@ __global__ __launch_bounds__(256) void k_accumulate(const float *__restrict__ pl
   if (count && i < n_floats / 3) count[i] += passes;
 }
 
-// Planes in tile-major order (what k_render_sm writes for several passes, see there): image float f of the window
-// (row-major, 3 * win_w per row) lives at ((y / 8) * tiles_x + x / 8) * 192 + ((y % 8) * 8 + x % 8) * 3 + channel of
-// every plane.  VEC = 4: windows whose width is a multiple of 8 -- four consecutive image floats then lie in one 96-byte
-// tile row and the loads stay 16 bytes wide; VEC = 1 otherwise.  Same additions per float, same order.
+// Planes in tile-major order (what k_render_sm writes for several passes, see there): slot ((ty * tiles_x + tx) * 64 +
+// (y % 8) * 8 + x % 8) * 3 + channel of every plane holds image float 3 * (y * win_w + x) + channel of the window.  The
+// threads walk the PLANES (consecutive threads read consecutive 16 bytes of all passes -- 16/17 of the traffic is these
+// reads) and scatter 96-byte tile rows into the image.  VEC = 4: window widths that are multiples of 8 (a tile row then
+// is 24 whole floats of one image row, 16-byte aligned on both sides); VEC = 1 otherwise.  Same additions per float, same
+// order.
 template <int VEC>
 __global__ __launch_bounds__(256) void k_accumulate_tiled(const float *__restrict__ planes, size_t plane_stride, int passes,
-                                                           size_t n_floats, uint32_t win_w, uint32_t tiles_x,
+                                                           uint32_t win_w, uint32_t n_rows, uint32_t tiles_x,
                                                            float *__restrict__ image, int32_t *__restrict__ count, bool resume) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t f = i * VEC;
-  if (f < n_floats) {
-    const size_t row_floats = (size_t)3 * win_w;
-    const uint32_t y = (uint32_t)(f / row_floats), c = (uint32_t)(f - (size_t)y * row_floats);
-    const uint32_t x = c / 3u, ch = c - 3u * x;
-    const size_t off = ((size_t)(y >> 3) * tiles_x + (x >> 3)) * 192u + (size_t)(((y & 7u) << 3) + (x & 7u)) * 3u + ch;
-    if (VEC == 4) {
-      float4 acc = resume ? *reinterpret_cast<const float4 *>(image + f) : make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int p = 0; p < passes; ++p) {
-        const float4 v = *reinterpret_cast<const float4 *>(planes + (size_t)p * plane_stride + off);
-        acc.x += v.x;
-        acc.y += v.y;
-        acc.z += v.z;
-        acc.w += v.w;
-      }
-      *reinterpret_cast<float4 *>(image + f) = acc;
-    } else {
-      float acc = resume ? image[f] : 0.f;
-      for (int p = 0; p < passes; ++p) acc += planes[(size_t)p * plane_stride + off];
-      image[f] = acc;
+  const size_t p0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC; // float index inside a plane
+  if (p0 >= plane_stride) return;
+  const uint32_t tile = (uint32_t)(p0 / 192u), o = (uint32_t)(p0 - (size_t)tile * 192u);
+  const uint32_t r = o / 24u, c = o - 24u * r; // row inside the tile, float inside that row (pixel c / 3, channel c % 3)
+  const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const uint32_t y = ty * 8u + r, x = tx * 8u + c / 3u;
+  if (y >= n_rows || x >= win_w) return; // padding of an edge tile
+  const size_t f = ((size_t)y * win_w + (size_t)tx * 8u) * 3u + c;
+  if (VEC == 4) {
+    float4 acc = resume ? *reinterpret_cast<const float4 *>(image + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < passes; ++p) {
+      const float4 v = *reinterpret_cast<const float4 *>(planes + (size_t)p * plane_stride + p0);
+      acc.x += v.x;
+      acc.y += v.y;
+      acc.z += v.z;
+      acc.w += v.w;
     }
-    if (count) // n_floats / 3 pixel counters dealt to the n_floats / VEC threads that hold image floats
-      for (size_t k = i; k < n_floats / 3; k += (n_floats + VEC - 1) / VEC) count[k] += passes;
+    *reinterpret_cast<float4 *>(image + f) = acc;
+    if (count) { // the pixels whose first channel lies in this thread's four floats
+      for (uint32_t k = 0; k < 4; ++k)
+        if ((c + k) % 3u == 0) count[(size_t)y * win_w + (size_t)tx * 8u + (c + k) / 3u] += passes;
+    }
+  } else {
+    float acc = resume ? image[f] : 0.f;
+    for (int p = 0; p < passes; ++p) acc += planes[(size_t)p * plane_stride + p0];
+    image[f] = acc;
+    if (count && c % 3u == 0) count[(size_t)y * win_w + x] += passes;
   }
 }
 
 void launch_accumulate_tiled(hipStream_t s, const float *planes, size_t plane_stride, int passes, size_t n_floats, int win_w,
                              float *image, int32_t *count, bool resume) {
   const uint32_t tiles_x = (uint32_t)(win_w + 7) >> 3;
+  const uint32_t n_rows = (uint32_t)(n_floats / ((size_t)3 * win_w));
   if (win_w % 8 == 0 && ((uintptr_t)image & 15) == 0 && ((uintptr_t)planes & 15) == 0 && plane_stride % 4 == 0) {
-    const size_t n4 = n_floats / 4; // 3 * win_w * rows with win_w % 8 == 0 is a multiple of 4
-    hipLaunchKernelGGL(k_accumulate_tiled<4>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, planes, plane_stride, passes,
-                       n_floats, (uint32_t)win_w, tiles_x, image, count, resume);
+    hipLaunchKernelGGL(k_accumulate_tiled<4>, dim3((unsigned)((plane_stride / 4 + 255) / 256)), dim3(256), 0, s, planes, plane_stride,
+                       passes, (uint32_t)win_w, n_rows, tiles_x, image, count, resume);
   } else {
-    hipLaunchKernelGGL(k_accumulate_tiled<1>, dim3((unsigned)((n_floats + 255) / 256)), dim3(256), 0, s, planes, plane_stride,
-                       passes, n_floats, (uint32_t)win_w, tiles_x, image, count, resume);
+    hipLaunchKernelGGL(k_accumulate_tiled<1>, dim3((unsigned)((plane_stride + 255) / 256)), dim3(256), 0, s, planes, plane_stride,
+                       passes, (uint32_t)win_w, n_rows, tiles_x, image, count, resume);
   }
 }
 

@@ -20,7 +20,9 @@ if os.path.exists(bl) and os.path.getsize(bl):
     lines.append("")
     lines.append("bench line of the traced run: " + open(bl).read().strip()[:400] + " ...")
 sha = open(os.path.join(src, "so_sha256.txt")).read().strip()
-out = {"so_sha256": sha, "tag": tag, "workloads": {}}
+sys.path.insert(0, ROOT)
+from mallie_amd import build as _build
+out = {"so_sha256": sha, "source_sha256": _build.source_digest(), "tag": tag, "workloads": {}}
 for d in sorted(glob.glob(os.path.join(src, "c?_*"))):
     if not os.path.isdir(d):
         continue
