@@ -189,7 +189,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
   int pass = 0;
   Rng rng{1, 0, 0, 0};
   V3 org = v3(0, 0, 0), dir = v3(0, 0, 1);
-  double thr0 = 1, thr1 = 1, thr2 = 1, rad0 = 0, rad1 = 0, rad2 = 0;
+  double thr0 = 1, thr1 = 1, thr2 = 1; // the radiance is not path state: it stays 0 until the step that ends the path (below)
   int pathLength = 1;
   uint32_t last_mat = kNoMaterial;
   uint32_t cost_base = 0;  // n_nodes + n_tris + 16 * n_rays when the current path started
@@ -476,11 +476,14 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
             rec[0] = org.x; rec[1] = org.y; rec[2] = org.z; rec[3] = dir.x; rec[4] = dir.y; rec[5] = dir.z;
             rec[6] = t; rec[7] = hit ? 1.0 : 0.0; rec[8] = (bt < kDblMax && t == bt) ? (double)bslot : -1.0;
             rec[9] = n.x; rec[10] = n.y; rec[11] = n.z; rec[12] = (double)last_mat; rec[13] = (double)pathLength;
-            rec[14] = thr0; rec[15] = rad0;
+            rec[14] = thr0; rec[15] = 0.0; // radiance before the iteration's update: nothing is added before the first miss
           }
 #ifdef MGPU_UTIL
           cyc_sub[0] += clock64() - cyc_s; cyc_s = clock64();
 #endif
+          // PathTrace adds to the radiance only on a miss (render.cc:409-418), and the first miss ends the path here (its
+          // continuation is evaluated in closed loop): the radiance lives in this step only, not in registers between steps
+          double rad0 = 0.0, rad1 = 0.0, rad2 = 0.0;
           if (!hit) {
             path_done = true;
             if (pathLength < 2) {
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
                 d1 = sc.mat_diffuse[3 * (size_t)last_mat + 1];
                 d2 = sc.mat_diffuse[3 * (size_t)last_mat + 2];
               }
-              if (thr0 == thr1 && thr1 == thr2 && rad0 == rad1 && rad1 == rad2 && d0 == d1 && d1 == d2) {
+              if (thr0 == thr1 && thr1 == thr2 && d0 == d1 && d1 == d2) {
                 // grey path (every material the reference can load from .obj/.eson is grey): the three channels
                 // perform identical operations on identical values, so evaluate one and copy -- same bits, 1/3 of the
                 // fp64 divisions
@@ -679,7 +682,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
           org = v3(P.frame[0], P.frame[1], P.frame[2]);
           dir = camera_dir(P.frame, (double)((float)gx + ju), (double)((float)gy + jv));
           thr0 = thr1 = thr2 = 1.0;
-          rad0 = rad1 = rad2 = 0.0;
           pathLength = 1;
           ++paths;
           cost_base = n_nodes + n_tris + 16u * n_rays;
