@@ -13,6 +13,7 @@
 //     `image[px] += radiance` exactly as written there: float += double, sample after sample;
 //   * primary rays come from sin / cos of the pixel's spherical angles (device sincos: <= 1 ulp from glibc; radiance
 //     depends on hit / miss events only, see DESIGN.md "Numerics").
+#include <mutex>
 #include <type_traits>
 #include "mgpu_device.hpp"
 #include "mgpu_kernels.hpp"
@@ -432,12 +433,18 @@ static hipError_t launch_one(dim3 grid, hipStream_t s, const DScene &sc, const E
   size_t shmem = LDS_SCENE ? (size_t)(BLOCK / 64) * CAP * 64 * sizeof(uint32_t) : (size_t)(BLOCK / 64) * WStack<kWideStackLds>::kWaveBytes;
   if (LDS_SCENE) {
     shmem += (size_t)p.lds_nodes_bytes + (size_t)p.lds_tris_bytes;
-    static size_t granted = 0; // one device per process in practice; the attribute is per function (dynamic + static <= 160 KB)
-    if (shmem > granted) {
+    // the attribute is per function and device (dynamic + static <= 160 KB); set it whenever a launch needs more than any
+    // before it on that device
+    static size_t granted[16] = {0};
+    static std::mutex granted_mutex;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(granted_mutex);
+    if (dev < 0 || dev >= 16 || shmem > granted[dev]) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render_env<CAP, OVF, LDS_SCENE, BLOCK>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
       if (e != hipSuccess) return e;
-      granted = shmem;
+      if (dev >= 0 && dev < 16) granted[dev] = shmem;
     }
   }
   hipLaunchKernelGGL((k_render_env<CAP, OVF, LDS_SCENE, BLOCK>), grid, dim3(BLOCK), shmem, s, sc, p);

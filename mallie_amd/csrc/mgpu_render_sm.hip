@@ -32,6 +32,7 @@
 #include "mgpu_kernels.hpp"
 
 #include <climits>
+#include <mutex>
 
 namespace mgpu {
 
@@ -1027,14 +1028,20 @@ void launch_tonemap(hipStream_t s, const float *image, const int32_t *count, siz
 template <int CAP, bool LDS, int BLOCK, bool OVF>
 static hipError_t launch_one(dim3 grid, hipStream_t s, size_t shmem, const DScene &sc, const RenderParams &p) {
   auto kern = k_render_sm<CAP, LDS, BLOCK, OVF>;
-  static size_t granted[16] = {0}; // per device: dynamic-LDS size already granted to this instantiation
+  // per device: dynamic-LDS size already granted to this instantiation.  Scenes on different devices are driven from
+  // different host threads (and the multi-GPU frame drives several from one): the table is guarded.
+  static size_t granted[16] = {0};
+  static std::mutex granted_mutex;
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (shmem > 48 * 1024 && (dev < 0 || dev >= 16 || shmem > granted[dev])) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)shmem);
-    if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < 16) granted[dev] = shmem;
+  if (shmem > 48 * 1024) {
+    std::lock_guard<std::mutex> lock(granted_mutex);
+    if (dev < 0 || dev >= 16 || shmem > granted[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)shmem);
+      if (e != hipSuccess) return e;
+      if (dev >= 0 && dev < 16) granted[dev] = shmem;
+    }
   }
   hipLaunchKernelGGL(kern, grid, dim3(BLOCK), shmem, s, sc, p);
   return hipGetLastError();
