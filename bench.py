@@ -63,7 +63,7 @@ def so_sha256(path):
 
 
 def pmc_for(workload, lib_path):
-    """Per-launch PMC numbers of the dominant kernel on `workload` from profiles/pmc_current.json (profiles/collect_pmc.sh +
+    """Per-FRAME PMC numbers of the dominant kernel (summed over its launches of one frame) on `workload` from profiles/pmc_current.json (profiles/collect_pmc.sh +
     profiles/summarize_pmc.py) -- only if they were collected on the library loaded now.  Returns (dict or None, reason)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_current.json")) as f:
@@ -84,7 +84,7 @@ def pmc_for(workload, lib_path):
 
 
 def hbm_bytes(p):
-    """HBM bytes per launch: 2 x FETCH_SIZE (gfx950 correction of the guide) + WRITE_SIZE, both reported in KiB."""
+    """HBM bytes per frame: 2 x FETCH_SIZE (gfx950 correction of the guide) + WRITE_SIZE, both reported in KiB."""
     if not p or "FETCH_SIZE" not in p or "WRITE_SIZE" not in p:
         return None
     return int(2 * p["FETCH_SIZE"] * 1024 + p["WRITE_SIZE"] * 1024)
@@ -387,20 +387,20 @@ def main():
                                        "ratio_to_peak": round(alg_gbs / HBM_PEAK_GBS, 4),
                                        "note": "SURVEY 8(d): nodes*64 + tris*76 + rays*80 over the kernel time against 8 TB/s. Not a "
                                                "roofline here: this scene's BVH is staged in LDS and those bytes never leave the CU"},
-                "note": "bound = fp64 VALU issue: `achieved` = executed VALU wave-instructions (SQ_INSTS_VALU per launch) / mean kernel "
+                "note": "bound = fp64 VALU issue: `achieved` = executed VALU wave-instructions (SQ_INSTS_VALU per frame = per launch here) / mean kernel "
                         "time of THIS run (HIP events on the launch stream); `peak` = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 fp64 "
                         "instruction. `valu.issue_busy` = SQ_ACTIVE_INST_VALU x 4 cycles / SIMD cycles; `lane_occupancy` = active lanes "
                         "per executed instruction, measured in this run; their product is the useful share of the issue peak."}
         if p and "SQ_ACTIVE_INST_VALU" in p and ksec > 0:
-            roof["valu"] = {"insts_per_launch": int(p["SQ_INSTS_VALU"]),
+            roof["valu"] = {"insts_per_frame": int(p["SQ_INSTS_VALU"]),
                             "wave_insts_per_ray": round(p["SQ_INSTS_VALU"] / max(st["real_rays"] / max(launches, 1), 1), 2),
                             "issue_busy": round(p["SQ_ACTIVE_INST_VALU"] * 4.0 / (ksec * CLOCK_HZ * N_SIMD), 3),
-                            "salu_insts_per_launch": int(p["SQ_INSTS_SALU"]) if "SQ_INSTS_SALU" in p else None}
+                            "salu_insts_per_frame": int(p["SQ_INSTS_SALU"]) if "SQ_INSTS_SALU" in p else None}
         if traffic and ksec > 0:
             roof["hbm"] = {"measured_GBps": round(traffic / ksec / 1e9, 1), "frac_of_peak": round(traffic / ksec / 1e9 / HBM_PEAK_GBS, 4),
                            "fetch_bytes": int(2 * p["FETCH_SIZE"] * 1024), "write_bytes": int(p["WRITE_SIZE"] * 1024),
                            "needed_write_bytes": int(12 * W * H * spp),
-                           "note": "2*FETCH_SIZE + WRITE_SIZE per launch of k_render_sm; needed_write = the per-pass radiance planes it produces"}
+                           "note": "2*FETCH_SIZE + WRITE_SIZE per frame (one launch) of k_render_sm; needed_write = the per-pass radiance planes it produces"}
         out = {
             "metric": "Mrays/sec + ms/frame at 1920x1080, cornellbox_suzanne, 1/2/4/8 GPU",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

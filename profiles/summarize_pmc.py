@@ -34,19 +34,22 @@ for d in sorted(glob.glob(os.path.join(src, "c?_*"))):
                 continue
             a = acc[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])]
             a[0] += float(r["Counter_Value"]); a[1].add(r["Dispatch_Id"])
+    FRAMES = 3  # tools/pmc_workload.py <workload> 3: frames rendered per pass of the collection
     for (k, c), (v, disp) in acc.items():
         e = out["workloads"].setdefault(w, {"kernel": k})
-        e[c] = v / max(len(disp), 1)
+        # per FRAME (a frame whose pass planes exceed 1 GiB is rendered in several launches: C3's 64 passes take two)
+        e[c] = v / FRAMES
         e["launches_" + c] = len(disp)
+        e["launches_per_frame"] = len(disp) / FRAMES
 lines.append("")
-lines.append("== PMC passes (per launch of the render kernel; library sha256 %s) ==" % sha)
+lines.append("== PMC passes (per FRAME: sum over the render kernel's launches of a frame; library sha256 %s) ==" % sha)
 for w, e in sorted(out["workloads"].items()):
     lines.append("%s  %s" % (w, e["kernel"]))
     for c, v in sorted(e.items()):
-        if c != "kernel" and not c.startswith("launches_"):
+        if c != "kernel" and not c.startswith("launches_") and c != "launches_per_frame":
             lines.append("    %-26s %.6g   (%d launches)" % (c, v, e["launches_" + c]))
     if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
-        lines.append("    HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes) = %.4g" % (2 * e["FETCH_SIZE"] * 1024 + e["WRITE_SIZE"] * 1024))
+        lines.append("    HBM bytes per frame = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes) = %.4g   (%.2g launches per frame)" % (2 * e["FETCH_SIZE"] * 1024 + e["WRITE_SIZE"] * 1024, e["launches_per_frame"]))
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_current.json"), "w"), indent=1, sort_keys=True)
 open(os.path.join(ROOT, "profiles", tag + "_summary.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
