@@ -1055,3 +1055,27 @@ def test_device_bvh_build_is_byte_identical():
     a = M.bvh_build(verts, faces, 0.1, 7, 40, 100, device=0)
     b = M.bvh_build(verts, faces, 0.1, 7, 40, 100)
     assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1])
+
+
+def test_bench_line_is_well_formed(tmp_path):
+    """bench.py end to end on the GPU (short run): ONE JSON object on the last stdout line with the contract's fields, the
+    roofline object naming its bound, the occupancy pass of the instrumented library, and the frame byte-equal to the oracle's."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1"], capture_output=True,
+                       text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "Mrays/s" and d["value"] > 1000 and "workload" in d["config"]
+    roof = d["roofline"]
+    assert roof["bound"] == "valu" and roof["peak"] > 0 and "traffic" in roof and "frac" in roof and roof["kernel_avg_ms"] > 0
+    assert 0.5 < roof["algorithmic_vs_hbm"]["ratio_to_peak"] < 5
+    occ = roof["lane_occupancy"]
+    assert occ and 0.2 < occ["node_frac"] < 1 and 0.2 < occ["tri_frac"] < 1 and 0.2 < occ["shade_frac"] <= 1
+    assert d["cpu_baseline"]["gpu_frame_byte_equal"] is True and d["cpu_baseline"]["kind"] == "port"
+    assert set(d["extra_configs"]) == {"c3", "c4"} and all("error" not in v for v in d["extra_configs"].values())
+    assert d["frame_with_readback"]["ms_per_frame"] >= d["ms_per_step"] * 0.9
