@@ -437,6 +437,11 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
   s->d.stack_overflow = nullptr;
   s->d.overflow_cap = 0;
   s->d.boxes_ordered = s->boxes_ordered ? 1 : 0;
+  s->d.grey = 1;
+  for (size_t i = 0; i < nm; i++)
+    if (!(mat_diffuse[3 * i] == mat_diffuse[3 * i + 1] && mat_diffuse[3 * i + 1] == mat_diffuse[3 * i + 2])) s->d.grey = 0;
+  if (const char *e = getenv("MGPU_GREY")) // 0: the general three-channel kernel even for grey scenes (A/B measurements, tests)
+    if (atoi(e) == 0) s->d.grey = 0;
   if (const char *e = getenv("MGPU_PLAIN_SLABS")) // 0: literal slab test only (A/B measurements, tests)
     if (atoi(e) == 0) s->d.boxes_ordered = 0;
   if (const char *e = getenv("MGPU_TILE_ORDER")) s->tile_order_on = atoi(e) != 0;

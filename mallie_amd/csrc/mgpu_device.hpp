@@ -73,6 +73,8 @@ struct DScene {
   // every reachable node has bmin <= bmax on all axes (checked at scene creation): rays without infinities may then
   // take the min/max form of the slab test, see slab_hit
   int boxes_ordered;
+  // every material has three equal diffuse channels (or there are none: the default material is 0.5 grey)
+  int grey;
 };
 
 struct Hit {

@@ -102,7 +102,10 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 #ifndef MGPU_SM_MIN_WAVES
 #define MGPU_SM_MIN_WAVES 4
 #endif
-template <int CAP, bool LDS_SCENE, int BLOCK, bool OVF>
+// GREY: every material of the scene has three equal diffuse channels (all the reference can load from .obj / .eson; checked
+// when the scene is created).  The three channels of throughput and radiance then perform identical operations on identical
+// values from the first to the last step of a path, so one is carried and the result copied: same bits, four registers less.
+template <int CAP, bool LDS_SCENE, int BLOCK, bool OVF, bool GREY>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) void k_render_sm(DScene sc, RenderParams P_arg) {
   // The launch parameters live in LDS, not in scalar registers: the traversal bodies use none of them, SHADE uses
   // nearly all, and ~60 kernel-argument SGPRs kept alive across the loop were being spilled to VGPR lanes.
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
                 d1 = sc.mat_diffuse[3 * (size_t)last_mat + 1];
                 d2 = sc.mat_diffuse[3 * (size_t)last_mat + 2];
               }
-              if (thr0 == thr1 && thr1 == thr2 && d0 == d1 && d1 == d2) {
+              if (GREY || (thr0 == thr1 && thr1 == thr2 && d0 == d1 && d1 == d2)) {
                 // grey path (every material the reference can load from .obj/.eson is grey): the three channels
                 // perform identical operations on identical values, so evaluate one and copy -- same bits, 1/3 of the
                 // fp64 divisions
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
                   if (mul) thr0 *= d0;
                 }
                 rad1 = rad2 = rad0;
-                thr1 = thr2 = thr0;
+                if (!GREY) thr1 = thr2 = thr0;
               } else {
                 for (int L = pathLength;; ++L) {
                   const double dl = (double)(unsigned)L;
@@ -536,10 +539,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
             if (last_mat != kNoMaterial) { // Scene::GetMaterial, scene.h:58-65
               if ((size_t)(int)last_mat < (size_t)sc.nm) {
                 thr0 *= sc.mat_diffuse[3 * (size_t)last_mat + 0];
-                thr1 *= sc.mat_diffuse[3 * (size_t)last_mat + 1];
-                thr2 *= sc.mat_diffuse[3 * (size_t)last_mat + 2];
+                if (!GREY) {
+                  thr1 *= sc.mat_diffuse[3 * (size_t)last_mat + 1];
+                  thr2 *= sc.mat_diffuse[3 * (size_t)last_mat + 2];
+                }
               } else {
-                thr0 *= 0.5; thr1 *= 0.5; thr2 *= 0.5;
+                thr0 *= 0.5;
+                if (!GREY) { thr1 *= 0.5; thr2 *= 0.5; }
               }
             }
             org = hitP + scale(sd, 1.0e-3);
@@ -682,7 +688,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
           const float jv = (float)(rng_next(rng) - 0.5);
           org = v3(P.frame[0], P.frame[1], P.frame[2]);
           dir = camera_dir(P.frame, (double)((float)gx + ju), (double)((float)gy + jv));
-          thr0 = thr1 = thr2 = 1.0;
+          thr0 = 1.0;
+          if (!GREY) thr1 = thr2 = 1.0;
           pathLength = 1;
           ++paths;
           cost_base = n_nodes + n_tris + 16u * n_rays;
@@ -1025,9 +1032,9 @@ void launch_tonemap(hipStream_t s, const float *image, const int32_t *count, siz
 // =====================================================================================================================
 // launcher
 // =====================================================================================================================
-template <int CAP, bool LDS, int BLOCK, bool OVF>
-static hipError_t launch_one(dim3 grid, hipStream_t s, size_t shmem, const DScene &sc, const RenderParams &p) {
-  auto kern = k_render_sm<CAP, LDS, BLOCK, OVF>;
+template <int CAP, bool LDS, int BLOCK, bool OVF, bool GREY>
+static hipError_t launch_grey(dim3 grid, hipStream_t s, size_t shmem, const DScene &sc, const RenderParams &p) {
+  auto kern = k_render_sm<CAP, LDS, BLOCK, OVF, GREY>;
   // per device: dynamic-LDS size already granted to this instantiation.  Scenes on different devices are driven from
   // different host threads (and the multi-GPU frame drives several from one): the table is guarded.
   static size_t granted[16] = {0};
@@ -1045,6 +1052,11 @@ static hipError_t launch_one(dim3 grid, hipStream_t s, size_t shmem, const DScen
   }
   hipLaunchKernelGGL(kern, grid, dim3(BLOCK), shmem, s, sc, p);
   return hipGetLastError();
+}
+
+template <int CAP, bool LDS, int BLOCK, bool OVF>
+static hipError_t launch_one(dim3 grid, hipStream_t s, size_t shmem, const DScene &sc, const RenderParams &p) {
+  return sc.grey ? launch_grey<CAP, LDS, BLOCK, OVF, true>(grid, s, shmem, sc, p) : launch_grey<CAP, LDS, BLOCK, OVF, false>(grid, s, shmem, sc, p);
 }
 
 // Instantiations: LDS-resident scene (small trees only: CAP 16 / 24, never an overflow column) with 1024- or 512-thread

@@ -490,6 +490,25 @@ def test_render_materials_and_no_matids():
             assert not np.array_equal(img[..., 0], img[..., 2])  # RGB really differ
 
 
+def test_grey_and_three_channel_kernels_agree(monkeypatch):
+    """Scenes whose materials all have equal diffuse channels run the GREY instantiation of k_render_sm (one channel carried,
+    the result copied); MGPU_GREY=0 forces the three-channel kernel on the same scene: same bits, with explicit grey
+    materials too (and a coloured scene can only take the three-channel kernel: test_render_materials_and_no_matids)."""
+    g = O.load_golden("cornell_obj")
+    mats = np.array([[0.25, 0.25, 0.25], [0.75, 0.75, 0.75]])
+    ids = (np.arange(len(g["faces"])) % 3).astype("u4")  # ids 0, 1 and 2 (2 = out of range -> default 0.5)
+    W, H = 200, 120
+    frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    imgs = []
+    for grey in ("1", "0"):
+        monkeypatch.setenv("MGPU_GREY", grey)
+        sc = M.Scene(g["verts"], g["faces"], ids, g["normals"], None, g["nodes"], g["indices"], mat_diffuse=mats)
+        imgs.append(sc.render(frame, W, H, 6, 3, sc.plane(), M.RNG_HASH, seed=2)[0])
+    osc = O.OracleScene(g["verts"], g["faces"], ids, g["normals"], None, g["nodes"], g["indices"], mat_diffuse=mats)
+    oimg, _, _, _ = osc.render(frame, W, H, 6, 3, osc.plane(), O.RNG_HASH, seed=2)
+    assert imgs[0].tobytes() == imgs[1].tobytes() == oimg.tobytes()
+
+
 def test_render_window_and_edge_sizes():
     sc, osc = gpu_scene("cornell_obj"), O.scene_from_golden("cornell_obj")
     plane = osc.plane()
