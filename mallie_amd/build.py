@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmallie_mgpu.so")
 LIB_OCC = os.path.join(HERE, "libmallie_mgpu_occ.so")
+LIB_LITERAL = os.path.join(HERE, "libmallie_mgpu_literal.so")
 SOURCES = ["mgpu_kernels.hip", "mgpu_render_sm.hip", "mgpu_trace_sm.hip", "mgpu_render_env.hip", "mgpu_bvh_build.hip", "mgpu_api.hip", "mgpu_frame.hip", "mgpu_stream.hip", "host/bvh_build.cc", "host/camera.cc", "host/scene_render.cc",
            "host/mesh_io.cc"]
 HEADERS = ["mgpu_device.hpp", "mgpu_kernels.hpp", "host/mesh_io.hpp", os.path.join("..", "..", "include", "mgpu.h"),
@@ -63,14 +64,17 @@ def build_variant(out_path, extra_flags):
 
 
 def build(force=False, verbose=False):
-    """libmallie_mgpu.so (the product) and libmallie_mgpu_occ.so (the same sources with -DMGPU_OCC=1: the render kernel's
-    active-lane accounting, used only by bench.py's occupancy pass -- python -m mallie_amd.occupancy), side by side."""
-    if not force and not is_stale() and os.path.exists(LIB_OCC) and os.path.getmtime(LIB_OCC) >= os.path.getmtime(LIB):
+    """libmallie_mgpu.so (the product) and, side by side, two builds of the same sources that only tests and bench.py load:
+    libmallie_mgpu_occ.so (-DMGPU_OCC=1: the render kernel's active-lane accounting, bench.py's occupancy pass) and
+    libmallie_mgpu_literal.so (-DMGPU_SAMPLE_MATH=0: SampleDiffuseIS through the literal acos / sincos calls of
+    render.cc:325-333 instead of their algebraic reduction, checked against the oracle by tests/test_gpu_parity.py)."""
+    variants = ((LIB_OCC, ["-DMGPU_OCC=1"]), (LIB_LITERAL, ["-DMGPU_SAMPLE_MATH=0"]))
+    if not force and not is_stale() and all(os.path.exists(v) and os.path.getmtime(v) >= os.path.getmtime(LIB) for v, _ in variants):
         return LIB
     srcs = [os.path.join(CSRC, f) for f in SOURCES]
     procs = [(out, subprocess.Popen([hipcc()] + FLAGS + extra + ["-o", out] + srcs, stdout=subprocess.PIPE,
                                     stderr=subprocess.STDOUT, text=True))
-             for out, extra in ((LIB + ".tmp", []), (LIB_OCC, ["-DMGPU_OCC=1"]))]
+             for out, extra in ((LIB + ".tmp", []),) + variants]
     for out, p in procs:
         log, _ = p.communicate()
         if p.returncode != 0:
@@ -78,8 +82,9 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed building %s" % out)
         if verbose:
             sys.stderr.write(log)
-    os.replace(LIB + ".tmp", LIB)  # the product library last: the variant is never newer than it is stale
-    os.utime(LIB_OCC, None)
+    os.replace(LIB + ".tmp", LIB)  # the product library last: a variant is never older than it
+    for v, _ in variants:
+        os.utime(v, None)
     return LIB
 
 

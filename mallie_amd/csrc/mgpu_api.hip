@@ -50,6 +50,7 @@ constexpr int kCounterRing = 64;
 // Scratch one render launch owns while it runs.  A slot is bound to the stream that used it last; a launch on another
 // stream takes an unused slot or re-binds the least recently used one after waiting (on the device) for its last launch.
 constexpr int kRenderSlots = 4;
+constexpr size_t kTracePinnedRays = 4096; // mgpu_trace: batches up to this size use the pinned staging
 struct RenderSlot {
   hipStream_t stream = nullptr;
   bool used = false;
@@ -101,6 +102,7 @@ struct MgpuScene {
                                     // reference calls Scene::Trace from all its OpenMP threads at once
   void *p_trace = nullptr;          // mgpu_trace: device staging of the host-buffer entry point (grow-only)
   size_t trace_cap = 0;             // rays it holds
+  void *p_trace_pinned = nullptr;   // mgpu_trace, small batches: pinned host mirror of the staging (kTracePinnedRays rays)
   void *p_host_img = nullptr;       // mgpu_render: device landing buffer of the host-buffer entry point (grow-only)
   size_t host_img_bytes = 0;
   int last_slot = 0;                // slot of the last render launch (mgpu_debug_tile_order)
@@ -460,6 +462,7 @@ int mgpu_scene_destroy(MgpuScene *s) {
                   s->p_woverflow};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
+  if (s->p_trace_pinned) (void)hipHostFree(s->p_trace_pinned);
   for (RenderSlot &r : s->slot) {
     void *rp[] = {r.p_planes, r.p_tile_cost, r.p_tile_order, r.p_overflow, r.p_woverflow};
     for (void *p : rp)
@@ -573,6 +576,37 @@ int mgpu_trace(MgpuScene *s, const MgpuRay *rays, size_t n, MgpuIntersection *ou
     rc = dev_alloc(s, (void **)&s->p_trace, cap * per_ray);
     if (rc) return rc;
     s->trace_cap = cap;
+  }
+  // Small batches -- Scene::Trace / BVHAccel::Traverse come through here ONE ray at a time -- go through a pinned mirror of
+  // the staging with two asynchronous copies and one synchronisation (records and hit flags leave the device as one block)
+  // instead of three blocking copies from / to pageable memory.
+  if (n <= kTracePinnedRays) {
+    const size_t out_bytes = sizeof(MgpuIntersection) * n, hit_bytes = (n + 15) & ~(size_t)15, ray_bytes = sizeof(MgpuRay) * n;
+    if (!s->p_trace_pinned) {
+      hipError_t e = hipHostMalloc(&s->p_trace_pinned, kTracePinnedRays * per_ray + 64, hipHostMallocDefault);
+      if (e != hipSuccess) {
+        s->p_trace_pinned = nullptr;
+        return fail(MGPU_ERR_OOM, "hipHostMalloc(trace staging): %s", hipGetErrorString(e));
+      }
+    }
+    unsigned char *dev = (unsigned char *)s->p_trace, *pin = (unsigned char *)s->p_trace_pinned;
+    MgpuIntersection *d_out_s = (MgpuIntersection *)dev;
+    uint8_t *d_hit_s = dev + out_bytes;
+    MgpuRay *d_rays_s = (MgpuRay *)(dev + out_bytes + hit_bytes); // 16-byte aligned: both sizes are multiples of 8 / 16
+    memcpy(pin + out_bytes + hit_bytes, rays, ray_bytes);
+    HIP_TRY(hipMemcpyAsync(d_rays_s, pin + out_bytes + hit_bytes, ray_bytes, hipMemcpyHostToDevice, nullptr));
+    MgpuStats dev_stats_s;
+    rc = mgpu_trace_device(s, d_rays_s, n, d_out_s, d_hit_s, nullptr, stats ? &dev_stats_s : nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(pin, dev, out_bytes + n, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    memcpy(out, pin, out_bytes);
+    memcpy(hit, pin + out_bytes, n);
+    if (stats) {
+      *stats = dev_stats_s;
+      stats->total_ms = now_ms() - t0;
+    }
+    return MGPU_OK;
   }
   MgpuIntersection *d_out = (MgpuIntersection *)s->p_trace; // 16-byte aligned (hipMalloc), records first
   MgpuRay *d_rays = (MgpuRay *)((unsigned char *)s->p_trace + s->trace_cap * sizeof(MgpuIntersection));

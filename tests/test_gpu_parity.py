@@ -490,6 +490,34 @@ def test_render_materials_and_no_matids():
             assert not np.array_equal(img[..., 0], img[..., 2])  # RGB really differ
 
 
+def test_literal_sampler_build_agrees_with_the_oracle(tmp_path):
+    """libmallie_mgpu_literal.so = the same sources with -DMGPU_SAMPLE_MATH=0: SampleDiffuseIS evaluated as written in
+    render.cc:325-333 (acos, then sin / cos of the two angles) instead of the algebraically reduced form of the product
+    build.  Radiance depends on the bounce directions only through hit / miss decisions, so both builds must give the oracle's
+    image (16-segment paths, 4 passes); run in a process of its own (one library per process)."""
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "mallie_amd", "libmallie_mgpu_literal.so")
+    assert os.path.exists(lib), "build it: python -m mallie_amd.build"
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import mallie_amd as M, oracle_lib as O\n"
+        "assert M.lib_path().endswith('libmallie_mgpu_literal.so')\n"
+        "g = O.load_golden('cornell_obj')\n"
+        "sc = M.Scene(g['verts'], g['faces'], g['matIDs'], g['normals'], None, g['nodes'], g['indices'])\n"
+        "osc = O.scene_from_golden('cornell_obj')\n"
+        "W, H = 256, 144\n"
+        "fr = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)\n"
+        "img, cnt, st = sc.render(fr, W, H, 16, 4, sc.plane(), M.RNG_HASH, seed=3)\n"
+        "oimg, _, ost, _ = osc.render(fr, W, H, 16, 4, osc.plane(), O.RNG_HASH, seed=3)\n"
+        "assert st['real_rays'] == ost['real_rays']\n"
+        "print('EQUAL' if img.tobytes() == oimg.tobytes() else 'DIFFERENT %%d' %% int((img != oimg).any(-1).sum()))\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MALLIE_MGPU_LIB=lib), timeout=300)
+    assert r.returncode == 0 and "EQUAL" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+
+
 def test_grey_and_three_channel_kernels_agree(monkeypatch):
     """Scenes whose materials all have equal diffuse channels run the GREY instantiation of k_render_sm (one channel carried,
     the result copied); MGPU_GREY=0 forces the three-channel kernel on the same scene: same bits, with explicit grey
