@@ -747,7 +747,7 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   P.pass_stride = 0;
   const size_t n_floats = 3 * (size_t)n_rows * (size_t)win_w;
   // Passes are rendered `group` at a time so that the per-pass planes stay below a fixed budget (1 GiB unless
-  // MGPU_PLANES_MAX_MB says otherwise); k_accumulate carries the running float sum from one group to the next, so the
+  // MGPU_PLANES_MAX_MB says otherwise); k_accumulate_tiled carries the running float sum from one group to the next, so the
   // additions and their order are those of a single launch.
   if (tiles >= ((uint64_t)1 << 28)) return fail(MGPU_ERR_INVALID, "window too large: %llu tiles", (unsigned long long)tiles);
   int group = passes;
@@ -878,7 +878,7 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
       launch_accumulate_tiled(st, R.p_planes, (size_t)tiles * 192, last, n_floats, win_w, d_image, d_count, passes > group);
       HIP_TRY(hipGetLastError());
     } else if (d_count) {
-      launch_accumulate(st, nullptr, 0, 1, n_floats, d_image, d_count, false); // single pass: only count[px] += 1
+      launch_count_add(st, d_count, n_floats / 3, 1); // single pass: the kernel wrote the image itself
       HIP_TRY(hipGetLastError());
     }
   }

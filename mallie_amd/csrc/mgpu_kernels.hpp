@@ -119,9 +119,8 @@ void stream_jump_matrices(uint32_t *out /* kStreamJumpBits * 128 * 4 words */);
 hipError_t launch_trace_sm(dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, uint32_t n,
                            MgpuIntersection *out, uint8_t *hit, uint32_t *counter, unsigned long long *stats,
                            const uint32_t *select);
-void launch_accumulate(hipStream_t s, const float *planes, size_t plane_stride, int passes, size_t n_floats, float *image,
-                       int32_t *count, bool resume);
-// the same for tile-major planes (k_render_sm with several passes): plane_stride = tiles * 192 floats
+void launch_count_add(hipStream_t s, int32_t *count, size_t npix, int passes); // single pass: count[px] += 1 only
+// pass accumulation from tile-major planes (k_render_sm with several passes): plane_stride = tiles * 192 floats
 void launch_accumulate_tiled(hipStream_t s, const float *planes, size_t plane_stride, int passes, size_t n_floats, int win_w,
                              float *image, int32_t *count, bool resume);
 // tile_order[0..n) = tile indices by descending cost (256 log buckets); zeroes cost[]. One workgroup.

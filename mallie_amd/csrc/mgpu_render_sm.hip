@@ -6,27 +6,31 @@
 // batch where 5.5 and 7.7 would do (lane utilisation 14 % / 19 %): rays of very different length share a wave and
 // everybody waits for the longest.  Here every lane carries an explicit state
 //
-//     NODE  : pop one BVH node, slab-test it, push children / open a leaf       (bvh_accel.cc:805-834, 550-593)
-//     TRI   : test ONE triangle of the open leaf                                 (bvh_accel.cc:595-697)
+//     NODE  : box tests.  BVH in LDS: pop up to six 64-byte nodes, slab-test each, push children / open a leaf.  BVH in HBM:
+//             enter up to three interior nodes through their 128-byte wide records (both child boxes at once, near child
+//             entered directly, far child stacked with its tmin: wide_node_step)     (bvh_accel.cc:805-834, 550-593)
+//     TRI   : test the open leaf's triangles, in leaf order; with at most 32 open leaves in the wave 2 or 4 lanes share
+//             each (shared_leaves_step)                                               (bvh_accel.cc:595-697)
 //     SHADE : finish the ray (plane, miss / bounce logic, sampling), start the next ray, path, pass or pixel
 //                                                                                (render.cc:381-456, 657-681)
 //
-// and each trip of the wave loop executes the ONE body that the most lanes are waiting for, with exactly those lanes
-// active.  A lane that finishes its ray early gets shaded and re-armed while its neighbours are still traversing, so
-// nobody waits for the longest ray any more; per-ray operation order (pop order, leaf order, RNG draws) is untouched,
-// hence results are bit-identical to k_render and to the oracle.
+// and each trip of the wave loop executes ONE body with exactly the lanes that wait for it active (the rule that picks it
+// is at the head of the loop).  A lane that finishes its ray early gets shaded and re-armed while its neighbours are still
+// traversing, so nobody waits for the longest ray any more; per-ray operation order (pop order, leaf order, RNG draws) is
+// untouched, hence results are bit-identical to k_render and to the oracle.
 //
 // Work distribution: the unit handed to a wave is one (8x8 pixel tile, pass) pair = 64 eye paths, drawn 2 or 4 at a time
 // from one of eight per-XCD counters; inside the wave, a lane whose path ends takes the next free path of the wave's
 // current item at its next SHADE step.  Items are this fine because path cost varies ~50x over the frame (sky: one
 // root-miss ray, Suzanne: five deep traversals): with a lane owning a pixel for all its passes the slowest wave ran
 // 2.2x longer than the median one and set the frame time.  The price is that a pixel's passes are no longer summed by
-// one lane, so every pass's float radiance goes to its own plane of `pass_buf` and k_accumulate adds the planes in
+// one lane, so every pass's float radiance goes to its own plane of `pass_buf` and k_accumulate_tiled adds the planes in
 // pass order afterwards -- the same float32 additions, in the same order, as Render() + AccumImage
 // (main_sdl.cc:138-143).  With passes == 1 the radiance is written straight into the image.
 //
 // Scene placement: with LDS_SCENE the whole BVH (64 B nodes + 80 B triangles) is staged once per workgroup into LDS
-// (cornellbox_suzanne: 13 KB + 78 KB) next to the traversal stacks; otherwise both are read from HBM through L1/L2.
+// (cornellbox_suzanne: 13 KB + 78 KB) next to the traversal stacks; otherwise wide records and triangles are read from HBM
+// through L1/L2 and the LDS holds the far-child stacks.
 #include <type_traits>
 #include "mgpu_device.hpp"
 #include "mgpu_kernels.hpp"
@@ -808,19 +812,17 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
 }
 
 // =====================================================================================================================
-// k_accumulate: image[px] = pass 0 + pass 1 + ... in float32, in pass order (AccumImage, main_sdl.cc:138-143); count += passes
-// `resume`: the planes hold a later group of passes and the sum continues from the image's current value.
+// Pass accumulation: image[px] = pass 0 + pass 1 + ... in float32, in pass order (AccumImage, main_sdl.cc:138-143);
+// count += passes.  `resume`: the planes hold a later group of passes and the sum continues from the image's current value.
 // =====================================================================================================================
-__global__ __launch_bounds__(256) void k_accumulate(const float *__restrict__ planes, size_t plane_stride, int passes,
-                                                     size_t n_floats, float *__restrict__ image,
-                                                     int32_t *__restrict__ count, bool resume) {
+// One pass writes the image itself; only the counters are due (count[px]++, render.cc:677-679).
+__global__ __launch_bounds__(256) void k_count_add(int32_t *__restrict__ count, size_t npix, int passes) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (planes && i < n_floats) { // planes == null: single pass already written in place, only count is due
-    float acc = resume ? image[i] : 0.f;
-    for (int p = 0; p < passes; ++p) acc += planes[(size_t)p * plane_stride + i];
-    image[i] = acc;
-  }
-  if (count && i < n_floats / 3) count[i] += passes;
+  if (i < npix) count[i] += passes;
+}
+
+void launch_count_add(hipStream_t s, int32_t *count, size_t npix, int passes) {
+  hipLaunchKernelGGL(k_count_add, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, count, npix, passes);
 }
 
 // Planes in tile-major order (what k_render_sm writes for several passes, see there): slot ((ty * tiles_x + tx) * 64 +
@@ -874,44 +876,6 @@ void launch_accumulate_tiled(hipStream_t s, const float *planes, size_t plane_st
     hipLaunchKernelGGL(k_accumulate_tiled<1>, dim3((unsigned)((plane_stride + 255) / 256)), dim3(256), 0, s, planes, plane_stride,
                        passes, (uint32_t)win_w, n_rows, tiles_x, image, count, resume);
   }
-}
-
-// The same sums four floats per thread (16-byte loads; the additions per float and their order are unchanged): for plane
-// sets whose stride and base keep every plane 16-byte aligned.  n4 = n_floats / 4 threads; the pixel counters
-// (n_floats / 3 of them) are covered by giving every thread two.
-__global__ __launch_bounds__(256) void k_accumulate4(const float4 *__restrict__ planes, size_t plane_stride4, int passes,
-                                                      size_t n4, float4 *__restrict__ image, int32_t *__restrict__ count,
-                                                      size_t npix, bool resume) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  float4 acc = resume ? image[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int p = 0; p < passes; ++p) {
-    const float4 v = planes[(size_t)p * plane_stride4 + i];
-    acc.x += v.x;
-    acc.y += v.y;
-    acc.z += v.z;
-    acc.w += v.w;
-  }
-  image[i] = acc;
-  if (count) {
-    count[i] += passes;
-    if (i + n4 < npix) count[i + n4] += passes;
-  }
-}
-
-void launch_accumulate(hipStream_t s, const float *planes, size_t plane_stride, int passes, size_t n_floats, float *image,
-                       int32_t *count, bool resume) {
-  if (planes && n_floats >= 4 && n_floats % 4 == 0 && plane_stride % 4 == 0 && ((uintptr_t)planes & 15) == 0 &&
-      ((uintptr_t)image & 15) == 0) {
-    const size_t n4 = n_floats / 4;
-    hipLaunchKernelGGL(k_accumulate4, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
-                       reinterpret_cast<const float4 *>(planes), plane_stride / 4, passes, n4,
-                       reinterpret_cast<float4 *>(image), count, n_floats / 3, resume);
-    return;
-  }
-  const unsigned blocks = (unsigned)((n_floats + 255) / 256);
-  hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(256), 0, s, planes, plane_stride, passes, n_floats, image, count,
-                     resume);
 }
 
 // =====================================================================================================================
