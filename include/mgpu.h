@@ -187,13 +187,25 @@ int mgpu_render_strips_device(MgpuScene *scene, const double frame[12], int W, i
                               int strip_h, int y_period, int n_rows, int maxPathLength, int passes,
                               const float plane[4], int rng_mode, const uint32_t *d_rng_states, uint64_t seed,
                               uint32_t pass_base, float *d_image, int32_t *d_count, void *stream, MgpuStats *stats);
+/* n_frames consecutive frames of the same window in one call: frame f renders passes pass_base + f * passes ... into
+ * d_images[f] (and d_counts[f]; d_counts may be NULL) -- bit for bit what n_frames calls of mgpu_render_strips_device with
+ * pass_base advancing by `passes` produce.  As many frames as the scratch budget holds (1 GiB of per-pass planes unless
+ * MGPU_PLANES_MAX_MB says otherwise) share ONE persistent launch, so the end of a launch -- waves running out of work one
+ * after the other -- is paid once per launch and not once per frame: rank 0's eighth of the 1080p Cornell frame takes 1.16
+ * ms alone and 0.83 ms as one of four.  MGPU_RNG_TABLE: d_rng_states holds n_frames * passes tables, frame-major.  `stats`
+ * (if not NULL) covers all frames; kernel_ms then includes the per-frame sums of the planes. */
+int mgpu_render_frames_device(MgpuScene *scene, const double frame[12], int W, int H, int x0, int x1, int y_first,
+                              int strip_h, int y_period, int n_rows, int maxPathLength, int passes,
+                              const float plane[4], int rng_mode, const uint32_t *d_rng_states, uint64_t seed,
+                              uint32_t pass_base, int n_frames, float *const *d_images, int32_t *const *d_counts,
+                              void *stream, MgpuStats *stats);
 
 /* -- Multi-GPU frames: the image is cut into interleaved strips of `strip_h` rows, rank r owns strips
  *    r, r + world, ...; the scene is replicated (one MgpuScene per GPU, created by the caller with mgpu_scene_create on
  *    that device); every GPU renders its strips (Render() semantics, MGPU_RNG_HASH seeding, so the frame does not depend on
  *    the GPU count) and ONE exchange step per frame -- grouped ncclSend / ncclRecv over RCCL / xGMI, each strip received
  *    at its final rows -- assembles the float RGB frame in rank 0's HBM.  RCCL is loaded on first use (dlopen), and not
- *    at all for one GPU.  Up to 4 frames may be in flight (own streams and buffers each): mgpu_frame_render only
+ *    at all for one GPU.  Up to 8 frames may be in flight (own streams and buffers each): mgpu_frame_render only
  *    enqueues, mgpu_frame_wait blocks until a slot's frame is complete. -------------------------------------------------- */
 typedef struct MgpuFrame MgpuFrame;
 /* One process driving n GPUs (ncclCommInitAll): scenes[r] lives on devices[r] and becomes rank r. */
@@ -209,6 +221,11 @@ int mgpu_frame_destroy(MgpuFrame *frame);
  * the next slot and returns that slot's index.  Collective across the ranks of a multi-process frame. */
 int mgpu_frame_render(MgpuFrame *frame, const double cam[12], int maxPathLength, int passes, const float plane[4],
                       int rng_mode, uint64_t seed, uint32_t pass_base, int *slot_out);
+/* n_frames (<= frames_in_flight) consecutive frames -- frame i renders passes pass_base + i * passes ... -- rendered by ONE
+ * launch per GPU (mgpu_render_frames_device) and exchanged frame by frame; slots_out[i] (may be NULL) receives frame i's
+ * slot.  Same frames as n_frames calls of mgpu_frame_render.  Collective like it. */
+int mgpu_frame_render_batch(MgpuFrame *frame, const double cam[12], int maxPathLength, int passes, const float plane[4],
+                            int rng_mode, uint64_t seed, uint32_t pass_base, int n_frames, int *slots_out);
 /* Waits for the frame of `slot`.  On the process that holds rank 0: *device_image (nullable) receives the device pointer
  * of the H x W x 3 float frame (valid until the slot is used again), host_image (nullable) a copy of it. */
 int mgpu_frame_wait(MgpuFrame *frame, int slot, float *host_image, float **device_image);

@@ -5,6 +5,7 @@
 // the gfx950 kernels of mgpu_kernels.hip.  There is no CPU execution path here: without a HIP device every call fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -640,11 +641,20 @@ int mgpu_trace(MgpuScene *s, const MgpuRay *rays, size_t n, MgpuIntersection *ou
 #undef TRY_T
 }
 
-int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H, int x0, int x1, int y_first,
-                              int strip_h, int y_period, int n_rows, int maxPathLength, int passes,
-                              const float plane[4], int rng_mode, const uint32_t *d_rng_states, uint64_t seed,
-                              uint32_t pass_base, float *d_image, int32_t *d_count, void *stream, MgpuStats *stats) {
-  if (!s || !frame || !d_image) return fail(MGPU_ERR_INVALID, "scene/frame/d_image must be non-NULL");
+} // extern "C"
+
+// n_frames consecutive frames of `passes` passes each (frame f: passes pass_base + f * passes ...) into d_images[f] /
+// d_counts[f].  With several frames the passes of as many frames as the plane budget holds go into ONE persistent launch
+// (the kernel sees n * passes passes; every frame's planes are then summed into its own image): the end of a launch, where
+// waves run out of work one by one, is paid once per launch instead of once per frame -- what matters when a GPU renders
+// an eighth of a frame.  The images are those of n single-frame calls, bit for bit.
+static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H, int x0, int x1, int y_first, int strip_h,
+                              int y_period, int n_rows, int maxPathLength, int passes, const float plane[4], int rng_mode,
+                              const uint32_t *d_rng_states, uint64_t seed, uint32_t pass_base, int n_frames,
+                              float *const *d_images, int32_t *const *d_counts, void *stream, MgpuStats *stats) {
+  if (!s || !frame || !d_images || n_frames < 1) return fail(MGPU_ERR_INVALID, "scene/frame/images must be non-NULL, n_frames >= 1");
+  for (int f = 0; f < n_frames; ++f)
+    if (!d_images[f]) return fail(MGPU_ERR_INVALID, "image %d is NULL", f);
   const int pstep = s ? s->pix_step : 1; // > 1: the window is given in step x step blocks of the W x H frame
   if (W <= 0 || H <= 0 || x0 < 0 || (long long)x1 * pstep > W || x0 > x1) return fail(MGPU_ERR_INVALID, "bad window columns");
   if (strip_h <= 0 || y_period < strip_h || n_rows < 0 || y_first < 0) return fail(MGPU_ERR_INVALID, "bad strip layout");
@@ -741,9 +751,9 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   P.rng_states = d_rng_states;
   P.seed = seed;
   P.pass_base = pass_base;
-  P.image = d_image;
-  P.count = d_count;
-  P.out = d_image;
+  P.image = d_images[0];
+  P.count = d_counts ? d_counts[0] : nullptr;
+  P.out = d_images[0];
   P.pass_stride = 0;
   const size_t n_floats = 3 * (size_t)n_rows * (size_t)win_w;
   // Passes are rendered `group` at a time so that the per-pass planes stay below a fixed budget (1 GiB unless
@@ -751,6 +761,7 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
   // additions and their order are those of a single launch.
   if (tiles >= ((uint64_t)1 << 28)) return fail(MGPU_ERR_INVALID, "window too large: %llu tiles", (unsigned long long)tiles);
   int group = passes;
+  int fpl = 1; // frames per launch
   if (kern != 0 && passes > 1) {
     size_t budget = (size_t)1 << 30;
     if (const char *e = getenv("MGPU_PLANES_MAX_MB")) budget = (size_t)(atoll(e) < 1 ? 1 : atoll(e)) << 20;
@@ -759,7 +770,12 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
     if ((size_t)group > fit) group = fit < 1 ? 1 : (int)fit;
     // the work cursor addresses (tile, pass) items with 28 bits per XCD part
     while (group > 1 && tiles * (uint64_t)group >= ((uint64_t)1 << 28)) group = (group + 1) / 2;
-    const size_t need = plane_floats * (size_t)group;
+    if (n_frames > 1 && group == passes && fit >= 2 * (size_t)passes) { // whole frames share a launch
+      fpl = (int)std::min<size_t>((size_t)n_frames, fit / (size_t)passes);
+      if (const char *e = getenv("MGPU_FRAMES_PER_LAUNCH")) fpl = std::max(1, std::min(fpl, atoi(e)));
+      while (fpl > 1 && tiles * (uint64_t)fpl * (uint64_t)passes >= ((uint64_t)1 << 28)) --fpl;
+    }
+    const size_t need = plane_floats * (size_t)group * (size_t)fpl;
     if (need > R.planes_floats) {
       if (R.p_planes) {
         HIP_TRY(hipDeviceSynchronize());
@@ -813,10 +829,13 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
       R.order_age = 0;
     }
     P.tile_order = R.p_tile_order;
-    // The order is renewed on the first two launches of a layout (image order, then the first measured costs) and every
-    // fourth launch after that (MGPU_TILE_ORDER_EVERY): a frame's costs change slowly, and the sort is one workgroup's work
-    // (35 us at 1080p) in front of the launch.  Costs are recorded only by the launch right before a renewal, so the
-    // table always holds ONE launch's costs (no sums that could wrap) and the other launches skip the atomics.
+  }
+  // The order is renewed on the first two launches of a layout (image order, then the first measured costs) and every
+  // fourth launch after that (MGPU_TILE_ORDER_EVERY): a frame's costs change slowly, and the sort is one workgroup's work
+  // (35 us at 1080p) in front of the launch.  Costs are recorded only by the launch right before a renewal, so the
+  // table always holds ONE launch's costs (no sums that could wrap) and the other launches skip the atomics.
+  auto order_for_next_launch = [&]() -> int {
+    if (!use_order) return MGPU_OK;
     const unsigned every = s->tile_order_every;
     auto renews = [&](unsigned age) { return age < 2 || age % every == 0; };
     if (renews(R.order_age)) {
@@ -825,6 +844,11 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
     }
     P.tile_cost = renews(R.order_age + 1) ? R.p_tile_cost : nullptr;
     ++R.order_age;
+    return MGPU_OK;
+  };
+  if (n_frames == 1) { // (several frames: once per launch, below)
+    rc = order_for_next_launch();
+    if (rc) return rc;
   }
   if (stats) {
     HIP_TRY(hipMemsetAsync(s->p_stats, 0, sizeof(unsigned long long) * kStatWords, st));
@@ -845,16 +869,11 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
     s->t_used += 2;
     HIP_TRY(hipEventRecord(tev0, st));
   }
-  for (int g0 = 0; g0 < passes; g0 += group) {
-    if (use_order && g0 > 0) {
-      launch_order_tiles(st, R.p_tile_cost, (uint32_t)tiles, R.p_tile_order);
-      HIP_TRY(hipGetLastError());
-    }
-    const int g = passes - g0 < group ? passes - g0 : group;
-    P.passes = g;
-    P.pass_base = pass_base + (uint32_t)g0;
-    P.rng_states = d_rng_states ? d_rng_states + (size_t)g0 * (size_t)W * (size_t)H * 4 : nullptr;
-    P.probe_pass = s->probe_pass - (uint32_t)g0; // wraps out of range for passes of other groups
+  auto launch_passes = [&](int n_passes, uint32_t first_pass) -> int { // one launch of the render kernel: passes first_pass ...
+    P.passes = n_passes;
+    P.pass_base = pass_base + first_pass;
+    P.rng_states = d_rng_states ? d_rng_states + (size_t)first_pass * (size_t)W * (size_t)H * 4 : nullptr;
+    P.probe_pass = s->probe_pass - first_pass; // wraps out of range for passes of other launches
     P.work_counter = s->p_counters + (size_t)(s->launch_seq++ % kCounterRing) * kShards;
     HIP_TRY(hipMemsetAsync(P.work_counter, 0, sizeof(uint32_t) * kShards, st));
     if (kern == 0) {
@@ -863,16 +882,11 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
     } else {
       HIP_TRY(launch_render_sm(s->cap, kern == 2, block, dim3((unsigned)blocks), st, shmem, dsc, P));
     }
-    if (g0 + g < passes) { // not the last group: fold it into the image now, the planes are reused
-      launch_accumulate_tiled(st, R.p_planes, (size_t)tiles * 192, g, n_floats, win_w, d_image, d_count, g0 > 0);
-      HIP_TRY(hipGetLastError());
-    }
-  }
-  // kernel_ms / the timing ring measure the dominant kernel alone (k_render or k_render_sm) when the passes fit one
-  // group (the benchmarked case); with several groups the interleaved partial sums are inside the bracket
-  if (tev1) HIP_TRY(hipEventRecord(tev1, st));
-  if (stats) HIP_TRY(hipEventRecord(s->ev1, st));
-  if (kern != 0) {
+    return MGPU_OK;
+  };
+  // what closes a frame rendered by launches of its own: the last group's planes into the image
+  auto close_frame = [&](float *d_image, int32_t *d_count) -> int {
+    if (kern == 0) return MGPU_OK;
     if (passes > 1) {
       const int last = passes - ((passes - 1) / group) * group;
       launch_accumulate_tiled(st, R.p_planes, (size_t)tiles * 192, last, n_floats, win_w, d_image, d_count, passes > group);
@@ -881,6 +895,57 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
       launch_count_add(st, d_count, n_floats / 3, 1); // single pass: the kernel wrote the image itself
       HIP_TRY(hipGetLastError());
     }
+    return MGPU_OK;
+  };
+  for (int f0 = 0; f0 < n_frames; f0 += fpl) {
+    const int nf = std::min(fpl, n_frames - f0);
+    if (nf > 1) { // the passes of nf frames in one launch, then every frame's planes into its image
+      rc = order_for_next_launch();
+      if (rc) return rc;
+      rc = launch_passes(nf * passes, (uint32_t)f0 * (uint32_t)passes);
+      if (rc) return rc;
+      for (int i = 0; i < nf; ++i) {
+        launch_accumulate_tiled(st, R.p_planes + (size_t)i * (size_t)passes * ((size_t)tiles * 192), (size_t)tiles * 192, passes, n_floats,
+                                win_w, d_images[f0 + i], d_counts ? d_counts[f0 + i] : nullptr, false);
+        HIP_TRY(hipGetLastError());
+      }
+      continue;
+    }
+    float *const d_image = d_images[f0];
+    int32_t *const d_count = d_counts ? d_counts[f0] : nullptr;
+    P.image = d_image;
+    P.count = d_count;
+    if (!P.pass_stride) P.out = d_image; // single pass: the kernel writes the image itself
+    if (n_frames > 1) {
+      rc = order_for_next_launch();
+      if (rc) return rc;
+    }
+    for (int g0 = 0; g0 < passes; g0 += group) {
+      if (use_order && g0 > 0) {
+        launch_order_tiles(st, R.p_tile_cost, (uint32_t)tiles, R.p_tile_order);
+        HIP_TRY(hipGetLastError());
+      }
+      const int g = passes - g0 < group ? passes - g0 : group;
+      rc = launch_passes(g, (uint32_t)f0 * (uint32_t)passes + (uint32_t)g0);
+      if (rc) return rc;
+      if (g0 + g < passes) { // not the last group: fold it into the image now, the planes are reused
+        launch_accumulate_tiled(st, R.p_planes, (size_t)tiles * 192, g, n_floats, win_w, d_image, d_count, g0 > 0);
+        HIP_TRY(hipGetLastError());
+      }
+    }
+    if (n_frames > 1) {
+      rc = close_frame(d_image, d_count);
+      if (rc) return rc;
+    }
+  }
+  // kernel_ms / the timing ring measure the dominant kernel alone (k_render or k_render_sm) when ONE frame is rendered and
+  // its passes fit one group (the benchmarked case); with several groups the interleaved partial sums are inside the
+  // bracket, with several frames their per-frame sums as well
+  if (tev1) HIP_TRY(hipEventRecord(tev1, st));
+  if (stats) HIP_TRY(hipEventRecord(s->ev1, st));
+  if (n_frames == 1) {
+    rc = close_frame(d_images[0], d_counts ? d_counts[0] : nullptr);
+    if (rc) return rc;
   }
   HIP_TRY(hipEventRecord(R.done, st));
   if (stats) {
@@ -894,6 +959,27 @@ int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H
     stats->total_ms = now_ms() - t0;
   }
   return MGPU_OK;
+}
+
+extern "C" {
+
+int mgpu_render_strips_device(MgpuScene *s, const double frame[12], int W, int H, int x0, int x1, int y_first,
+                              int strip_h, int y_period, int n_rows, int maxPathLength, int passes,
+                              const float plane[4], int rng_mode, const uint32_t *d_rng_states, uint64_t seed,
+                              uint32_t pass_base, float *d_image, int32_t *d_count, void *stream, MgpuStats *stats) {
+  if (!d_image) return fail(MGPU_ERR_INVALID, "scene/frame/d_image must be non-NULL");
+  float *const images[1] = {d_image};
+  int32_t *const counts[1] = {d_count};
+  return render_frames_impl(s, frame, W, H, x0, x1, y_first, strip_h, y_period, n_rows, maxPathLength, passes, plane, rng_mode,
+                            d_rng_states, seed, pass_base, 1, images, d_count ? counts : nullptr, stream, stats);
+}
+
+int mgpu_render_frames_device(MgpuScene *s, const double frame[12], int W, int H, int x0, int x1, int y_first, int strip_h,
+                              int y_period, int n_rows, int maxPathLength, int passes, const float plane[4], int rng_mode,
+                              const uint32_t *d_rng_states, uint64_t seed, uint32_t pass_base, int n_frames,
+                              float *const *d_images, int32_t *const *d_counts, void *stream, MgpuStats *stats) {
+  return render_frames_impl(s, frame, W, H, x0, x1, y_first, strip_h, y_period, n_rows, maxPathLength, passes, plane, rng_mode,
+                            d_rng_states, seed, pass_base, n_frames, d_images, d_counts, stream, stats);
 }
 
 int mgpu_render(MgpuScene *s, const double origin[3], const double corner[3], const double du[3], const double dv[3],

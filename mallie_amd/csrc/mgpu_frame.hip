@@ -87,7 +87,7 @@ int load_rccl() {
     if (r_ != ncclSuccess) return ffail(MGPU_ERR_HIP, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
   } while (0)
 
-constexpr int kMaxInFlight = 4;
+constexpr int kMaxInFlight = 8;
 
 // what one device keeps for one frame in flight
 struct Slot {
@@ -297,65 +297,84 @@ int mgpu_frame_create_rank(MgpuScene *scene, int device, int rank, int world, co
   return MGPU_OK;
 }
 
-// One frame: every member renders its strips on the slot's stream; then, on the communicator streams, the strips travel
-// to rank 0's frame (grouped send / recv, one pair per strip, received at the strip's final rows); rank 0's own strips
-// are placed by one strided device copy.
-int mgpu_frame_render(MgpuFrame *f, const double cam[12], int maxPathLength, int passes, const float plane[4], int rng_mode,
-                      uint64_t seed, uint32_t pass_base, int *slot_out) {
+// n frames (n = 1: mgpu_frame_render): every member renders its strips of all n frames with ONE launch on the first slot's
+// stream; then, on the communicator streams and frame by frame, the strips travel to rank 0's frame (grouped send / recv,
+// one pair per strip, received at the strip's final rows); rank 0's own strips are placed by one strided device copy.
+static int render_frames(MgpuFrame *f, const double cam[12], int maxPathLength, int passes, const float plane[4], int rng_mode,
+                         uint64_t seed, uint32_t pass_base, int n, int *slots_out) {
   if (!f || !cam) return ffail(MGPU_ERR_INVALID, "NULL argument");
-  const int k = (int)(f->next % (unsigned long long)f->in_flight);
+  if (n < 1 || n > f->in_flight) return ffail(MGPU_ERR_INVALID, "n_frames must be 1..frames_in_flight (%d)", f->in_flight);
+  int ks[kMaxInFlight];
+  for (int i = 0; i < n; ++i) ks[i] = (int)((f->next + (unsigned long long)i) % (unsigned long long)f->in_flight);
   const int W = f->W, H = f->H, sh = f->strip_h, world = f->world;
   const size_t strip_floats = (size_t)3 * sh * W;
   const bool exchange = world > 1 || f->force_exchange;
   for (Member &m : f->members) {
     FHIP(hipSetDevice(m.device));
-    Slot &s = m.slot[k];
-    // the slot's previous frame must have left its buffers: its exchange is the last thing that touched them
-    FHIP(hipStreamWaitEvent(s.stream, s.exchanged, 0));
+    hipStream_t rs = m.slot[ks[0]].stream; // the launch and the copies of the whole batch
+    // the slots' previous frames must have left their buffers: their exchange is the last thing that touched them
+    for (int i = 0; i < n; ++i) FHIP(hipStreamWaitEvent(rs, m.slot[ks[i]].exchanged, 0));
     if (m.n_rows) {
-      int rc = mgpu_render_strips_device(m.scene, cam, W, H, 0, W, m.rank * sh, sh, sh * world, m.n_rows, maxPathLength, passes,
-                                         plane, rng_mode, nullptr, seed, pass_base, s.local, nullptr, s.stream, nullptr);
+      float *images[kMaxInFlight];
+      for (int i = 0; i < n; ++i) images[i] = m.slot[ks[i]].local;
+      int rc = mgpu_render_frames_device(m.scene, cam, W, H, 0, W, m.rank * sh, sh, sh * world, m.n_rows, maxPathLength, passes, plane,
+                                         rng_mode, nullptr, seed, pass_base, n, images, nullptr, rs, nullptr);
       if (rc) return ffail(rc, "rank %d: %s", m.rank, mgpu_last_error());
     }
-    if (m.rank == 0 && m.n_rows && !f->force_exchange) {
-      // own strips to their final rows: local strip j -> frame rows [j * world * sh, +sh); the last one may be partial
-      const int full = m.n_rows / sh, tail = m.n_rows - full * sh;
-      if (full)
-        FHIP(hipMemcpy2DAsync(s.frame, sizeof(float) * strip_floats * world, s.local, sizeof(float) * strip_floats,
-                              sizeof(float) * strip_floats, (size_t)full, hipMemcpyDeviceToDevice, s.stream));
-      if (tail)
-        FHIP(hipMemcpyAsync(s.frame + (size_t)full * world * strip_floats, s.local + (size_t)full * strip_floats,
-                            sizeof(float) * 3 * (size_t)tail * W, hipMemcpyDeviceToDevice, s.stream));
-    }
-    FHIP(hipEventRecord(s.rendered, s.stream));
-    if (exchange) FHIP(hipStreamWaitEvent(m.comm_stream, s.rendered, 0));
-  }
-  if (exchange) {
-    FNCCL(g_rccl.GroupStart());
-    for (Member &m : f->members) {
-      Slot &s = m.slot[k];
-      std::vector<Piece> plan;
-      if (m.rank != 0 || f->force_exchange) { // sends: this rank's strips, in strip order
-        plan_of(W, H, sh, world, m.rank, plan);
-        for (const Piece &p : plan) FNCCL(g_rccl.Send(s.local + p.local_off, p.count, ncclFloat, 0, m.comm, m.comm_stream));
+    for (int i = 0; i < n; ++i) {
+      Slot &s = m.slot[ks[i]];
+      if (m.rank == 0 && m.n_rows && !f->force_exchange) {
+        // own strips to their final rows: local strip j -> frame rows [j * world * sh, +sh); the last one may be partial
+        const int full = m.n_rows / sh, tail = m.n_rows - full * sh;
+        if (full)
+          FHIP(hipMemcpy2DAsync(s.frame, sizeof(float) * strip_floats * world, s.local, sizeof(float) * strip_floats,
+                                sizeof(float) * strip_floats, (size_t)full, hipMemcpyDeviceToDevice, rs));
+        if (tail)
+          FHIP(hipMemcpyAsync(s.frame + (size_t)full * world * strip_floats, s.local + (size_t)full * strip_floats,
+                              sizeof(float) * 3 * (size_t)tail * W, hipMemcpyDeviceToDevice, rs));
       }
-      if (m.rank == 0) { // receives: every other rank's strips (its own too when the exchange is forced), at their final rows
-        for (int r = f->force_exchange ? 0 : 1; r < world; ++r) {
-          plan_of(W, H, sh, world, r, plan);
-          for (const Piece &p : plan) FNCCL(g_rccl.Recv(s.frame + p.frame_off, p.count, ncclFloat, r, m.comm, m.comm_stream));
+      FHIP(hipEventRecord(s.rendered, rs));
+    }
+    if (exchange) FHIP(hipStreamWaitEvent(m.comm_stream, m.slot[ks[n - 1]].rendered, 0));
+  }
+  for (int i = 0; i < n; ++i) {
+    const int k = ks[i];
+    if (exchange) {
+      FNCCL(g_rccl.GroupStart());
+      for (Member &m : f->members) {
+        Slot &s = m.slot[k];
+        std::vector<Piece> plan;
+        if (m.rank != 0 || f->force_exchange) { // sends: this rank's strips, in strip order
+          plan_of(W, H, sh, world, m.rank, plan);
+          for (const Piece &p : plan) FNCCL(g_rccl.Send(s.local + p.local_off, p.count, ncclFloat, 0, m.comm, m.comm_stream));
+        }
+        if (m.rank == 0) { // receives: every other rank's strips (its own too when the exchange is forced), at their final rows
+          for (int r = f->force_exchange ? 0 : 1; r < world; ++r) {
+            plan_of(W, H, sh, world, r, plan);
+            for (const Piece &p : plan) FNCCL(g_rccl.Recv(s.frame + p.frame_off, p.count, ncclFloat, r, m.comm, m.comm_stream));
+          }
         }
       }
+      FNCCL(g_rccl.GroupEnd());
     }
-    FNCCL(g_rccl.GroupEnd());
+    for (Member &m : f->members) {
+      FHIP(hipSetDevice(m.device));
+      FHIP(hipEventRecord(m.slot[k].exchanged, exchange ? m.comm_stream : m.slot[ks[0]].stream));
+    }
+    if (slots_out) slots_out[i] = k;
   }
-  for (Member &m : f->members) {
-    FHIP(hipSetDevice(m.device));
-    Slot &s = m.slot[k];
-    FHIP(hipEventRecord(s.exchanged, exchange ? m.comm_stream : s.stream));
-  }
-  if (slot_out) *slot_out = k;
-  ++f->next;
+  f->next += (unsigned long long)n;
   return MGPU_OK;
+}
+
+int mgpu_frame_render(MgpuFrame *f, const double cam[12], int maxPathLength, int passes, const float plane[4], int rng_mode,
+                      uint64_t seed, uint32_t pass_base, int *slot_out) {
+  return render_frames(f, cam, maxPathLength, passes, plane, rng_mode, seed, pass_base, 1, slot_out);
+}
+
+int mgpu_frame_render_batch(MgpuFrame *f, const double cam[12], int maxPathLength, int passes, const float plane[4], int rng_mode,
+                            uint64_t seed, uint32_t pass_base, int n_frames, int *slots_out) {
+  return render_frames(f, cam, maxPathLength, passes, plane, rng_mode, seed, pass_base, n_frames, slots_out);
 }
 
 int mgpu_frame_wait(MgpuFrame *f, int slot, float *host_image, float **device_image) {

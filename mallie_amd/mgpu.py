@@ -80,6 +80,9 @@ def load_library():
     L.mgpu_render_strips_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, u64,
                                             u32, vp, vp, vp, vp]
     L.mgpu_render_strips_device.restype = i32
+    L.mgpu_render_frames_device.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, u64,
+                                            u32, i32, vp, vp, vp, vp]
+    L.mgpu_render_frames_device.restype = i32
     L.mgpu_hash_state.argtypes = [u64, u32, u32, vp]
     L.mgpu_stats_read.argtypes = [vp, vp, i32]
     L.mgpu_stats_read.restype = i32
@@ -101,6 +104,8 @@ def load_library():
     L.mgpu_frame_destroy.restype = i32
     L.mgpu_frame_render.argtypes = [vp, vp, i32, i32, vp, i32, u64, u32, C.POINTER(i32)]
     L.mgpu_frame_render.restype = i32
+    L.mgpu_frame_render_batch.argtypes = [vp, vp, i32, i32, vp, i32, u64, u32, i32, vp]
+    L.mgpu_frame_render_batch.restype = i32
     L.mgpu_frame_wait.argtypes = [vp, i32, vp, C.POINTER(vp)]
     L.mgpu_frame_wait.restype = i32
     L.mgpu_frame_done_event_wait.argtypes = [vp, i32, vp]
@@ -299,6 +304,17 @@ class Frame:
         if rc:
             raise MgpuError(rc, "mgpu_frame_render", L.mgpu_frame_last_error().decode())
         return slot.value
+
+    def render_batch(self, cam, maxPathLength, passes, n_frames, plane=None, seed=1, pass_base=0, rng_mode=RNG_HASH):
+        """mgpu_frame_render_batch: n_frames consecutive frames (frame i: passes pass_base + i * passes ...) rendered by one
+        launch per GPU; returns their slots."""
+        L = load_library()
+        slots = (C.c_int32 * n_frames)()
+        rc = L.mgpu_frame_render_batch(self.h, _p(_c(cam, "<f8")), maxPathLength, passes, _p(_c(plane, "<f4")), rng_mode, seed,
+                                       pass_base, n_frames, slots)
+        if rc != 0:
+            raise MgpuError(rc, "mgpu_frame_render_batch", L.mgpu_frame_last_error().decode())
+        return list(slots)
 
     def wait(self, slot, to_host=False):
         """Blocks until the slot's frame is complete. Returns the device pointer of rank 0's frame (0 on other ranks), or a
@@ -535,4 +551,24 @@ class Scene:
             self.h, _p(frame), W, H, x0, x1, y_first, strip_h, y_period, n_rows, maxPathLength, passes, _p(plane),
             rng_mode, d_rng_states_ptr, seed, pass_base, d_image_ptr, d_count_ptr, stream,
             C.byref(st) if st is not None else None), "mgpu_render_strips_device")
+        return st.as_dict() if st is not None else None
+
+    def render_frames_device(self, frame, W, H, d_image_ptrs, n_rows, x0=0, x1=None, y_first=0, strip_h=None, y_period=None,
+                             maxPathLength=16, passes=1, plane=None, rng_mode=RNG_HASH, d_rng_states_ptr=None, seed=1,
+                             pass_base=0, d_count_ptrs=None, stream=None, want_stats=False):
+        """mgpu_render_frames_device: len(d_image_ptrs) consecutive frames of `passes` passes each, as many of them per
+        launch as the scratch budget holds; frame f renders passes pass_base + f * passes ... into d_image_ptrs[f]."""
+        frame = _c(frame, "<f8")
+        x1 = W if x1 is None else x1
+        strip_h = n_rows if strip_h is None else strip_h
+        y_period = strip_h if y_period is None else y_period
+        plane = _c(plane, "<f4")
+        n = len(d_image_ptrs)
+        images = (C.c_void_p * n)(*d_image_ptrs)
+        counts = (C.c_void_p * n)(*d_count_ptrs) if d_count_ptrs is not None else None
+        st = Stats() if want_stats else None
+        _check(load_library().mgpu_render_frames_device(
+            self.h, _p(frame), W, H, x0, x1, y_first, strip_h, y_period, n_rows, maxPathLength, passes, _p(plane),
+            rng_mode, d_rng_states_ptr, seed, pass_base, n, images, counts, stream,
+            C.byref(st) if st is not None else None), "mgpu_render_frames_device")
         return st.as_dict() if st is not None else None

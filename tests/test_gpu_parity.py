@@ -976,6 +976,81 @@ def test_c_abi_frame_on_one_gpu(force, monkeypatch):
     fr.close()
 
 
+@pytest.mark.parametrize("scene_name,budget_mb", [("cornell_obj", None), ("cornell_obj", "1"), ("teapot_obj", None)])
+def test_frames_per_launch_equal_single_frames(scene_name, budget_mb, monkeypatch):
+    """mgpu_render_frames_device: n consecutive frames in one call -- as many per launch as the plane budget holds (all five
+    by default; with a 1 MB budget two, two and one through the plain path) -- are the frames of n single calls with the pass
+    base moving on, byte for byte, images and counts, on an interleaved strip layout; LDS-resident and HBM-resident scene.
+    Repeated: the second round runs with the cost order the first one measured."""
+    import torch
+    if budget_mb:
+        monkeypatch.setenv("MGPU_PLANES_MAX_MB", budget_mb)
+    sc = gpu_scene(scene_name)
+    eye, look = ((0.0, 40.0, 250.0), (0.0, 40.0, 0.0)) if scene_name == "teapot_obj" else ((0, 0, 20), (0, 0, 0))
+    W, H, mpl, passes, n = 200, 150, 5, 3, 5
+    cam = M.camera_frame(eye, look, width=W, height=H)
+    plane = sc.plane()
+    rows = M.frame_rows(H, 8, 2, 1)  # rank 1 of 2: strips 1, 3, ... the last one partial
+    kw = dict(y_first=8, strip_h=8, y_period=16, maxPathLength=mpl, passes=passes, plane=plane, seed=11)
+    refs, rcnt = [], []
+    for k in range(n):
+        img = torch.full((rows, W, 3), float("nan"), dtype=torch.float32, device="cuda")
+        cnt = torch.full((rows, W), 7 + k, dtype=torch.int32, device="cuda")
+        sc.render_strips_device(cam, W, H, img.data_ptr(), rows, pass_base=k * passes, d_count_ptr=cnt.data_ptr(), **kw)
+        refs.append(img.cpu().numpy())
+        rcnt.append(cnt.cpu().numpy())
+    assert refs[0].tobytes() != refs[1].tobytes()
+    for rep in range(2):
+        imgs = [torch.full((rows, W, 3), float("nan"), dtype=torch.float32, device="cuda") for _ in range(n)]
+        cnts = [torch.full((rows, W), 7 + k, dtype=torch.int32, device="cuda") for k in range(n)]
+        st = sc.render_frames_device(cam, W, H, [t.data_ptr() for t in imgs], rows, pass_base=0,
+                                     d_count_ptrs=[t.data_ptr() for t in cnts], want_stats=(rep == 1), **kw)
+        torch.cuda.synchronize()
+        for k in range(n):
+            assert imgs[k].cpu().numpy().tobytes() == refs[k].tobytes(), (rep, k)
+            assert cnts[k].cpu().numpy().tobytes() == rcnt[k].tobytes(), (rep, k)
+        if st is not None:
+            assert st["paths"] == n * passes * rows * W
+    # one pass per frame: the kernel writes every image itself, no planes
+    kw["passes"] = 1
+    imgs = [torch.full((rows, W, 3), float("nan"), dtype=torch.float32, device="cuda") for _ in range(3)]
+    sc.render_frames_device(cam, W, H, [t.data_ptr() for t in imgs], rows, pass_base=2, **kw)
+    for k in range(3):
+        ref = torch.empty((rows, W, 3), dtype=torch.float32, device="cuda")
+        sc.render_strips_device(cam, W, H, ref.data_ptr(), rows, pass_base=2 + k, **kw)
+        assert imgs[k].cpu().numpy().tobytes() == ref.cpu().numpy().tobytes(), k
+
+
+@pytest.mark.parametrize("force", [0, 1])
+def test_c_abi_frame_batches_on_one_gpu(force, monkeypatch):
+    """mgpu_frame_render_batch: three frames by one launch (then two more, wrapping round the six slots, then a single
+    frame) through the plain path and through the forced RCCL exchange; every frame equals the single-launch frame of its
+    passes.  A batch larger than frames_in_flight is refused."""
+    import torch
+    if force:
+        monkeypatch.setenv("MGPU_FRAME_FORCE_EXCHANGE", "1")
+    sc = gpu_scene("cornell_obj")
+    W, H, mpl, passes = 320, 203, 5, 3
+    cam = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    plane = sc.plane()
+    fr = M.Frame([sc], [0], W, H, strip_h=8, frames_in_flight=6)
+    with pytest.raises(M.MgpuError):
+        fr.render_batch(cam, mpl, passes, 7, plane, seed=7)
+    slots = fr.render_batch(cam, mpl, passes, 3, plane, seed=7, pass_base=0)
+    slots += fr.render_batch(cam, mpl, passes, 2, plane, seed=7, pass_base=3 * passes)
+    slots.append(fr.render(cam, mpl, passes, plane, seed=7, pass_base=5 * passes))
+    assert sorted(slots) == [0, 1, 2, 3, 4, 5]
+    frames = [fr.wait(s, to_host=True) for s in slots]
+    slots2 = fr.render_batch(cam, mpl, passes, 4, plane, seed=7, pass_base=6 * passes)  # slots come round again
+    frames += [fr.wait(s, to_host=True) for s in slots2]
+    for k, img in enumerate(frames):
+        ref = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        sc.render_strips_device(cam, W, H, ref.data_ptr(), H, maxPathLength=mpl, passes=passes, plane=plane, seed=7,
+                                pass_base=k * passes)
+        assert img.tobytes() == ref.cpu().numpy().tobytes(), k
+    fr.close()
+
+
 @pytest.mark.parametrize("strip_h,parts", [(5, 3), (8, 2), (13, 4), (1, 2)])
 def test_odd_strip_layouts_reassemble_to_the_full_frame(strip_h, parts):
     """mgpu_render_strips_device with strips that are not multiples of the 8-row work tiles, a frame height that is not a
