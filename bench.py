@@ -245,6 +245,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the occupancy pass, the read-back timing and extra_configs")
     ap.add_argument("--exchange", choices=("rccl", "torch"), default="rccl",
                     help="N > 1: rccl = the C ABI's multi-GPU frame (RCCL called directly), torch = torch.distributed gather")
+    ap.add_argument("--frames-per-launch", type=int, default=0,
+                    help="frames rendered by one persistent launch per GPU (mgpu_frame_render_batch); default 1 at N=1, 4 at N>1")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames enqueued concurrently (own stream and buffers each); default 1 on one GPU -- kernel time "
                          "then is what rocprofv3 shows -- and 3 on N > 1, where the RCCL gather and the end of a launch "
@@ -285,7 +287,14 @@ def main():
     scene = M.Scene(verts, faces, mats, normals, None, device=local_rank)  # BVH: this library's host builder
     frame = workloads.camera(cfg)
     plane = scene.plane() if cfg["plane"] else None
-    fif = args.frames_in_flight if args.frames_in_flight > 0 else (1 if world == 1 else 3)
+    # N > 1: a GPU renders 1/N of the frame, and the end of a persistent launch (waves running dry one by one, ~0.35 ms) does not
+    # shrink with it -- so several frames share a launch (mgpu_frame_render_batch) and twice that many are in flight, the
+    # exchange of one batch under the launch of the next.  N = 1: one frame per launch, one in flight (SURVEY 8(d)'s frame).
+    fpl = args.frames_per_launch if args.frames_per_launch > 0 else (1 if world == 1 else 4)
+    if world > 1 and args.exchange != "rccl":
+        fpl = 1  # the torch.distributed formulation renders frame by frame
+    fif = args.frames_in_flight if args.frames_in_flight > 0 else (min(8, 2 * fpl) if fpl > 1 else (1 if world == 1 else 3))
+    fpl = min(fpl, fif)
     fr = FrameRenderer(scene, frame, W, H, mpl, spp, plane, cfg["seed"], rank, world, dev, frames_in_flight=fif,
                        force_collective=force_gather)
     # N > 1: the exchange goes through the C ABI's multi-GPU frame (mgpu_frame_*: RCCL called directly, every strip received
@@ -323,6 +332,13 @@ def main():
         else:
             fr.render(pass_base=k * spp)
 
+    def render_frames(k0, n):
+        if cframe is not None and n > 1:
+            pending.extend(cframe.render_batch(frame, mpl, spp, n, plane, seed=cfg["seed"], pass_base=k0 * spp))
+        else:
+            for k in range(k0, k0 + n):
+                render_frame(k)
+
     def finish_frames():
         if cframe is not None:
             for slot in sorted(set(pending[-fif:])):
@@ -335,16 +351,17 @@ def main():
             dist.barrier(device_ids=[local_rank])
             torch.cuda.synchronize(dev)
 
-    for k in range(args.warmup):
-        render_frame(k)
+    batched = cframe is not None and fpl > 1
+    for k0 in range(0, args.warmup, fpl if batched else 1):
+        render_frames(k0, min(fpl, args.warmup - k0) if batched else 1)
     finish_frames()
     sync_all()
     flush_c_stdio()  # the communicators exist by now: whatever RCCL had to say goes out before the measurement
     scene.stats_read(reset=True)
     scene.timing_enable(True)
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        render_frame(k)  # frame k = passes [k*spp, (k+1)*spp): the next 16 samples per pixel, not the same ones
+    for k0 in range(0, args.steps, fpl if batched else 1):  # frame k = passes [k*spp, (k+1)*spp): the next 16 samples per pixel
+        render_frames(k0, min(fpl, args.steps - k0) if batched else 1)
     finish_frames()
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -410,7 +427,7 @@ def main():
                                    "(pass_base advances by %d per step)" % (spp, spp),
                        "parallelism": "replicated scene, interleaved 8-row strips x%d, 1 RCCL exchange/frame: %s" % (world, exchange)
                                       if world > 1 else "single GPU, persistent-threads kernel",
-                       "frames_in_flight": fif,
+                       "frames_in_flight": fif, "frames_per_launch": fpl if batched else 1,
                        "rays_per_frame": int(rays / args.steps), "trace_calls_per_frame": int(trace_calls / args.steps),
                        "nodes_per_ray": round(nodes / rays, 3), "tris_per_ray": round(tris / rays, 3),
                        "mtrace_calls_per_s": round(trace_calls / elapsed / 1e6, 2)},

@@ -1201,3 +1201,19 @@ def test_bench_line_is_well_formed(tmp_path):
     assert d["cpu_baseline"]["gpu_frame_byte_equal"] is True and d["cpu_baseline"]["kind"] == "port"
     assert set(d["extra_configs"]) == {"c3", "c4"} and all("error" not in v for v in d["extra_configs"].values())
     assert d["frame_with_readback"]["ms_per_frame"] >= d["ms_per_step"] * 0.9
+
+
+def test_bench_batched_frames_through_the_c_abi_exchange():
+    """bench.py's N > 1 frame loop on one GPU: the C ABI's multi-GPU frame with the exchange forced (RCCL send / recv to self),
+    three frames per launch, five steps (a full batch and a short one), the last frame still byte-equal to the oracle's."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, MGPU_FRAME_FORCE_EXCHANGE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-extras",
+                        "--frames-per-launch", "3", "--frames-in-flight", "6"], capture_output=True, text=True, cwd=ROOT, timeout=600,
+                       env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["steps"] == 5 and d["config"]["frames_per_launch"] == 3 and d["config"]["frames_in_flight"] == 6
+    assert d["value"] > 1000 and d["cpu_baseline"]["gpu_frame_byte_equal"] is True
