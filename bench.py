@@ -461,6 +461,30 @@ def main():
             out["tile_order_off"] = {"ms_per_frame": round(ms_no, 3), "note": "MGPU_TILE_ORDER=0 (image-order hand-out), same frames"}
             del fr0
             scene0.close()
+            # the fast mode (MGPU_PRECISION_FP32, SURVEY 7 step 6 "report both"): the same frames in float.  Never `value`:
+            # its frames are close to the reference's, not equal to them -- the distance is measured here, on the last frame.
+            try:
+                frf = FrameRenderer(scene, frame, W, H, mpl, spp, plane, cfg["seed"], 0, 1, dev)
+                ref64 = frf.render(pass_base=last_pass_base).clone()
+                torch.cuda.synchronize(dev)
+                scene.set_precision("fp32")
+                frf.render(pass_base=0)
+                ms_f, kms_f, st_f = time_frames(scene, lambda k: frf.render(pass_base=k * spp), args.steps, lambda: torch.cuda.synchronize(dev))
+                d = (frf.render(pass_base=last_pass_base).double() - ref64.double()) / spp
+                torch.cuda.synchronize(dev)
+                l2 = d.pow(2).sum(-1).sqrt()
+                out["fast_mode_fp32"] = {
+                    "ms_per_frame": round(ms_f, 3), "kernel_avg_ms": round(kms_f, 3), "kernel": "k_render_f32",
+                    "value": round(st_f["real_rays"] / args.steps / ms_f / 1e3, 2), "unit": "Mrays/s", "dtype": "f32",
+                    "distance_to_fp64_frame": {"rms_per_pixel_l2": float("%.3g" % float(l2.pow(2).mean().sqrt().item())),
+                                               "pixels_moved_over_1e-3": float("%.3g" % float((l2 > 1e-3).double().mean().item())),
+                                               "note": "pixel means of the last timed frame (%d spp); north_star's tolerance is 1e-4" % spp},
+                    "note": "mgpu_scene_set_precision(MGPU_PRECISION_FP32): same algorithm, visiting order and random stream in float on a "
+                            "float copy of the scene; NOT bit-identical to the reference and not the headline"}
+            except Exception as e:  # an extra line must never take the headline down
+                out["fast_mode_fp32"] = {"error": repr(e)}
+            finally:
+                scene.set_precision("fp64")
         gpu_frame = None
         if world == 1 and not args.no_cpu_baseline:
             # the last timed frame (pass_base of the last step), re-rendered after the timed region so that the extras above

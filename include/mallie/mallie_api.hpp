@@ -14,6 +14,8 @@
 //    (render.cc:116-168 with OMP_NUM_THREADS=1): the image then IS the reference's image.
 //  * MALLIE_GPUS=n in the environment makes mallie::Render / RenderPasses use n GPUs of the node (scene replicated,
 //    interleaved 8-row strips, one RCCL exchange per frame; mgpu_frame_* in include/mgpu.h).  The image does not depend on n.
+//  * mallie::SetRenderFastMode(true) (or MALLIE_FAST=1) switches Render / RenderPasses to fp32 arithmetic: faster, close to
+//    the reference's image (rms per-pixel L2 2e-5 on the Cornell frame) but not identical to it.  Off by default.
 //  * kMaxPathLength (render.cc:52) is a run-time setting here: mallie::SetMaxPathLength (default 16 = reference).
 //  * Render() with step > 1 (progressive block fill, render.cc:684-696) needs a frame whose sizes are multiples of the
 //    step: for other sizes the reference writes outside the image, and this implementation reports an error instead.
@@ -294,6 +296,10 @@ void SetRenderRngTable(const unsigned int *states); // W*H*4 words for the NEXT 
 // true: Render / RenderPasses draw from the reference's own serial stream (render.cc:116-168, one OpenMP thread), starting at
 // its seed and continuing from call to call; resets that stream to the seed.  false: back to per-(pixel, pass) seeding.
 void SetRenderReferenceStream(bool on);
+// true (or MALLIE_FAST=1 in the environment): Render / RenderPasses compute in float (mgpu_scene_set_precision,
+// MGPU_PRECISION_FP32): the same algorithm and random stream, ~1.3x faster, NOT bit-identical to the reference -- a path
+// whose ray passes within ~1e-6 of a silhouette may decide differently and continue as another sample.
+void SetRenderFastMode(bool on);
 // `passes` passes in one launch, accumulated on the device in pass order (== Render + AccumImage, main_sdl.cc:138-143);
 // count[px] += passes.  Returns false (after printing a Mallie:err line) on failure.
 bool RenderPasses(Scene &scene, const RenderConfig &config, std::vector<float> &image, std::vector<int> &count,

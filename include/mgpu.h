@@ -102,6 +102,18 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
                       const double *fv_normals, const double *fv_uvs, const MgpuNode *nodes, size_t nn,
                       const uint32_t *indices, const double *mat_diffuse, size_t nm, int device, MgpuScene **out);
 int mgpu_scene_destroy(MgpuScene *scene);
+
+/* Arithmetic of the render entry points of this scene (mgpu_render, mgpu_render_strips_device, mgpu_render_frames_device,
+ * mgpu_frame_*): MGPU_PRECISION_FP64 (default) = the reference's double arithmetic, bit-identical to the reference;
+ * MGPU_PRECISION_FP32 = the FAST MODE: the same algorithm, same random stream, same visiting order in
+ * float on a float copy of the scene (32-byte nodes with outward-rounded boxes, 48-byte triangles; built on first use, +56 %
+ * of the node / triangle memory).  Not bit-exact: a path follows the reference's path until a hit / miss decision falls
+ * differently (rays within ~1e-6 of a silhouette) and is another sample of the same integrand from there; measured distance
+ * to the fp64 frame and speed: DESIGN.md 5.  mgpu_trace*, mgpu_render_aov, mgpu_render_stream, mgpu_render_step and
+ * mgpu_render_panoramic* always compute in double. */
+#define MGPU_PRECISION_FP64 0
+#define MGPU_PRECISION_FP32 1
+int mgpu_scene_set_precision(MgpuScene *scene, int precision);
 /* Scene::BoundingBox (scene.cc:317-333). */
 int mgpu_scene_bbox(const MgpuScene *scene, double bmin[3], double bmax[3]);
 /* Bytes resident on the device for this scene. */

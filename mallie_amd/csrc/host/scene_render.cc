@@ -264,6 +264,8 @@ void SetRenderSeed(unsigned long long seed) {
   gPassCounter = 0;
 }
 void SetRenderRngTable(const unsigned int *states) { gRngTable = states; }
+static int gFastMode = -1; // SetRenderFastMode; -1: not set, MALLIE_FAST decides
+void SetRenderFastMode(bool on) { gFastMode = on ? 1 : 0; }
 void SetRenderReferenceStream(bool on) {
   gReferenceStream = on;
   gStreamState[0] = 123456789u; gStreamState[1] = 362436069u; gStreamState[2] = 521288629u; gStreamState[3] = 88675123u;
@@ -298,6 +300,14 @@ static bool render_impl(Scene &scene, const RenderConfig &config, std::vector<fl
     printf("Mallie:err\tmsg:Render: no device scene (%s)\n", mgpu_last_error());
     return false;
   }
+  {
+    const char *e = getenv("MALLIE_FAST");
+    const bool fast = gFastMode >= 0 ? gFastMode == 1 : (e && atoi(e) != 0);
+    if (mgpu_scene_set_precision(dev, fast ? MGPU_PRECISION_FP32 : MGPU_PRECISION_FP64) != MGPU_OK) {
+      printf("Mallie:err\tmsg:Render: %s\n", mgpu_last_error());
+      return false;
+    }
+  }
   const float pl[4] = {gPlaneObject.m_a, gPlaneObject.m_b, gPlaneObject.m_c, gPlaneObject.m_d};
   const bool table = gRngTable != NULL;
   if (table && passes != 1) { // SetRenderRngTable holds the start states of ONE pass (width * height * 4 words)
@@ -326,6 +336,12 @@ static bool render_impl(Scene &scene, const RenderConfig &config, std::vector<fl
   if (gpus > 1 || (step == 1 && !table && force_frame && atoi(force_frame) != 0)) { // the same frame from n GPUs: strips, one RCCL exchange, assembled on device 0 (include/mgpu.h, mgpu_frame_*)
     MgpuFrame *mf = multi_frame(scene, gpus, width, height);
     if (!mf) return false;
+    {
+      const char *e = getenv("MALLIE_FAST");
+      const bool fast = gFastMode >= 0 ? gFastMode == 1 : (e && atoi(e) != 0);
+      for (size_t i = 1; i < gMulti.scenes.size(); i++) // the replicas follow the first scene's arithmetic
+        if (mgpu_scene_set_precision(gMulti.scenes[i], fast ? MGPU_PRECISION_FP32 : MGPU_PRECISION_FP64) != MGPU_OK) return false;
+    }
     const double cam[12] = {origin[0], origin[1], origin[2], corner[0], corner[1], corner[2],
                             du[0],     du[1],     du[2],     dv[0],     dv[1],     dv[2]};
     int slot = 0;

@@ -75,12 +75,14 @@ struct MgpuScene {
   size_t nv = 0, nf = 0, nn = 0, nm = 0;
   int tree_depth = 0;  // deepest node level (root = 0)
   bool boxes_ordered = false; // bmin <= bmax in every reachable node (lets the kernels take the min/max slab test)
+  int precision = MGPU_PRECISION_FP64; // mgpu_scene_set_precision: which render kernel family the render entry points use
   int stack_need = 1;  // entries a traversal can ever hold = tree_depth + 1
   int cap = 16;        // LDS stack entries per lane of the instantiated kernels
   double bmin[3], bmax[3];
   DScene d{};
   // owned device allocations
   void *p_nodes = nullptr, *p_tris = nullptr, *p_slotn = nullptr, *p_mat = nullptr, *p_verts = nullptr,
+       *p_fnodes = nullptr, *p_ftris = nullptr, *p_fnormals = nullptr, *p_fdiffuse = nullptr, // fast mode (float copies)
        *p_faces = nullptr, *p_fvn = nullptr, *p_fvuv = nullptr, *p_overflow = nullptr, *p_wnodes = nullptr,
        *p_woverflow = nullptr;
   size_t overflow_lanes = 0, woverflow_lanes = 0;
@@ -460,7 +462,7 @@ int mgpu_scene_destroy(MgpuScene *s) {
   (void)hipDeviceSynchronize();
   void *ptrs[] = {s->p_nodes, s->p_tris, s->p_slotn, s->p_mat, s->p_verts, s->p_faces, s->p_fvn, s->p_fvuv,
                   s->p_overflow, s->p_counters, s->p_stats, s->p_wave_log, s->p_host_img, s->p_trace, s->p_wnodes,
-                  s->p_woverflow};
+                  s->p_woverflow, s->p_fnodes, s->p_ftris, s->p_fnormals, s->p_fdiffuse};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (s->p_trace_pinned) (void)hipHostFree(s->p_trace_pinned);
@@ -474,6 +476,27 @@ int mgpu_scene_destroy(MgpuScene *s) {
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   for (hipEvent_t e : s->t_ev) (void)hipEventDestroy(e);
   delete s;
+  return MGPU_OK;
+}
+
+int mgpu_scene_set_precision(MgpuScene *s, int precision) {
+  if (!s) return fail(MGPU_ERR_INVALID, "scene is NULL");
+  if (precision != MGPU_PRECISION_FP64 && precision != MGPU_PRECISION_FP32) return fail(MGPU_ERR_INVALID, "bad precision %d", precision);
+  if (precision == MGPU_PRECISION_FP32 && !s->p_fnodes) { // first use: the float copy of the scene
+    int rc = set_device(s);
+    if (rc) return rc;
+    const int per = s->d.has_fv_normals ? 9 : 3;
+    rc = dev_alloc(s, &s->p_fnodes, sizeof(FNode) * (s->nn ? s->nn : 1));
+    if (!rc) rc = dev_alloc(s, &s->p_ftris, sizeof(FTri) * (s->nf ? s->nf : 1));
+    if (!rc) rc = dev_alloc(s, &s->p_fnormals, sizeof(float) * per * (s->nf ? s->nf : 1));
+    if (!rc) rc = dev_alloc(s, &s->p_fdiffuse, sizeof(float) * 3 * (s->d.nm ? s->d.nm : 1));
+    if (rc) return rc;
+    launch_layout_f32(nullptr, (const MgpuNode *)s->p_nodes, s->nn, (const DTri *)s->p_tris, s->nf, s->d.slot_normal, s->d.has_fv_normals,
+                      s->d.mat_diffuse, s->d.nm, (FNode *)s->p_fnodes, (FTri *)s->p_ftris, (float *)s->p_fnormals, (float *)s->p_fdiffuse);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(nullptr));
+  }
+  s->precision = precision;
   return MGPU_OK;
 }
 
@@ -643,6 +666,19 @@ int mgpu_trace(MgpuScene *s, const MgpuRay *rays, size_t n, MgpuIntersection *ou
 
 } // extern "C"
 
+// mgpu_render_stream / mgpu_render_step / mgpu_probe_path compute in double whatever mgpu_scene_set_precision says: their
+// results are defined against the reference's own numbers (its random stream, its block fill, its per-iteration record)
+struct Fp64Only {
+  MgpuScene *s;
+  int saved;
+  explicit Fp64Only(MgpuScene *scene) : s(scene), saved(scene ? scene->precision : 0) {
+    if (s) s->precision = MGPU_PRECISION_FP64;
+  }
+  ~Fp64Only() {
+    if (s) s->precision = saved;
+  }
+};
+
 // n_frames consecutive frames of `passes` passes each (frame f: passes pass_base + f * passes ...) into d_images[f] /
 // d_counts[f].  With several frames the passes of as many frames as the plane budget holds go into ONE persistent launch
 // (the kernel sees n * passes passes; every frame's planes are then summed into its own image): the end of a launch, where
@@ -708,6 +744,19 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
   }
   if (kern == 1) shmem = (size_t)(block / 64) * WStack<kWideStackLds>::kWaveBytes; // wide traversal: far-child stack
   int per_cu = kern == 2 ? 1 : (kern == 1 ? 4 : 2); // workgroups per CU: 16 waves per CU for the state-machine kernels
+  // fast mode (mgpu_scene_set_precision): k_render_f32 on the float copy of the scene -- 32-byte nodes and 48-byte
+  // triangles, so scenes twice the size still fit in LDS beside the stacks
+  bool f32_lds = false;
+  if (s->precision == MGPU_PRECISION_FP32) {
+    if (kern == 0) return fail(MGPU_ERR_UNSUPPORTED, "MGPU_RENDER_KERNEL=v1 has no fast mode");
+    const size_t fscene_lds = sizeof(FNode) * s->nn + sizeof(FTri) * s->nf;
+    const size_t stacks = (size_t)16 * s->cap * 64 * sizeof(uint32_t);
+    f32_lds = s->cap <= 24 && s->stack_need <= s->cap && stacks + fscene_lds <= kLdsBudget && !getenv("MGPU_F32_HBM");
+    kern = 3;
+    block = f32_lds ? 1024 : kBlock;
+    shmem = (size_t)(block / 64) * s->cap * 64 * sizeof(uint32_t) + (f32_lds ? fscene_lds : 0);
+    per_cu = f32_lds ? 1 : (s->cap <= 24 ? 5 : 4); // HBM-resident: 20 waves per CU while their stacks fit (mgpu_render_f32.hip)
+  }
   if (const char *e = getenv("MGPU_RENDER_BLOCKS_PER_CU")) per_cu = atoi(e) < 1 ? 1 : atoi(e);
   // persistent grid: as many workgroups as stay resident, capped by the work available
   const uint64_t tiles = (uint64_t)((win_w + 7) / 8) * (uint64_t)((n_rows + 7) / 8);
@@ -794,6 +843,19 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
   P.stats = s->p_stats;
   P.lds_nodes_bytes = (uint32_t)(sizeof(MgpuNode) * s->nn);
   P.lds_tris_bytes = (uint32_t)(sizeof(DTri) * s->nf);
+  FScene fsc{};
+  if (kern == 3) {
+    P.lds_nodes_bytes = (uint32_t)(sizeof(FNode) * s->nn);
+    P.lds_tris_bytes = (uint32_t)(sizeof(FTri) * s->nf);
+    fsc.nodes = (const FNode *)s->p_fnodes;
+    fsc.tris = (const FTri *)s->p_ftris;
+    fsc.normals = (const float *)s->p_fnormals;
+    fsc.diffuse = (const float *)s->p_fdiffuse;
+    fsc.nm = s->d.nm;
+    fsc.has_fv_normals = s->d.has_fv_normals;
+    fsc.stack_overflow = dsc.stack_overflow;
+    fsc.overflow_cap = dsc.overflow_cap;
+  }
   if (!s->p_wave_log && getenv("MGPU_WAVE_LOG")) {
     rc = dev_alloc(s, (void **)&s->p_wave_log, sizeof(unsigned long long) * 8 * 16384);
     if (rc) return rc;
@@ -879,6 +941,8 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
     if (kern == 0) {
       launch_render(s->cap, dim3((unsigned)blocks), st, dsc, P);
       HIP_TRY(hipGetLastError());
+    } else if (kern == 3) {
+      HIP_TRY(launch_render_f32(s->cap, f32_lds, dim3((unsigned)blocks), st, shmem, fsc, P));
     } else {
       HIP_TRY(launch_render_sm(s->cap, kern == 2, block, dim3((unsigned)blocks), st, shmem, dsc, P));
     }
@@ -1158,6 +1222,7 @@ int mgpu_render_stream(MgpuScene *s, const double origin[3], const double corner
     memcpy(frame + 6, du, 24);
     memcpy(frame + 9, dv, 24);
     MgpuStats local;
+    Fp64Only fp64_guard(s);
     rc = mgpu_render_strips_device(s, frame, W, H, 0, W, 0, H, H, H, maxPathLength, passes, plane, MGPU_RNG_TABLE, d_table, 0, 0,
                                    (float *)s->p_host_img, nullptr, nullptr, &local);
     if (rc) {
@@ -1225,6 +1290,7 @@ int mgpu_render_step(MgpuScene *s, const double origin[3], const double corner[3
   }
   MgpuStats local;
   s->pix_step = step; // the window below counts step x step blocks; a block's path is its top-left pixel's
+  Fp64Only fp64_guard(s);
   rc = mgpu_render_strips_device(s, frame, W, H, 0, cw, 0, ch, ch, ch, maxPathLength, 1, plane, rng_mode, d_states, seed,
                                  pass_base, (float *)s->p_host_img, nullptr, nullptr, &local);
   s->pix_step = 1;
@@ -1615,6 +1681,7 @@ int mgpu_probe_path(MgpuScene *s, const double frame[12], int W, int H, int px, 
   s->probe_pixel = (uint32_t)pix;
   s->probe_pass = 0;
   MgpuStats st;
+  Fp64Only fp64_guard(s);
   rc = mgpu_render_strips_device(s, frame, W, H, px, px + 1, py, 1, 1, 1, maxPathLength, 1, plane, MGPU_RNG_TABLE,
                                  d_states, 0, 0, d_img, nullptr, nullptr, &st);
   if (rc) {

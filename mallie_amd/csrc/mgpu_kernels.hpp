@@ -131,6 +131,29 @@ void launch_scene_layout(hipStream_t s, const double *verts, const uint32_t *fac
 // WNode records of the wide traversal (nn + 1 of them, the last is the super root)
 void launch_wide_layout(hipStream_t s, const MgpuNode *nodes, size_t nn, WNode *out);
 constexpr int kWideStackLds = 8; // far-child stack entries per lane kept in LDS by the wide traversal (16 bytes each)
+// ---- fast mode (mgpu_render_f32.hip): the scene in float --------------------------------------------------------------
+struct alignas(16) FNode { // 32 bytes: box (rounded outward), a / b = children or leaf run (see k_layout_f32)
+  float bmin[3], bmax[3];
+  uint32_t a, b;
+};
+struct alignas(16) FTri { // 48 bytes: p0, e1, e2, material
+  float v[9];
+  uint32_t mat;
+  uint32_t pad[2];
+};
+struct FScene {
+  const FNode *nodes;
+  const FTri *tris;
+  const float *normals; // slot order: 9 floats (face-varying) or 3 (geometric)
+  const float *diffuse; // 3 * nm
+  uint32_t nm;
+  int has_fv_normals;
+  uint32_t *stack_overflow;
+  uint32_t overflow_cap;
+};
+void launch_layout_f32(hipStream_t s, const MgpuNode *nodes, size_t nn, const DTri *tris, size_t nf, const double *slot_normal,
+                       int has_fv, const double *mat_diffuse, uint32_t nm, FNode *fnodes, FTri *ftris, float *fnormals, float *fdiffuse);
+hipError_t launch_render_f32(int cap, bool lds_scene, dim3 grid, hipStream_t s, size_t shmem, const FScene &sc, const RenderParams &p);
 void launch_tonemap(hipStream_t s, const float *image, const int32_t *count, size_t npix, int mode, unsigned char *out);
 constexpr size_t kLdsBudget = 160 * 1024 - 512; // bytes of LDS per CU on gfx950, less the kernels' static cursor words
 

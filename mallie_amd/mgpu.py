@@ -8,6 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("MALLIE_MGPU_LIB") or os.path.join(_HERE, "libmallie_mgpu.so")  # override: A/B builds
 
 RNG_STREAM, RNG_TABLE, RNG_HASH = 0, 1, 2
+PRECISION_FP64, PRECISION_FP32 = 0, 1
 
 # byte-identical to the reference's BVHNode / Ray / Intersection (bvh_accel.h:10-30, common.h:78-83, intersection.h:6-24)
 NODE_DT = np.dtype([("bmin", "<f8", 3), ("bmax", "<f8", 3), ("flag", "<i4"), ("axis", "<i4"), ("data", "<u4", 2)])
@@ -67,6 +68,8 @@ def load_library():
     L.mgpu_scene_create.argtypes = [vp, sz, vp, sz, vp, vp, vp, vp, sz, vp, vp, sz, i32, C.POINTER(vp)]
     L.mgpu_scene_create.restype = i32
     L.mgpu_scene_destroy.argtypes = [vp]
+    L.mgpu_scene_set_precision.argtypes = [vp, i32]
+    L.mgpu_scene_set_precision.restype = i32
     L.mgpu_scene_destroy.restype = i32
     L.mgpu_scene_bbox.argtypes = [vp, vp, vp]
     L.mgpu_scene_bbox.restype = i32
@@ -535,6 +538,11 @@ class Scene:
                                               _p(_c(plane, "<f4")), _p(_c(start_state, "<u4")), _p(rec), C.byref(n)),
                "mgpu_probe_path")
         return rec[: n.value]
+
+    def set_precision(self, precision):
+        """mgpu_scene_set_precision: "fp64" (default, bit-identical to the reference) or "fp32" (the fast mode)."""
+        code = {"fp64": PRECISION_FP64, "fp32": PRECISION_FP32}.get(precision, precision)
+        _check(load_library().mgpu_scene_set_precision(self.h, int(code)), "mgpu_scene_set_precision")
 
     def render_strips_device(self, frame, W, H, d_image_ptr, n_rows, x0=0, x1=None, y_first=0, strip_h=None,
                              y_period=None, maxPathLength=16, passes=1, plane=None, rng_mode=RNG_HASH,

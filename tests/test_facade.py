@@ -276,6 +276,34 @@ def test_facade_render_through_the_multi_gpu_frame(driver, tmp_path):
 
 
 @pytest.mark.gpu
+def test_facade_render_in_the_fast_mode(driver, tmp_path):
+    """MALLIE_FAST=1: mallie::Render / RenderPasses in fp32 (plain and through the multi-GPU frame): close to the oracle's
+    frame -- rms per-pixel L2 of the pixel means <= 1e-3 at this tiny size, under 0.5 % of the pixels moved by more than
+    1e-3 -- and not equal to it (the switch did something); the driver's own check RenderPasses == Render + AccumImage holds
+    in the fast mode too."""
+    obj = str(tmp_path / "cornell_like.obj")
+    _write_cornell_obj(obj)
+    W, H, passes, mpl, seed = 96, 64, 3, 6, 5
+    g = O.load_golden("cornell_obj")
+    osc = O.OracleScene(g["verts"].astype(np.float64), g["faces"], np.full(len(g["faces"]), 0xFFFFFFFF, "u4"), g["normals"], None)
+    frame = O.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    oimg, _, _, _ = osc.render(frame, W, H, mpl, passes, osc.plane(), O.RNG_HASH, seed=seed)
+    imgs = []
+    for extra in ({}, {"MGPU_FRAME_FORCE_EXCHANGE": "1"}):
+        out = str(tmp_path / "img.f32")
+        r = subprocess.run([driver, "render", "obj", obj, str(W), str(H), "1", str(passes), str(mpl), str(seed), out],
+                           capture_output=True, text=True, cwd=str(tmp_path), env=dict(os.environ, MALLIE_FAST="1", **extra))
+        assert r.returncode == 0, r.stdout + r.stderr
+        raw = np.fromfile(out, "<f4")
+        img, count = raw[: 3 * W * H].reshape(H, W, 3), raw[3 * W * H:].view("<i4").reshape(H, W)
+        assert np.all(count == passes) and img.tobytes() != oimg.tobytes()
+        l2 = np.sqrt((((img.astype(np.float64) - oimg) / passes) ** 2).sum(-1))
+        assert np.sqrt((l2 ** 2).mean()) <= 1e-3 and (l2 > 1e-3).mean() <= 5e-3, (np.sqrt((l2 ** 2).mean()), (l2 > 1e-3).mean())
+        imgs.append(img)
+    assert imgs[0].tobytes() == imgs[1].tobytes()
+
+
+@pytest.mark.gpu
 def test_facade_render_in_the_reference_stream(driver, tmp_path):
     """MALLIE_RNG_STREAM=1: mallie::Render draws from the reference's own serial random stream, continued from call to call
     (three Render() calls + AccumImage in the driver) -- the oracle's run of three passes in that stream, bit for bit; the

@@ -1200,6 +1200,8 @@ def test_bench_line_is_well_formed(tmp_path):
     assert occ and 0.2 < occ["node_frac"] < 1 and 0.2 < occ["tri_frac"] < 1 and 0.2 < occ["shade_frac"] <= 1
     assert d["cpu_baseline"]["gpu_frame_byte_equal"] is True and d["cpu_baseline"]["kind"] == "port"
     assert set(d["extra_configs"]) == {"c3", "c4"} and all("error" not in v for v in d["extra_configs"].values())
+    fast = d["fast_mode_fp32"]
+    assert "error" not in fast and fast["ms_per_frame"] < d["ms_per_step"] and fast["distance_to_fp64_frame"]["rms_per_pixel_l2"] <= 1e-4
     assert d["frame_with_readback"]["ms_per_frame"] >= d["ms_per_step"] * 0.9
 
 
@@ -1217,3 +1219,79 @@ def test_bench_batched_frames_through_the_c_abi_exchange():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["steps"] == 5 and d["config"]["frames_per_launch"] == 3 and d["config"]["frames_in_flight"] == 6
     assert d["value"] > 1000 and d["cpu_baseline"]["gpu_frame_byte_equal"] is True
+
+
+def _l2_stats(a, b, spp):
+    d = a.astype(np.float64) / spp - b.astype(np.float64) / spp
+    l2 = np.sqrt((d ** 2).sum(-1))
+    return float(np.sqrt((l2 ** 2).mean())), float((l2 > 1e-3).mean())
+
+
+@pytest.mark.parametrize("name,force_hbm", [("cornell_obj", False), ("cornell_obj", True), ("teapot_obj", False)])
+def test_fast_mode_fp32_stays_close_to_the_fp64_frame(name, force_hbm, monkeypatch):
+    """MGPU_PRECISION_FP32 (the fast mode) is the same algorithm in float: the same paths are started (equal path and
+    Trace() call counts up to the handful of decisions that fall differently), node / triangle work within 0.1 %, and the
+    frame close to the fp64 frame -- which the other tests pin to the oracle: rms per-pixel L2 of the pixel means <= 5e-4 at
+    this size (a moved pixel weighs 1 / sqrt(pixels); teapot 1.5e-3), at most 0.1 % of the pixels moved by more than 1e-3,
+    image mean within 1e-4.  LDS-resident, the same scene forced through the HBM-resident variant, and teapot.
+    Switching back to fp64 gives the bit-identical frame again; stream / step entry points ignore the switch."""
+    import torch
+    if force_hbm:
+        monkeypatch.setenv("MGPU_F32_HBM", "1")
+    sc = gpu_scene(name)
+    eye, look = ((0.0, 40.0, 250.0), (0.0, 40.0, 0.0)) if name == "teapot_obj" else ((0, 0, 20), (0, 0, 0))
+    W, H, mpl, passes = 320, 240, 5, 8
+    cam = M.camera_frame(eye, look, width=W, height=H)
+    plane = sc.plane()
+
+    def frame(pb=0):
+        buf = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        st = sc.render_strips_device(cam, W, H, buf.data_ptr(), H, maxPathLength=mpl, passes=passes, plane=plane, seed=3,
+                                     pass_base=pb, want_stats=True)
+        return buf.cpu().numpy(), st
+
+    ref, st64 = frame()
+    sc.set_precision("fp32")
+    fast, st32 = frame()
+    fast2, _ = frame()
+    assert fast.tobytes() == fast2.tobytes()  # deterministic
+    assert fast.tobytes() != ref.tobytes()
+    rms, moved = _l2_stats(fast, ref, passes)
+    # (teapot: coordinates up to 250 and slivers at the lid -- nine of 76 800 pixels move, each by up to 0.1)
+    assert rms <= (1.5e-3 if name == "teapot_obj" else 5e-4) and moved <= 1e-3, (rms, moved)
+    assert abs(fast.mean() - ref.mean()) / passes <= 1e-4
+    assert st32["paths"] == st64["paths"] == W * H * passes
+    assert abs(st32["real_rays"] - st64["real_rays"]) <= 1e-3 * st64["real_rays"]
+    assert abs(st32["nodes"] - st64["nodes"]) <= 2e-3 * st64["nodes"] and abs(st32["tris"] - st64["tris"]) <= 2e-3 * st64["tris"]
+    # several frames per launch in the fast mode = single fast frames
+    imgs = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+    sc.render_frames_device(cam, W, H, [t.data_ptr() for t in imgs], H, maxPathLength=mpl, passes=passes, plane=plane, seed=3)
+    assert imgs[0].cpu().numpy().tobytes() == fast.tobytes()
+    assert imgs[1].cpu().numpy().tobytes() == frame(passes)[0].tobytes()
+    # Render(step) keeps computing in double
+    img_s, cnt_s, _ = sc.render_step(cam, W, H, 4, mpl, plane, seed=3)
+    sc.set_precision("fp64")
+    back, _ = frame()
+    assert back.tobytes() == ref.tobytes()
+    img_d, cnt_d, _ = sc.render_step(cam, W, H, 4, mpl, plane, seed=3)
+    assert img_s.tobytes() == img_d.tobytes() and cnt_s.tobytes() == cnt_d.tobytes()
+
+
+def test_fast_mode_c2_frame_within_north_star_distance():
+    """The C2 frame (1920x1080, 16 spp) in the fast mode against the fp64 frame of the same passes (itself byte-equal to the
+    oracle's, test_c2_full_frame_digest_vs_oracle): rms per-pixel L2 <= 1e-4, north_star's figure."""
+    import torch
+    from mallie_amd import workloads
+    cfg = workloads.CONFIGS["c2"]
+    W, H, mpl, spp = cfg["width"], cfg["height"], cfg["bounces"] + 1, cfg["spp"]
+    verts, faces, mats, normals = workloads.mesh_arrays(cfg)
+    sc = M.Scene(verts, faces, mats, normals, None)
+    cam = workloads.camera(cfg)
+    out = {}
+    for prec in ("fp64", "fp32"):
+        sc.set_precision(prec)
+        buf = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        sc.render_strips_device(cam, W, H, buf.data_ptr(), H, maxPathLength=mpl, passes=spp, plane=sc.plane(), seed=cfg["seed"])
+        out[prec] = buf.cpu().numpy()
+    rms, moved = _l2_stats(out["fp32"], out["fp64"], spp)
+    assert rms <= 1e-4 and moved <= 1e-4, (rms, moved)
