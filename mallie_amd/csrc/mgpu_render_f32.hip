@@ -248,7 +248,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_F32_HBM_WAVES(CAP)
   int pathLength = 1;
   uint32_t last_mat = kNoMaterial;
   uint32_t cost_base = 0;
-  bool sx = false, sy = false, sz = false;
+  uint32_t sgn = 0; // bit k: dir[k] < 0
   int sp = -1;
   float bt = 3.0e38f, bu = 0, bv = 0;
   uint32_t bslot = kNoHit;
@@ -281,11 +281,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_F32_HBM_WAVES(CAP)
             q0 = nd[0];
             q1 = nd[1];
           }
+          // the node's last 8 bytes travel with its box (the compiler would fetch them again behind the test)
+          asm volatile("" : "+v"(q1.z), "+v"(q1.w));
           if (slab_f(q0, q1, org, inv, bt)) {
             const uint32_t a = __float_as_uint(q1.z), b = __float_as_uint(q1.w);
             const uint32_t tag = b >> 30, low = b & 0x3FFFFFFFu;
             if (tag != kLeafTag) {
-              const bool nearIsSecond = (tag == 0) ? sx : ((tag == 1) ? sy : sz); // dirSign[node.axis], bvh_accel.cc:818-824
+              const bool nearIsSecond = ((sgn >> tag) & 1u) != 0u; // dirSign[node.axis], bvh_accel.cc:818-824
               stk.put(sp + 1, nearIsSecond ? a : low);   // far
               stk.put(sp + 2, nearIsSecond ? low : a);   // near: popped first
               sp += 2;
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_F32_HBM_WAVES(CAP)
           if (exhausted) st = F_IDLE;
         } else {
           // BVHAccel::Traverse prologue (bvh_accel.cc:774-802)
-          sx = dir.x < 0.0f; sy = dir.y < 0.0f; sz = dir.z < 0.0f;
+          sgn = (dir.x < 0.0f ? 1u : 0u) | (dir.y < 0.0f ? 2u : 0u) | (dir.z < 0.0f ? 4u : 0u);
           inv = f3(__builtin_amdgcn_rcpf(dir.x), __builtin_amdgcn_rcpf(dir.y), __builtin_amdgcn_rcpf(dir.z));
           bt = 3.0e38f; bu = 0.0f; bv = 0.0f; bslot = kNoHit;
           sp = 0;
