@@ -331,7 +331,8 @@ enum : int { WT_NODE = 0, WT_TRI = 1, WT_DONE = 2 };
 // empty, WT_NODE when the repetitions are used up.  n_nodes += 2 per record entered.
 template <bool kPlain, int REPS, int K>
 __device__ __forceinline__ int wide_node_step(const WNode *__restrict__ wn, const WStack<K> &stk, V3 org, double ix,
-                                              double iy, double iz, bool sx, bool sy, bool sz, double bt, uint32_t &cur,
+                                              double iy, double iz, bool sx, bool sy, bool sz, uint32_t sgn /* sx | sy << 1 | sz << 2 */,
+                                              double bt, uint32_t &cur,
                                               int &sp, uint32_t &tri_cur, uint32_t &tri_end, uint32_t &n_nodes) {
   int res = WT_NODE;
 #pragma unroll 1
@@ -373,7 +374,7 @@ __device__ __forceinline__ int wide_node_step(const WNode *__restrict__ wn, cons
     const bool h0 = slab_t<kPlain>(a0, a1, a2, org, ix, iy, iz, sx, sy, sz, bt, t0);
     const bool h1 = slab_t<kPlain>(a3, a4, a5, org, ix, iy, iz, sx, sy, sz, bt, t1);
     const uint32_t axis = m.y >> 30, tag0 = m.y & kWInterior, tag1 = m.w;
-    const bool nearIsSecond = (axis == 0) ? sx : ((axis == 1) ? sy : sz); // dirSign[node.axis], bvh_accel.cc:818-824
+    const bool nearIsSecond = ((sgn >> axis) & 1u) != 0u; // dirSign[node.axis], bvh_accel.cc:818-824
     const bool hn = nearIsSecond ? h1 : h0, hf = nearIsSecond ? h0 : h1;
     const uint32_t refn = nearIsSecond ? m.z : m.x, tagn = nearIsSecond ? tag1 : tag0;
     const uint32_t reff = nearIsSecond ? m.x : m.z, tagf = nearIsSecond ? tag0 : tag1;

@@ -174,9 +174,9 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
         } else {
           int r;
           if (all_plain)
-            r = wide_node_step<true, 3, kWideStackLds>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, bt, cur, sp, tri_cur, tri_end, n_nodes);
+            r = wide_node_step<true, 3, kWideStackLds>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u), bt, cur, sp, tri_cur, tri_end, n_nodes);
           else
-            r = wide_node_step<false, 3, kWideStackLds>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, bt, cur, sp, tri_cur, tri_end, n_nodes);
+            r = wide_node_step<false, 3, kWideStackLds>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u), bt, cur, sp, tri_cur, tri_end, n_nodes);
           if (r == WT_TRI) st = ES_TRI;
           else if (r == WT_DONE) st = ES_SHADE;
         }

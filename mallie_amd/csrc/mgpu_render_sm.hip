@@ -203,7 +203,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
   uint32_t cost_base = 0;  // n_nodes + n_tris + 16 * n_rays when the current path started
   // ---- per-lane traversal state ---------------------------------------------------------------------------------
   double ix = 0, iy = 0, iz = 0;
-  bool sx = false, sy = false, sz = false;
+  uint32_t sgn = 0; // bit k: dir[k] < 0 (dirSign, bvh_accel.cc:786-790)
   bool ray_plain = false; // this ray may take the min/max form of the slab test (see the NODE step)
   int sp = -1;           // LDS_SCENE: index of the stack top; wide form: number of far children on the stack
   uint32_t cur = kWNone; // wide form: record to enter next (kWNone: pop)
@@ -278,6 +278,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
       const bool occ_sample = occ_sampled();
       const uint32_t occ_n0 = MGPU_OCC ? n_nodes : 0u;
       if (st == ST_NODE) {
+        const bool sx = (sgn & 1u) != 0u, sy = (sgn & 2u) != 0u, sz = (sgn & 4u) != 0u;
 #ifdef MGPU_UTIL
         if (lane == __ffsll((long long)mN) - 1) u_node++;
 #endif
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
             const bool hit = slab_hit<kPlain>(b0, b1, b2, org, ix, iy, iz, sx, sy, sz, bt);
             if (hit) {
               if (meta.x == 0) {
-                const bool nearIsSecond = (meta.y == 0) ? sx : ((meta.y == 1) ? sy : sz); // dirSign[node.axis]
+                const bool nearIsSecond = ((sgn >> (uint32_t)meta.y) & 1u) != 0u; // dirSign[node.axis]
                 const uint32_t c0 = (uint32_t)meta.z, c1 = (uint32_t)meta.w;
                 stk.put(sp + 1, nearIsSecond ? c0 : c1); // far
                 stk.put(sp + 2, nearIsSecond ? c1 : c0); // near: popped first
@@ -335,10 +336,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
         } else {
           int r;
           if (all_plain)
-            r = wide_node_step<true, MGPU_WIDE_PER_STEP, kWideStackLds>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, bt, cur, sp,
+            r = wide_node_step<true, MGPU_WIDE_PER_STEP, kWideStackLds>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, sgn, bt, cur, sp,
                                                                        tri_cur, tri_end, n_nodes);
           else
-            r = wide_node_step<false, MGPU_WIDE_PER_STEP, kWideStackLds>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, bt, cur, sp,
+            r = wide_node_step<false, MGPU_WIDE_PER_STEP, kWideStackLds>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, sgn, bt, cur, sp,
                                                                         tri_cur, tri_end, n_nodes);
           if (r == WT_TRI) st = ST_TRI;
           else if (r == WT_DONE) st = ST_SHADE;
@@ -706,7 +707,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
           cyc_sub[4] += clock64() - cyc_s; cyc_s = clock64();
 #endif
           // arm the traversal of (org, dir): BVHAccel::Traverse prologue, bvh_accel.cc:774-802
-          sx = dir.x < 0.0; sy = dir.y < 0.0; sz = dir.z < 0.0;
+          sgn = (dir.x < 0.0 ? 1u : 0u) | (dir.y < 0.0 ? 2u : 0u) | (dir.z < 0.0 ? 4u : 0u);
           const bool inv_ok = inverse_dir_w(dir, ix, iy, iz); // 1.0 / dir, no zero guard, as the reference
           ray_plain = sc.boxes_ordered && inv_ok && origin_is_finite(org);
           bt = kDblMax; bu = 0.0; bv = 0.0; bslot = kNoHit;

@@ -90,9 +90,9 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
         // slab test in min/max form when every lane's ray qualifies, the literal form for this step otherwise
         int r;
         if (all_plain)
-          r = wide_node_step<true, 4, kWideStackLds>(sc.wnodes, stk, org, ix, iy, iz, sx, sy, sz, bt, cur, sp, tri_cur, tri_end, n_nodes);
+          r = wide_node_step<true, 4, kWideStackLds>(sc.wnodes, stk, org, ix, iy, iz, sx, sy, sz, (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u), bt, cur, sp, tri_cur, tri_end, n_nodes);
         else
-          r = wide_node_step<false, 4, kWideStackLds>(sc.wnodes, stk, org, ix, iy, iz, sx, sy, sz, bt, cur, sp, tri_cur, tri_end, n_nodes);
+          r = wide_node_step<false, 4, kWideStackLds>(sc.wnodes, stk, org, ix, iy, iz, sx, sy, sz, (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u), bt, cur, sp, tri_cur, tri_end, n_nodes);
         if (r == WT_TRI) st = TS_TRI;
         else if (r == WT_DONE) st = TS_EMIT;
       }
