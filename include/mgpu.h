@@ -110,7 +110,8 @@ int mgpu_scene_destroy(MgpuScene *scene);
  * of the node / triangle memory).  Not bit-exact: a path follows the reference's path until a hit / miss decision falls
  * differently (rays within ~1e-6 of a silhouette) and is another sample of the same integrand from there; measured distance
  * to the fp64 frame and speed: DESIGN.md 5.  mgpu_trace*, mgpu_render_aov, mgpu_render_stream, mgpu_render_step and
- * mgpu_render_panoramic* always compute in double. */
+ * mgpu_render_panoramic* always compute in double.  Like mgpu_scene_destroy, not to be called while another thread is
+ * inside a render call of the same scene; launches already enqueued keep the arithmetic they were enqueued with. */
 #define MGPU_PRECISION_FP64 0
 #define MGPU_PRECISION_FP32 1
 int mgpu_scene_set_precision(MgpuScene *scene, int precision);

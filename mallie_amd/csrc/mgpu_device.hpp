@@ -512,6 +512,7 @@ __device__ __forceinline__ bool shared_leaves_step(unsigned long long mT, int cT
 template <int CAP, bool OVF>
 __device__ __forceinline__ void traverse(const DScene &sc, const Stack<CAP, OVF> &stk, V3 org, V3 dir, Hit &h, Counters &c) {
   const bool sx = dir.x < 0.0, sy = dir.y < 0.0, sz = dir.z < 0.0;
+  const uint32_t sgn = (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u);
   double ix, iy, iz;
   const bool inv_ok = inverse_dir_w(dir, ix, iy, iz); // 1.0 / dir, no zero guard, as the reference
   // wave-uniform: every active lane's ray may take the min/max form of the box test (slab_hit)
@@ -547,7 +548,7 @@ __device__ __forceinline__ void traverse(const DScene &sc, const Stack<CAP, OVF>
                                  : slab_hit<false>(b0, b1, b2, org, ix, iy, iz, sx, sy, sz, h.t);
       if (hit) {
         if (meta.x == 0) {
-          const bool nearIsSecond = (meta.y == 0) ? sx : ((meta.y == 1) ? sy : sz); // dirSign[node.axis]
+          const bool nearIsSecond = ((sgn >> (uint32_t)meta.y) & 1u) != 0u; // dirSign[node.axis]
           const uint32_t c0 = (uint32_t)meta.z, c1 = (uint32_t)meta.w;
           stk.put(sp + 1, nearIsSecond ? c0 : c1); // far
           stk.put(sp + 2, nearIsSecond ? c1 : c0); // near: popped first

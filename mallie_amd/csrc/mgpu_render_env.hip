@@ -102,7 +102,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
   int pathLength = 1;
   // per-lane traversal state
   double ix = 0, iy = 0, iz = 0;
-  bool sx = false, sy = false, sz = false;
+  uint32_t sgn = 0; // bit k: dir[k] < 0
   bool ray_plain = false; // the ray may take the min/max form of the slab test (mgpu_device.hpp, slab_hit)
   int sp = -1;           // LDS_SCENE: index of the stack top; wide form: far children on the stack
   uint32_t cur = kWNone; // wide form: record to enter next
@@ -124,6 +124,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
       // ================================ NODE step ================================
       const bool all_plain = __ballot(st == ES_NODE && !ray_plain) == 0ull; // wave-uniform
       if (st == ES_NODE) {
+        const bool sx = (sgn & 1u) != 0u, sy = (sgn & 2u) != 0u, sz = (sgn & 4u) != 0u;
         // slab_hit<true> (min/max form) when every lane's ray qualifies, the literal form for this step otherwise
         auto node_pops = [&](auto plain_tag) {
           constexpr bool kPlain = decltype(plain_tag)::value;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
             const bool hit = slab_hit<kPlain>(b0, b1, b2, org, ix, iy, iz, sx, sy, sz, bt); // IntersectRayAABB
             if (hit) {
               if (meta.x == 0) {
-                const bool nearIsSecond = (meta.y == 0) ? sx : ((meta.y == 1) ? sy : sz); // dirSign[node.axis]
+                const bool nearIsSecond = ((sgn >> (uint32_t)meta.y) & 1u) != 0u; // dirSign[node.axis]
                 const uint32_t c0 = (uint32_t)meta.z, c1 = (uint32_t)meta.w;
                 stk.put(sp + 1, nearIsSecond ? c0 : c1); // far
                 stk.put(sp + 2, nearIsSecond ? c1 : c0); // near: popped first
@@ -174,9 +175,9 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
         } else {
           int r;
           if (all_plain)
-            r = wide_node_step<true, 3, kWideStackLds>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u), bt, cur, sp, tri_cur, tri_end, n_nodes);
+            r = wide_node_step<true, 3, kWideStackLds>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, sgn, bt, cur, sp, tri_cur, tri_end, n_nodes);
           else
-            r = wide_node_step<false, 3, kWideStackLds>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u), bt, cur, sp, tri_cur, tri_end, n_nodes);
+            r = wide_node_step<false, 3, kWideStackLds>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, sgn, bt, cur, sp, tri_cur, tri_end, n_nodes);
           if (r == WT_TRI) st = ES_TRI;
           else if (r == WT_DONE) st = ES_SHADE;
         }
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
             ++paths;
           }
           // arm the traversal of (org, dir): BVHAccel::Traverse prologue, bvh_accel.cc:774-802
-          sx = dir.x < 0.0; sy = dir.y < 0.0; sz = dir.z < 0.0;
+          sgn = (dir.x < 0.0 ? 1u : 0u) | (dir.y < 0.0 ? 2u : 0u) | (dir.z < 0.0 ? 4u : 0u);
           const bool inv_ok = inverse_dir_w(dir, ix, iy, iz); // 1.0 / dir, no zero guard, as the reference
           ray_plain = sc.boxes_ordered && inv_ok && origin_is_finite(org);
           bt = kDblMax; bu = 0.0; bv = 0.0; bslot = kNoHit;

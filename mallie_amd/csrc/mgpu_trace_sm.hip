@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
   uint32_t rid = 0;
   V3 org = v3(0, 0, 0), dir = v3(0, 0, 1);
   double ix = 0, iy = 0, iz = 0;
-  bool sx = false, sy = false, sz = false;
+  uint32_t sgn = 0; // bit k: dir[k] < 0
   bool ray_plain = false; // the ray may take the min/max form of the slab test (mgpu_device.hpp, slab_hit)
   int sp = 0;               // far children on the stack
   uint32_t cur = kWNone;    // wide record to enter next (kWNone: pop)
@@ -87,12 +87,13 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
       // ================================ NODE step ================================
       const bool all_plain = __ballot(st == TS_NODE && !ray_plain) == 0ull; // wave-uniform
       if (st == TS_NODE) {
+        const bool sx = (sgn & 1u) != 0u, sy = (sgn & 2u) != 0u, sz = (sgn & 4u) != 0u;
         // slab test in min/max form when every lane's ray qualifies, the literal form for this step otherwise
         int r;
         if (all_plain)
-          r = wide_node_step<true, 4, kWideStackLds>(sc.wnodes, stk, org, ix, iy, iz, sx, sy, sz, (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u), bt, cur, sp, tri_cur, tri_end, n_nodes);
+          r = wide_node_step<true, 4, kWideStackLds>(sc.wnodes, stk, org, ix, iy, iz, sx, sy, sz, sgn, bt, cur, sp, tri_cur, tri_end, n_nodes);
         else
-          r = wide_node_step<false, 4, kWideStackLds>(sc.wnodes, stk, org, ix, iy, iz, sx, sy, sz, (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u), bt, cur, sp, tri_cur, tri_end, n_nodes);
+          r = wide_node_step<false, 4, kWideStackLds>(sc.wnodes, stk, org, ix, iy, iz, sx, sy, sz, sgn, bt, cur, sp, tri_cur, tri_end, n_nodes);
         if (r == WT_TRI) st = TS_TRI;
         else if (r == WT_DONE) st = TS_EMIT;
       }
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
           const MgpuRay *r = rays + rid;
           org = v3(r->org[0], r->org[1], r->org[2]);
           dir = v3(r->dir[0], r->dir[1], r->dir[2]);
-          sx = dir.x < 0.0; sy = dir.y < 0.0; sz = dir.z < 0.0;
+          sgn = (dir.x < 0.0 ? 1u : 0u) | (dir.y < 0.0 ? 2u : 0u) | (dir.z < 0.0 ? 4u : 0u);
           const bool inv_ok = inverse_dir_w(dir, ix, iy, iz); // 1.0 / dir, no zero guard, as the reference
           ray_plain = sc.boxes_ordered && inv_ok && origin_is_finite(org);
           bt = kDblMax; bu = 0.0; bv = 0.0; bslot = kNoHit;
