@@ -795,6 +795,8 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
   P.y_first = y_first; P.strip_h = strip_h; P.y_period = y_period; P.n_rows = n_rows;
   P.maxPathLength = maxPathLength; P.passes = passes;
   P.pix_step = pstep;
+  P.inv_len[0] = 0.0;
+  for (int L = 1; L <= 16; ++L) P.inv_len[L] = 1.0 / (double)L;
   if (pstep != 1 && kern == 0) return fail(MGPU_ERR_UNSUPPORTED, "MGPU_RENDER_KERNEL=v1 has no pixel step");
   P.rng_mode = rng_mode;
   P.rng_states = d_rng_states;
@@ -1445,6 +1447,12 @@ int mgpu_render_panoramic_device(MgpuScene *s, const double origin[3], int W, in
   rc = ensure_woverflow(s, blocks * block);
   if (rc) return rc;
   EnvParams P;
+  for (int L0 = 0; L0 <= 32; ++L0) { // EnvParams::tail_sum: the kernel's own loop, run here once per call
+    volatile double r = 0.0;
+    if (L0 >= 2 && L0 <= maxPathLength && maxPathLength <= 32)
+      for (int L = L0; L <= maxPathLength; ++L) r = r + 0.5 / (double)(unsigned)L;
+    P.tail_sum[L0] = r;
+  }
   P.lds_nodes_bytes = (uint32_t)(sizeof(MgpuNode) * s->nn);
   P.lds_tris_bytes = (uint32_t)(sizeof(DTri) * s->nf);
   memcpy(P.origin, origin, sizeof(P.origin));

@@ -35,6 +35,10 @@ struct RenderParams {
   int y_first, strip_h, y_period, n_rows; // row strips: local row j -> y_first + (j/strip_h)*y_period + j%strip_h
   int maxPathLength, passes;
   int pix_step;     // 1, or Render()'s `step`: window coordinates then count step x step blocks (k_render_sm only)
+  // RN(1 / L) for L = 0 .. 16 (host division; [0] unused): the post-miss tail's `x / L` as q = x * y, q += fma(-q, L, x) * y,
+  // which is the correctly rounded quotient when y is the correctly rounded reciprocal (Markstein); tests/test_host_cpu.py
+  // checks the sequence against exact rational arithmetic.  Longer paths divide.
+  double inv_len[17];
   int rng_mode;
   const uint32_t *rng_states; // device, MGPU_RNG_TABLE layout, or null
   unsigned long long seed;
@@ -85,6 +89,10 @@ struct EnvParams {
   uint32_t *work_counter; // one zeroed word
   unsigned long long *stats;
   uint32_t lds_nodes_bytes, lds_tris_bytes; // LDS_SCENE variant: bytes of nodes / triangles staged into LDS
+  // tail_sum[L0] = the radiance of a path whose first miss comes at length L0 (2 <= L0 <= maxPathLength <= 32): 0.5 / L
+  // added for L = L0 .. maxPathLength in that order, evaluated on the host with the same IEEE additions and divisions the
+  // kernel's loop would perform (render.cc:563-574) -- one LDS read instead of up to fifteen divisions.  Longer paths loop.
+  double tail_sum[33];
 };
 hipError_t launch_render_env(int cap, bool lds_scene, dim3 grid, hipStream_t s, const DScene &sc, const EnvParams &p);
 // k_render_aov (mgpu_kernels.hip): ShowNormal (mode 0) / ShowUV (mode 1), one primary ray per pixel of the whole frame

@@ -253,12 +253,21 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
               // first miss at length L0 >= 2: the reference adds 0.5 / L for L = L0 .. maxPathLength, tracing garbage
               // rays in between and drawing three random numbers per remaining iteration (render.cc:563-574)
               trace_calls += (uint32_t)P.maxPathLength;
-              for (int L = pathLength;; ++L) {
-                rad += 0.5 / (double)(unsigned)L;
-                if (L >= P.maxPathLength) break;
-                (void)rng_next(rng);
-                (void)rng_next(rng);
-                (void)rng_next(rng);
+              if (P.maxPathLength <= 32) { // the sum from the host's table (EnvParams::tail_sum), the draws as they come
+                rad += P.tail_sum[pathLength];
+                for (int L = pathLength; L < P.maxPathLength; ++L) {
+                  (void)rng_next(rng);
+                  (void)rng_next(rng);
+                  (void)rng_next(rng);
+                }
+              } else {
+                for (int L = pathLength;; ++L) {
+                  rad += 0.5 / (double)(unsigned)L;
+                  if (L >= P.maxPathLength) break;
+                  (void)rng_next(rng);
+                  (void)rng_next(rng);
+                  (void)rng_next(rng);
+                }
               }
             }
           } else if (pathLength >= P.maxPathLength) {

@@ -94,6 +94,9 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 #ifndef MGPU_WIDE_PER_STEP
 #define MGPU_WIDE_PER_STEP 3 // interior nodes entered per NODE step with the BVH in HBM (two box tests each)
 #endif
+#ifndef MGPU_TAIL_RECIP
+#define MGPU_TAIL_RECIP 1
+#endif
 #ifndef MGPU_OCC
 #define MGPU_OCC 0 // 1: active-lane accounting (kOcc* words); built into libmallie_mgpu_occ.so only, see mallie_amd/build.py
 #endif
@@ -514,19 +517,39 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
                 // grey path (every material the reference can load from .obj/.eson is grey): the three channels
                 // perform identical operations on identical values, so evaluate one and copy -- same bits, 1/3 of the
                 // fp64 divisions
-                for (int L = pathLength;; ++L) {
-                  rad0 += thr0 * 0.5 / (double)(unsigned)L;
-                  if (L >= P.maxPathLength) break;
-                  if (mul) thr0 *= d0;
+                if (MGPU_TAIL_RECIP && P.maxPathLength <= 16) { // x / L through the rounded reciprocal (mgpu_kernels.hpp, inv_len)
+                  for (int L = pathLength;; ++L) {
+                    const double x = thr0 * 0.5, y = P.inv_len[L], dl = (double)(unsigned)L;
+                    const double q = x * y;
+                    rad0 += fma(fma(-q, dl, x), y, q);
+                    if (L >= P.maxPathLength) break;
+                    if (mul) thr0 *= d0;
+                  }
+                } else {
+                  for (int L = pathLength;; ++L) {
+                    rad0 += thr0 * 0.5 / (double)(unsigned)L;
+                    if (L >= P.maxPathLength) break;
+                    if (mul) thr0 *= d0;
+                  }
                 }
                 rad1 = rad2 = rad0;
                 if (!GREY) thr1 = thr2 = thr0;
               } else {
+                const bool recip = MGPU_TAIL_RECIP && P.maxPathLength <= 16;
                 for (int L = pathLength;; ++L) {
                   const double dl = (double)(unsigned)L;
-                  rad0 += thr0 * 0.5 / dl;
-                  rad1 += thr1 * 0.5 / dl;
-                  rad2 += thr2 * 0.5 / dl;
+                  if (recip) {
+                    const double y = P.inv_len[L];
+                    const double x0 = thr0 * 0.5, x1 = thr1 * 0.5, x2 = thr2 * 0.5;
+                    const double q0 = x0 * y, q1 = x1 * y, q2 = x2 * y;
+                    rad0 += fma(fma(-q0, dl, x0), y, q0);
+                    rad1 += fma(fma(-q1, dl, x1), y, q1);
+                    rad2 += fma(fma(-q2, dl, x2), y, q2);
+                  } else {
+                    rad0 += thr0 * 0.5 / dl;
+                    rad1 += thr1 * 0.5 / dl;
+                    rad2 += thr2 * 0.5 / dl;
+                  }
                   if (L >= P.maxPathLength) break;
                   if (mul) { thr0 *= d0; thr1 *= d1; thr2 *= d2; }
                 }

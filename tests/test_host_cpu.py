@@ -128,3 +128,47 @@ def test_product_does_not_touch_the_oracle():
                 assert "mallie_oracle" not in txt and "oracle_lib" not in txt and "libmallie_oracle" not in txt, fn
     out = os.popen("ldd %s" % M.lib_path()).read()
     assert "oracle" not in out
+
+
+def test_tail_division_through_the_rounded_reciprocal_is_exact():
+    """k_render_sm evaluates the post-miss tail's x / L (L <= 16) as q = x * y, q' = fma(fma(-q, L, x), y, q) with
+    y = RN(1 / L) from the host (RenderParams::inv_len).  With a correctly rounded reciprocal that sequence yields the
+    correctly rounded quotient (Markstein); checked here against IEEE division with exact rational arithmetic, on throughput-
+    like values, random mantissas and mantissas next to the powers of two."""
+    import math
+    import random
+    from fractions import Fraction
+
+    def rn(fr):  # Fraction -> nearest double, ties to even
+        if fr == 0:
+            return 0.0
+        sign, fr = (-1 if fr < 0 else 1), abs(fr)
+        sh = 52 - (fr.numerator.bit_length() - fr.denominator.bit_length())
+        m = fr * (Fraction(2) ** sh)
+        if m < 2 ** 52:
+            sh, m = sh + 1, m * 2
+        if m >= 2 ** 53:
+            sh, m = sh - 1, m / 2
+        fl = m.numerator // m.denominator
+        rem = m - fl
+        if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and (fl & 1)):
+            fl += 1
+        return sign * math.ldexp(fl, -sh)
+
+    rng = random.Random(7)
+    for L in range(1, 17):
+        y = 1.0 / L
+        assert y == rn(Fraction(1, L))
+        for k in range(1500):
+            if k % 3 == 0:
+                a = rng.random() * 0.5 * (0.8 ** rng.randint(0, 16))
+            elif k % 3 == 1:
+                a = math.ldexp(rng.getrandbits(53) | (1 << 52), -53 - rng.randint(0, 40))
+            else:
+                m = (1 << 53) - 1 - rng.getrandbits(6) if rng.random() < 0.5 else (1 << 52) + rng.getrandbits(6)
+                a = math.ldexp(m, -53 - rng.randint(0, 20))
+            A = Fraction(a)
+            q = rn(A * Fraction(y))
+            r = A - Fraction(q) * L  # what fma(-q, L, a) returns: it is exactly representable
+            assert Fraction(rn(r)) == r
+            assert rn(Fraction(q) + r * Fraction(y)) == a / L, (a, L)
