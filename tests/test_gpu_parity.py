@@ -1295,3 +1295,25 @@ def test_fast_mode_c2_frame_within_north_star_distance():
         out[prec] = buf.cpu().numpy()
     rms, moved = _l2_stats(out["fp32"], out["fp64"], spp)
     assert rms <= 1e-4 and moved <= 1e-4, (rms, moved)
+
+
+@pytest.mark.parametrize("mpl", [3, 17, 40])
+def test_long_paths_take_the_dividing_tail(mpl):
+    """The post-miss tail has two forms: up to maxPathLength 16 (Render) / 32 (RenderPanoramic) it runs on the host's
+    reciprocals / tabulated sums, beyond that it divides as the reference does.  Both against the oracle, byte for byte with
+    equal counters, on both sides of each limit -- LDS- and HBM-resident scene, Render and RenderPanoramic."""
+    for name, eye, look in (("cornell_obj", (0, 0, 20), (0, 0, 0)), ("teapot_obj", (0.0, 40.0, 250.0), (0.0, 40.0, 0.0))):
+        sc, osc = gpu_scene(name), O.scene_from_golden(name)
+        W, H, passes = 72, 48, 2
+        frame = M.camera_frame(eye, look, width=W, height=H)
+        img, cnt, st = sc.render(frame, W, H, mpl, passes, sc.plane(), M.RNG_HASH, seed=4)
+        oimg, ocnt, ost, _ = osc.render(frame, W, H, mpl, passes, osc.plane(), O.RNG_HASH, seed=4)
+        assert img.tobytes() == oimg.tobytes() and cnt.tobytes() == ocnt.tobytes(), (name, mpl)
+        assert st["trace_calls"] == ost["trace_calls"] and st["real_rays"] == ost["real_rays"]
+    sc, osc = gpu_scene("cornell_obj"), O.scene_from_golden("cornell_obj")
+    origin = np.array([0.0, 1.0, 4.0])
+    for stereo in (0, 1):
+        img, cnt, st = sc.render_panoramic(origin, 96, 48, stereo, maxPathLength=mpl, samples=3, seed=2)
+        oimg, ocnt, ost, _ = osc.render_panoramic(origin, 96, 48, stereo, mpl, 3, O.RNG_HASH, seed=2)
+        assert img.tobytes() == oimg.tobytes() and cnt.tobytes() == ocnt.tobytes(), (stereo, mpl)
+        assert st["trace_calls"] == ost["trace_calls"] and st["real_rays"] == ost["real_rays"]
