@@ -1317,3 +1317,53 @@ def test_long_paths_take_the_dividing_tail(mpl):
         oimg, ocnt, ost, _ = osc.render_panoramic(origin, 96, 48, stereo, mpl, 3, O.RNG_HASH, seed=2)
         assert img.tobytes() == oimg.tobytes() and cnt.tobytes() == ocnt.tobytes(), (stereo, mpl)
         assert st["trace_calls"] == ost["trace_calls"] and st["real_rays"] == ost["real_rays"]
+
+
+def _chain_scene(n=44):
+    """n triangles along z under a hand-made BVH that is a chain: interior node k = {leaf of triangle k, interior k + 1},
+    depth n -- deeper than any stack's LDS part, with coordinates that stay inside the float range."""
+    from mallie_amd.mgpu import NODE_DT
+    rng = np.random.default_rng(5)
+    tri = np.zeros((n, 3, 3))
+    tri[:, :, 2] = np.arange(n)[:, None] * 1.5 + rng.random((n, 3))
+    tri[:, :, 0] = rng.random((n, 3)) * 3 - 1.5
+    tri[:, :, 1] = rng.random((n, 3)) * 3 - 1.5
+    verts, faces = tri.reshape(-1, 3), np.arange(3 * n, dtype="u4").reshape(n, 3)
+    lo, hi = tri.min(1), tri.max(1)
+    nodes = np.zeros(2 * n - 1, NODE_DT)  # interior k at 2k (k < n - 1), leaf k at 2k + 1, the last leaf at 2n - 2
+    for k in range(n - 1):
+        nodes[2 * k]["bmin"], nodes[2 * k]["bmax"] = lo[k:].min(0), hi[k:].max(0)
+        nodes[2 * k]["flag"], nodes[2 * k]["axis"] = 0, 2
+        nodes[2 * k]["data"] = (2 * k + 1, 2 * k + 2)
+        leaf = 2 * k + 1
+        nodes[leaf]["bmin"], nodes[leaf]["bmax"], nodes[leaf]["flag"], nodes[leaf]["data"] = lo[k], hi[k], 1, (1, k)
+    last = 2 * n - 2
+    nodes[last]["bmin"], nodes[last]["bmax"], nodes[last]["flag"], nodes[last]["data"] = lo[n - 1], hi[n - 1], 1, (1, n - 1)
+    return verts, faces, nodes, np.arange(n, dtype="u4")
+
+
+def test_fast_mode_on_a_tree_deeper_than_the_lds_stack():
+    """k_render_f32's HBM-resident variant with a tree deeper than its 32 LDS stack entries (per-lane overflow columns), seen
+    from the far end so that rays walk the whole chain: the same paths as the fp64 kernel -- itself equal to the oracle on
+    this scene --, rays within 1 %, a finite frame close to the fp64 one."""
+    import torch
+    verts, faces, nodes, idx = _chain_scene()
+    sc = M.Scene(verts, faces, None, None, None, nodes, idx)
+    osc = O.OracleScene(verts, faces, None, None, None, nodes, idx)
+    W, H, mpl, passes = 64, 48, 4, 4
+    frame = M.camera_frame((0.3, 0.2, 80.0), (0.0, 0.0, 0.0), width=W, height=H, fov=12.0)
+    out = {}
+    for prec in ("fp64", "fp32"):
+        sc.set_precision(prec)
+        buf = torch.full((H, W, 3), float("nan"), dtype=torch.float32, device="cuda")
+        st = sc.render_strips_device(frame, W, H, buf.data_ptr(), H, maxPathLength=mpl, passes=passes, plane=None, seed=2,
+                                     want_stats=True)
+        out[prec] = (buf.cpu().numpy(), st)
+    a, b = out["fp64"], out["fp32"]
+    oimg, _, ost, _ = osc.render(frame, W, H, mpl, passes, None, O.RNG_HASH, seed=2)
+    assert a[0].tobytes() == oimg.tobytes() and a[1]["nodes"] == ost["nodes"]
+    assert a[1]["nodes"] > 20 * a[1]["real_rays"]  # the rays do go deep
+    assert np.isfinite(b[0]).all() and b[1]["paths"] == a[1]["paths"] == W * H * passes
+    assert a[1]["real_rays"] > W * H * passes and abs(b[1]["real_rays"] - a[1]["real_rays"]) <= 0.01 * a[1]["real_rays"]
+    rms, moved = _l2_stats(b[0], a[0], passes)
+    assert rms <= 5e-3 and moved <= 0.02, (rms, moved)
