@@ -15,6 +15,8 @@
 #define MGPU_SAMPLE_MATH 1 // 0 = acos/sincos transcription, 1 = algebraically reduced evaluation (default)
 #endif
 
+#include "mgpu_sincos.hpp"
+
 namespace mgpu {
 
 constexpr uint32_t kNoMaterial = 0xFFFFFFFFu;
@@ -228,6 +230,15 @@ __device__ __forceinline__ bool origin_is_finite(V3 org) {
 struct Rng {
   uint32_t x, y, z, w;
 };
+// the 32-bit word randomreal() scales (render.cc:137-168)
+__device__ __forceinline__ uint32_t rng_next_u32(Rng &r) {
+  uint32_t t = r.x ^ (r.x << 11);
+  r.x = r.y;
+  r.y = r.z;
+  r.z = r.w;
+  r.w = (r.w ^ (r.w >> 19)) ^ (t ^ (t >> 8));
+  return r.w;
+}
 // randomreal(), render.cc:137-168
 __device__ __forceinline__ double rng_next(Rng &r) {
   uint32_t t = r.x ^ (r.x << 11);
@@ -620,7 +631,9 @@ __device__ __forceinline__ bool plane_hit(const float pl[4], const double unit_n
 }
 
 // ---- GenerateBasis + SampleDiffuseIS (render.cc:271-339) ------------------------------------------------------------------
-__device__ __forceinline__ V3 sample_diffuse(V3 n, Rng &rng) {
+// `azimuth`: null = the device library's sincospi; a table in LDS = sincos_turn (mgpu_sincos.hpp), the same two numbers to
+// 2e-16 for a quarter of the instructions (k_render_sm).
+__device__ __forceinline__ V3 sample_diffuse(V3 n, Rng &rng, const SincosTable *azimuth = nullptr) {
   // Minor axis by |n[i]| compared after rounding to float (fabsf); the loop of render.cc:279-285 keeps the FIRST
   // strict minimum below 1e6, and an index that stays -1 (NaN / huge normal) takes the final else branch.
   // Written as boolean selects, not as an int index + if/else-if chain: hipcc (ROCm 7.2, clang 22) lowers that
@@ -643,7 +656,8 @@ __device__ __forceinline__ V3 sample_diffuse(V3 n, Rng &rng) {
   // theta = acos(sqrt(1 - u1)), phi = 2*pi*u2 (render.cc:325-326); only sin/cos of the two angles are ever used.
   // = cos(theta) before the reference's acos -> cos round trip; the argument is 1 - k / 2^32 >= 2^-32
   const double x = sqrt_core(1.0 - rng_next(rng));
-  const double u2 = rng_next(rng);
+  const uint32_t k2 = rng_next_u32(rng);
+  const double u2 = k2 * (1.0 / 4294967296.0);
   double sin_theta, cos_theta, sin_phi, cos_phi;
 #if MGPU_SAMPLE_MATH == 0
   // literal transcription: device acos / sincos of the same arguments (<= 1 ulp from glibc's results)
@@ -660,7 +674,8 @@ __device__ __forceinline__ V3 sample_diffuse(V3 n, Rng &rng) {
   const double s2 = fma(-x, x, 1.0); // >= 2^-53 or exactly 0 (u1 == 0)
   if (__builtin_expect(__ballot(!(s2 > 0x1p-100)) != 0ull, 0)) sin_theta = sqrt(s2);
   else sin_theta = sqrt_core(s2);
-  sincospi(2.0 * u2, &sin_phi, &cos_phi);
+  if (azimuth) sincos_turn(k2, *azimuth, sin_phi, cos_phi);
+  else sincospi(2.0 * u2, &sin_phi, &cos_phi);
 #endif
   const V3 T = scale(scale(t, cos_phi), sin_theta);
   const V3 B = scale(scale(b, sin_phi), sin_theta);

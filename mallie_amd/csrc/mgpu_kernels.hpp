@@ -163,6 +163,6 @@ void launch_layout_f32(hipStream_t s, const MgpuNode *nodes, size_t nn, const DT
                        int has_fv, const double *mat_diffuse, uint32_t nm, FNode *fnodes, FTri *ftris, float *fnormals, float *fdiffuse);
 hipError_t launch_render_f32(int cap, bool lds_scene, dim3 grid, hipStream_t s, size_t shmem, const FScene &sc, const RenderParams &p);
 void launch_tonemap(hipStream_t s, const float *image, const int32_t *count, size_t npix, int mode, unsigned char *out);
-constexpr size_t kLdsBudget = 160 * 1024 - 2048; // bytes of LDS per CU on gfx950, less the kernels' static part (launch parameters, cursor words, leaf tables: up to 1.4 KB)
+constexpr size_t kLdsBudget = 160 * 1024 - 3072; // bytes of LDS per CU on gfx950, less the kernels' static part (launch parameters, cursor words, leaf tables, the sampler's azimuth table: up to 2.6 KB)
 
 } // namespace mgpu

@@ -53,8 +53,10 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
   __shared__ EnvParams s_P; // launch parameters live in LDS, not in scalar registers (see k_render_sm)
   __shared__ unsigned long long s_cnt[5];
   __shared__ unsigned char s_owner[BLOCK]; // TRI step with shared leaves: lane of the k-th open leaf, per wave
+  __shared__ SincosTable s_azimuth;        // the cosine sampler's azimuth table (mgpu_sincos.hpp)
   if (threadIdx.x == 0) s_P = P_arg;
   if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0ull;
+  sincos_table_fill(s_azimuth, threadIdx.x, BLOCK);
   __syncthreads();
   const EnvParams &P = s_P;
   uint32_t *s_stack = reinterpret_cast<uint32_t *>(smem); // [waves][CAP][64]
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
             (void)rng_next(rng); // `double r = randomreal();` drawn and never used (render.cc:563)
             const double ndoti = dot(n, neg(dir));
             if (ndoti < 0.0) n = neg(n);
-            const V3 sd = sample_diffuse(n, rng);
+            const V3 sd = sample_diffuse(n, rng, &s_azimuth);
             org = hitP + scale(sd, 1.0e-3);
             dir = sd;
             ++pathLength;

@@ -94,6 +94,9 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 #ifndef MGPU_WIDE_PER_STEP
 #define MGPU_WIDE_PER_STEP 3 // interior nodes entered per NODE step with the BVH in HBM (two box tests each)
 #endif
+#ifndef MGPU_SINCOS_TURN
+#define MGPU_SINCOS_TURN 1
+#endif
 #ifndef MGPU_TAIL_RECIP
 #define MGPU_TAIL_RECIP 1
 #endif
@@ -117,7 +120,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
   // The launch parameters live in LDS, not in scalar registers: the traversal bodies use none of them, SHADE uses
   // nearly all, and ~60 kernel-argument SGPRs kept alive across the loop were being spilled to VGPR lanes.
   __shared__ RenderParams s_P;
+  __shared__ SincosTable s_azimuth; // the cosine sampler's azimuth table (mgpu_sincos.hpp)
   if (threadIdx.x == 0) s_P = P_arg;
+  if (MGPU_SINCOS_TURN) sincos_table_fill(s_azimuth, threadIdx.x, BLOCK);
   __syncthreads();
   const RenderParams &P = s_P;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -563,7 +568,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
             (void)rng_next(rng); // `double r = randomreal();` drawn and never used (render.cc:430)
             const double ndoti = dot(n, neg(dir));
             if (ndoti < 0.0) n = neg(n);
-            const V3 sd = sample_diffuse(n, rng);
+            const V3 sd = sample_diffuse(n, rng, MGPU_SINCOS_TURN ? &s_azimuth : nullptr);
             if (last_mat != kNoMaterial) { // Scene::GetMaterial, scene.h:58-65
               if ((size_t)(int)last_mat < (size_t)sc.nm) {
                 thr0 *= sc.mat_diffuse[3 * (size_t)last_mat + 0];
