@@ -119,6 +119,8 @@ int mgpu_scene_set_precision(MgpuScene *scene, int precision);
 int mgpu_scene_bbox(const MgpuScene *scene, double bmin[3], double bmax[3]);
 /* Bytes resident on the device for this scene. */
 size_t mgpu_scene_device_bytes(const MgpuScene *scene);
+/* The HIP device the scene was created on (-1 for NULL). */
+int mgpu_scene_device(const MgpuScene *scene);
 
 /* -- batched Scene::Trace (scene.cc:253-315 -> BVHAccel::Traverse, bvh_accel.cc:773-844) ------------------------------ */
 /* For each of n rays: out[i] = the Intersection Traverse would fill, hit[i] = its bool result. On a miss out[i] has
@@ -221,7 +223,14 @@ int mgpu_render_frames_device(MgpuScene *scene, const double frame[12], int W, i
  *    at all for one GPU.  Up to 8 frames may be in flight (own streams and buffers each): mgpu_frame_render only
  *    enqueues, mgpu_frame_wait blocks until a slot's frame is complete. -------------------------------------------------- */
 typedef struct MgpuFrame MgpuFrame;
-/* One process driving n GPUs (ncclCommInitAll): scenes[r] lives on devices[r] and becomes rank r. */
+/* How the strips travel to rank 0 (MGPU_FRAME_EXCHANGE=block|strips when the frame is created; default block):
+ *   MGPU_EXCHANGE_BLOCK   a rank's strip buffer is ONE message into a staging area on rank 0; one strided device copy per
+ *                         rank deals it to the strips' final rows (world - 1 receives + as many 2-D copies per frame)
+ *   MGPU_EXCHANGE_STRIPS  one send / receive pair per strip, received at its final rows (no staging; 118 pairs per 1080p
+ *                         frame at eight ranks, 236 at 3840x2160) */
+enum { MGPU_EXCHANGE_BLOCK = 0, MGPU_EXCHANGE_STRIPS = 1 };
+/* One process driving n GPUs (ncclCommInitAll): scenes[r] must live on devices[r] (MGPU_ERR_INVALID otherwise) and becomes
+ * rank r. */
 int mgpu_frame_create(MgpuScene *const *scenes, const int *devices, int n, int W, int H, int strip_h, int frames_in_flight,
                       MgpuFrame **out);
 /* One process per GPU (ncclCommInitRank): `id` = the 128 bytes mgpu_frame_unique_id produced on ONE rank, distributed by the
@@ -231,7 +240,9 @@ int mgpu_frame_create_rank(MgpuScene *scene, int device, int rank, int world, co
                            int strip_h, int frames_in_flight, MgpuFrame **out);
 int mgpu_frame_destroy(MgpuFrame *frame);
 /* Enqueues one frame of `passes` passes (camera frame as mgpu_camera_frame; plane NULL = off; rng_mode MGPU_RNG_HASH) on
- * the next slot and returns that slot's index.  Collective across the ranks of a multi-process frame. */
+ * the next slot and returns that slot's index.  Collective across the ranks of a multi-process frame.  A render call that
+ * fails leaves the frame object unusable (work already enqueued on some GPUs and not on others): every later call on it
+ * except mgpu_frame_destroy returns MGPU_ERR_INVALID. */
 int mgpu_frame_render(MgpuFrame *frame, const double cam[12], int maxPathLength, int passes, const float plane[4],
                       int rng_mode, uint64_t seed, uint32_t pass_base, int *slot_out);
 /* n_frames (<= frames_in_flight) consecutive frames -- frame i renders passes pass_base + i * passes ... -- rendered by ONE
@@ -242,6 +253,19 @@ int mgpu_frame_render_batch(MgpuFrame *frame, const double cam[12], int maxPathL
 /* Waits for the frame of `slot`.  On the process that holds rank 0: *device_image (nullable) receives the device pointer
  * of the H x W x 3 float frame (valid until the slot is used again), host_image (nullable) a copy of it. */
 int mgpu_frame_wait(MgpuFrame *frame, int slot, float *host_image, float **device_image);
+/* What the frame object knows about itself and its exchange step: `rccl_ranks` is read back from the communicator
+ * (ncclCommCount; 0 when no communicator exists, i.e. one GPU without MGPU_FRAME_FORCE_EXCHANGE); `exchange_ms` is the device
+ * time of the exchange steps (grouped sends / receives + the placement copies) of `exchange_frames` frames, from HIP events
+ * on rank 0's communicator stream -- only on the process that holds rank 0, and only for frames whose slot was waited for or
+ * reused after their exchange had finished.  Waits for exchanges still in flight.  reset != 0 zeroes the sums. */
+typedef struct {
+  int world, members, rccl_ranks, exchange_mode;
+  uint64_t frames;                 /* frames enqueued so far                                  */
+  uint64_t exchange_frames;        /* frames whose exchange step was timed                    */
+  uint64_t exchange_ops_per_frame; /* receives rank 0 posts per frame                         */
+  double exchange_ms;              /* summed over exchange_frames                             */
+} MgpuFrameStats;
+int mgpu_frame_stats(MgpuFrame *frame, MgpuFrameStats *out, int reset);
 /* Makes `stream` (a hipStream_t on rank 0's device) wait for the slot's frame without blocking the host. */
 int mgpu_frame_done_event_wait(MgpuFrame *frame, int slot, void *stream);
 /* Rows of a W x H frame that rank `rank` of `world` owns with strips of strip_h rows (-1 on bad arguments). */

@@ -14,6 +14,8 @@
 #include <cstring>
 #include <new>
 #include <mutex>
+#include <queue>
+#include <unordered_map>
 #include <vector>
 
 #include "mgpu_kernels.hpp"
@@ -84,7 +86,7 @@ struct MgpuScene {
   void *p_nodes = nullptr, *p_tris = nullptr, *p_slotn = nullptr, *p_mat = nullptr, *p_verts = nullptr,
        *p_fnodes = nullptr, *p_ftris = nullptr, *p_fnormals = nullptr, *p_fdiffuse = nullptr, // fast mode (float copies)
        *p_faces = nullptr, *p_fvn = nullptr, *p_fvuv = nullptr, *p_overflow = nullptr, *p_wnodes = nullptr,
-       *p_woverflow = nullptr;
+       *p_woverflow = nullptr, *p_treelet = nullptr;
   size_t overflow_lanes = 0, woverflow_lanes = 0;
   uint32_t *p_counters = nullptr;         // kCounterRing work counters
   unsigned long long *p_stats = nullptr;  // kStatWords
@@ -164,6 +166,61 @@ int tree_depth(const MgpuNode *nodes, size_t nn, size_t nf, int *depth_out, bool
   }
   *depth_out = depth;
   return MGPU_OK; // *boxes_ordered was initialised by the caller
+}
+
+// The treelet of the HBM-resident render kernel (mgpu_device.hpp, kWTreelet): wide records of the super root and of the
+// interior nodes with the largest boxes -- a ray enters a node with a probability roughly proportional to its box's surface
+// area -- taken parent before child, so the table is closed under "parent of".  The records are what k_wide_layout writes
+// (boxes verbatim), except that references to children which are in the table too carry kWTreelet | their index there.
+constexpr size_t kTreeletMaxRecords = (kLdsBudget - 16 * WStack<kWideStackLds>::kWaveBytes) / sizeof(WNode);
+void build_treelet(const MgpuNode *nodes, size_t nn, size_t max_records, std::vector<WNode> &out) {
+  out.clear();
+  auto area = [&](uint32_t i) -> double {
+    const MgpuNode &n = nodes[i];
+    const double dx = n.bmax[0] - n.bmin[0], dy = n.bmax[1] - n.bmin[1], dz = n.bmax[2] - n.bmin[2];
+    const double a = dx * dy + dy * dz + dz * dx;
+    return a == a ? a : 0.0;
+  };
+  std::vector<uint32_t> picked; // node indices, in table order after the super root
+  std::unordered_map<uint32_t, uint32_t> local; // node index -> table index
+  std::priority_queue<std::pair<double, uint32_t>> heap;
+  if (nodes[0].flag == 0) heap.push({area(0), 0u});
+  while (!heap.empty() && picked.size() + 1 < max_records) {
+    const uint32_t g = heap.top().second;
+    heap.pop();
+    local[g] = (uint32_t)picked.size() + 1u;
+    picked.push_back(g);
+    for (int k = 0; k < 2; ++k) {
+      const uint32_t c = nodes[g].data[k];
+      if (nodes[c].flag == 0) heap.push({area(c), c});
+    }
+  }
+  auto child = [&](uint32_t c, double *box, uint32_t &ref, uint32_t &tag) {
+    const MgpuNode &n = nodes[c];
+    for (int k = 0; k < 3; ++k) {
+      box[k] = n.bmin[k];
+      box[3 + k] = n.bmax[k];
+    }
+    if (n.flag == 0) {
+      const auto it = local.find(c);
+      ref = it != local.end() ? (kWTreelet | it->second) : c;
+      tag = kWInterior;
+    } else {
+      ref = n.data[1];
+      tag = n.data[0];
+    }
+  };
+  out.resize(picked.size() + 1);
+  memset(out.data(), 0, out.size() * sizeof(WNode));
+  child(0u, out[0].box0, out[0].ref0, out[0].tag0); // the super root, as k_wide_layout writes it
+  for (int k = 0; k < 6; ++k) out[0].box1[k] = kDblMax;
+  for (size_t i = 0; i < picked.size(); ++i) {
+    WNode &w = out[i + 1];
+    const MgpuNode &n = nodes[picked[i]];
+    child(n.data[0], w.box0, w.ref0, w.tag0);
+    child(n.data[1], w.box1, w.ref1, w.tag1);
+    w.tag0 |= (uint32_t)n.axis << 30;
+  }
 }
 
 int set_device(const MgpuScene *s) {
@@ -428,6 +485,19 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
   s->d.nodes = (const MgpuNode *)s->p_nodes;
   s->d.wnodes = (const WNode *)s->p_wnodes;
   s->d.wroot = (uint32_t)nn;
+  s->d.treelet = nullptr;
+  s->d.treelet_n = 0;
+  if (nn < 0x80000000ull && nf < 0x80000000ull) { // the flag bit of a treelet reference must be free in every other reference
+    size_t max_records = kTreeletMaxRecords;
+    if (const char *e = getenv("MGPU_TREELET")) max_records = atoll(e) < 0 ? 0 : std::min<size_t>((size_t)atoll(e), kTreeletMaxRecords);
+    if (max_records >= 1) {
+      std::vector<WNode> tl;
+      build_treelet(nodes, nn, max_records, tl);
+      TRY_OR_FREE(upload(s, &s->p_treelet, tl.data(), tl.size() * sizeof(WNode)));
+      s->d.treelet = (const WNode *)s->p_treelet;
+      s->d.treelet_n = (uint32_t)tl.size();
+    }
+  }
   s->d.wstack_overflow = nullptr;
   s->d.woverflow_cap = 0;
   s->d.tris = (const DTri *)s->p_tris;
@@ -462,7 +532,7 @@ int mgpu_scene_destroy(MgpuScene *s) {
   (void)hipDeviceSynchronize();
   void *ptrs[] = {s->p_nodes, s->p_tris, s->p_slotn, s->p_mat, s->p_verts, s->p_faces, s->p_fvn, s->p_fvuv,
                   s->p_overflow, s->p_counters, s->p_stats, s->p_wave_log, s->p_host_img, s->p_trace, s->p_wnodes,
-                  s->p_woverflow, s->p_fnodes, s->p_ftris, s->p_fnormals, s->p_fdiffuse};
+                  s->p_woverflow, s->p_fnodes, s->p_ftris, s->p_fnormals, s->p_fdiffuse, s->p_treelet};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (s->p_trace_pinned) (void)hipHostFree(s->p_trace_pinned);
@@ -507,6 +577,8 @@ int mgpu_scene_bbox(const MgpuScene *s, double bmin[3], double bmax[3]) {
 }
 
 size_t mgpu_scene_device_bytes(const MgpuScene *s) { return s ? s->device_bytes : 0; }
+
+int mgpu_scene_device(const MgpuScene *s) { return s ? s->device : -1; }
 
 int mgpu_trace_device(MgpuScene *s, const MgpuRay *d_rays, size_t n, MgpuIntersection *d_out, uint8_t *d_hit, void *stream,
                       MgpuStats *stats) {
@@ -742,8 +814,12 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
       shmem += scene_lds;
     }
   }
-  if (kern == 1) shmem = (size_t)(block / 64) * WStack<kWideStackLds>::kWaveBytes; // wide traversal: far-child stack
-  int per_cu = kern == 2 ? 1 : (kern == 1 ? 4 : 2); // workgroups per CU: 16 waves per CU for the state-machine kernels
+  // BVH in HBM: the wide traversal's far-child stacks, and -- one 1024-thread workgroup per CU instead of four of 256 -- the
+  // treelet of the scene behind them (mgpu_device.hpp, kWTreelet)
+  const bool treelet = kern == 1 && s->d.treelet != nullptr;
+  if (treelet) block = 1024;
+  if (kern == 1) shmem = (size_t)(block / 64) * WStack<kWideStackLds>::kWaveBytes + (treelet ? (size_t)s->d.treelet_n * sizeof(WNode) : 0);
+  int per_cu = kern == 2 || treelet ? 1 : (kern == 1 ? 4 : 2); // workgroups per CU: 16 waves per CU for the state-machine kernels
   // fast mode (mgpu_scene_set_precision): k_render_f32 on the float copy of the scene -- 32-byte nodes and 48-byte
   // triangles, so scenes twice the size still fit in LDS beside the stacks
   bool f32_lds = false;
@@ -845,6 +921,7 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
   P.stats = s->p_stats;
   P.lds_nodes_bytes = (uint32_t)(sizeof(MgpuNode) * s->nn);
   P.lds_tris_bytes = (uint32_t)(sizeof(DTri) * s->nf);
+  if (treelet) P.lds_nodes_bytes = (uint32_t)(sizeof(WNode) * s->d.treelet_n); // what the HBM-resident kernel stages into LDS
   FScene fsc{};
   if (kern == 3) {
     P.lds_nodes_bytes = (uint32_t)(sizeof(FNode) * s->nn);

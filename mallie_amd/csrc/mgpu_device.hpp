@@ -52,11 +52,19 @@ struct alignas(16) WNode {
 static_assert(sizeof(WNode) == 128, "WNode must be 128 bytes (one L2 line)");
 constexpr uint32_t kWInterior = 0x3FFFFFFFu;
 constexpr uint32_t kWNone = 0xFFFFFFFFu;
+// Treelet (k_render_sm with the BVH in HBM): copies of the records of the interior nodes a ray is most likely to enter -- the top
+// of the tree, chosen by box surface area when the scene is created -- held in LDS beside the far-child stacks.  A record
+// reference with this bit set is an index into that table; inside the table, references to children that are in the table
+// too carry the bit, all others are the node indices they always were (the table is closed under "parent of": once a walk
+// has left it, it never comes back).  Same records, same decisions, same counts; only where the bytes come from changes.
+constexpr uint32_t kWTreelet = 0x80000000u;
 
 struct DScene {
   const MgpuNode *nodes;     // reference 64-byte layout, uploaded verbatim
   const WNode *wnodes;       // nn + 1 wide records (k_wide_layout); record nn is the super root
   uint32_t wroot;            // = nn
+  const WNode *treelet;      // treelet_n records, [0] = the super root (see kWTreelet); null when the scene has none
+  uint32_t treelet_n;
   uint4 *wstack_overflow;    // wide traversal: far-child stack entries beyond the LDS part, per hardware lane slot
   uint32_t woverflow_cap;    // entries per lane (0: the tree is shallow enough for the LDS part alone)
   const DTri *tris;          // nf entries, slot order
@@ -340,11 +348,13 @@ enum : int { WT_NODE = 0, WT_TRI = 1, WT_DONE = 2 };
 // Up to REPS interior nodes for the calling lane.  `cur` = record to enter next (kWNone: take one from the stack), `sp` =
 // entries on the stack.  Returns WT_TRI with [tri_cur, tri_end) set when a leaf was opened, WT_DONE when the stack ran
 // empty, WT_NODE when the repetitions are used up.  n_nodes += 2 per record entered.
-template <bool kPlain, int REPS, int K>
+// TL: references with kWTreelet set are read from the treelet table at `tl` in LDS.
+template <bool kPlain, int REPS, int K, bool TL = false>
 __device__ __forceinline__ int wide_node_step(const WNode *__restrict__ wn, const WStack<K> &stk, V3 org, double ix,
                                               double iy, double iz, bool sx, bool sy, bool sz, uint32_t sgn /* sx | sy << 1 | sz << 2 */,
                                               double bt, uint32_t &cur,
-                                              int &sp, uint32_t &tri_cur, uint32_t &tri_end, uint32_t &n_nodes) {
+                                              int &sp, uint32_t &tri_cur, uint32_t &tri_end, uint32_t &n_nodes,
+                                              const unsigned char *tl = nullptr) {
   int res = WT_NODE;
 #pragma unroll 1
   for (int rep = 0; rep < REPS; ++rep) {
@@ -374,10 +384,29 @@ __device__ __forceinline__ int wide_node_step(const WNode *__restrict__ wn, cons
       }
       cur = ref;
     }
-    const WNode *r = wn + cur;
-    const double2 *q = reinterpret_cast<const double2 *>(r);
-    const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5];
-    uint4 m = *reinterpret_cast<const uint4 *>(&r->ref0);
+    double2 a0, a1, a2, a3, a4, a5;
+    uint4 m;
+    if (TL && (cur & kWTreelet) != 0u) {
+      // an LDS address in its own address space, and an opaque statement in this branch only: otherwise hipcc folds the two
+      // branches into ONE flat_load from a selected address (see Stack above), which is neither an LDS nor a global load
+      typedef __attribute__((address_space(3))) const unsigned char lds_byte;
+      typedef double lds_d2 __attribute__((ext_vector_type(2)));
+      typedef uint32_t lds_u4 __attribute__((ext_vector_type(4)));
+      lds_byte *r = (lds_byte *)tl + (cur & ~kWTreelet) * (uint32_t)sizeof(WNode);
+      const lds_d2 l0 = *(__attribute__((address_space(3))) const lds_d2 *)(r), l1 = *(__attribute__((address_space(3))) const lds_d2 *)(r + 16),
+                   l2 = *(__attribute__((address_space(3))) const lds_d2 *)(r + 32), l3 = *(__attribute__((address_space(3))) const lds_d2 *)(r + 48),
+                   l4 = *(__attribute__((address_space(3))) const lds_d2 *)(r + 64), l5 = *(__attribute__((address_space(3))) const lds_d2 *)(r + 80);
+      const lds_u4 lm = *(__attribute__((address_space(3))) const lds_u4 *)(r + 96);
+      a0 = make_double2(l0.x, l0.y); a1 = make_double2(l1.x, l1.y); a2 = make_double2(l2.x, l2.y);
+      a3 = make_double2(l3.x, l3.y); a4 = make_double2(l4.x, l4.y); a5 = make_double2(l5.x, l5.y);
+      m = make_uint4(lm.x, lm.y, lm.z, lm.w);
+      asm volatile("" : "+v"(m.x));
+    } else {
+      const WNode *r = wn + cur;
+      const double2 *q = reinterpret_cast<const double2 *>(r);
+      a0 = q[0]; a1 = q[1]; a2 = q[2]; a3 = q[3]; a4 = q[4]; a5 = q[5];
+      m = *reinterpret_cast<const uint4 *>(&r->ref0);
+    }
     // all seven loads of the record are issued together (the compiler would sink the last behind the box tests)
     asm volatile("" : "+v"(m.x), "+v"(m.y), "+v"(m.z), "+v"(m.w));
     n_nodes += 2;

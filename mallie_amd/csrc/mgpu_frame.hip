@@ -13,7 +13,6 @@
 // flight (the next frame's kernel runs under the previous frame's exchange and drain).
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -22,6 +21,17 @@
 #include <vector>
 
 #include "../../include/mgpu.h"
+
+// The handful of RCCL declarations this file needs, written out so that the library builds where the RCCL headers are not
+// installed (single-GPU users never load RCCL at all): rccl.h, `ncclUniqueId` / `ncclResult_t` / `ncclDataType_t`.
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;   // ncclSuccess = 0
+typedef int ncclDataType_t; // ncclFloat32 = 7
+}
+constexpr ncclResult_t ncclSuccess = 0, ncclUnhandledCudaError = 1;
+constexpr ncclDataType_t ncclFloat = 7;
 
 namespace {
 
@@ -46,6 +56,7 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -71,6 +82,7 @@ int load_rccl() {
   SYM(CommInitRank, "ncclCommInitRank");
   SYM(CommInitAll, "ncclCommInitAll");
   SYM(CommDestroy, "ncclCommDestroy");
+  SYM(CommCount, "ncclCommCount");
   SYM(GroupStart, "ncclGroupStart");
   SYM(GroupEnd, "ncclGroupEnd");
   SYM(Send, "ncclSend");
@@ -94,7 +106,10 @@ struct Slot {
   hipStream_t stream = nullptr; // render stream of this slot
   float *local = nullptr;       // this rank's strips, local rows contiguous (n_rows x W x 3)
   float *frame = nullptr;       // rank 0 only: the whole frame (H x W x 3)
+  float *staging = nullptr;     // rank 0 only, block exchange: the other ranks' strip buffers as they arrive, rank after rank
   hipEvent_t rendered = nullptr, exchanged = nullptr;
+  hipEvent_t x0 = nullptr, x1 = nullptr; // rank 0: the exchange step of this slot's frame on the communicator stream (timed)
+  bool x_pending = false;                // x0 / x1 were recorded and not read yet
 };
 
 struct Member { // one GPU of this process
@@ -111,8 +126,17 @@ struct Member { // one GPU of this process
 struct MgpuFrame {
   int world = 1, W = 0, H = 0, strip_h = 8, in_flight = 1;
   bool force_exchange = false; // world == 1: send the strips to ourselves through RCCL (exercises the N > 1 path on one GPU)
+  // How the strips travel.  BLOCK (default): a rank's strip buffer is ONE message into a staging area on rank 0, which a
+  // strided device copy per rank deals to the strips' final rows -- world - 1 receives and as many 2-D copies per frame.
+  // STRIPS: one send / receive pair per strip, received at its final rows -- no staging, but 118 (1080p) or 236 (4K) pairs
+  // per frame at eight ranks.  MGPU_FRAME_EXCHANGE=strips|block; measured in profiles/ (DESIGN.md 6).
+  int exchange_mode = MGPU_EXCHANGE_BLOCK;
   std::vector<Member> members;  // the ranks this process drives (all of them, or one)
   unsigned long long next = 0;  // frames enqueued so far
+  // exchange timing (rank 0's communicator stream): summed when a slot is waited for or reused
+  double x_ms_sum = 0.0;
+  unsigned long long x_frames = 0, x_ops = 0; // frames measured; receives rank 0 posts per frame
+  bool broken = false; // a render call failed half-way: streams and slots are out of step, only destroy is allowed
 };
 
 namespace {
@@ -140,7 +164,15 @@ void plan_of(int W, int H, int strip_h, int world, int owner, std::vector<Piece>
   }
 }
 
+// rows the block exchange stages on rank 0: every other rank's (with the exchange forced on one GPU: its own)
+size_t staging_rows(const MgpuFrame *f) {
+  size_t rows = 0;
+  for (int r = f->force_exchange ? 0 : 1; r < f->world; ++r) rows += (size_t)rows_of(f->H, f->strip_h, f->world, r);
+  return rows;
+}
+
 int create_common(MgpuFrame *f) {
+  const bool exchange = f->world > 1 || f->force_exchange;
   for (Member &m : f->members) {
     FHIP(hipSetDevice(m.device));
     m.n_rows = rows_of(f->H, f->strip_h, f->world, m.rank);
@@ -151,10 +183,49 @@ int create_common(MgpuFrame *f) {
       FHIP(hipEventCreateWithFlags(&s.rendered, hipEventDisableTiming));
       FHIP(hipEventCreateWithFlags(&s.exchanged, hipEventDisableTiming));
       if (m.n_rows) FHIP(hipMalloc((void **)&s.local, sizeof(float) * 3 * (size_t)m.n_rows * f->W));
-      if (m.rank == 0) FHIP(hipMalloc((void **)&s.frame, sizeof(float) * 3 * (size_t)f->H * f->W));
+      if (m.rank == 0) {
+        FHIP(hipMalloc((void **)&s.frame, sizeof(float) * 3 * (size_t)f->H * f->W));
+        FHIP(hipEventCreate(&s.x0));
+        FHIP(hipEventCreate(&s.x1));
+        if (exchange && f->exchange_mode == MGPU_EXCHANGE_BLOCK && staging_rows(f))
+          FHIP(hipMalloc((void **)&s.staging, sizeof(float) * 3 * staging_rows(f) * f->W));
+      }
     }
   }
   return MGPU_OK;
+}
+
+// local strips of `rows` rows (strip j at local rows [j * sh, ...)) to their final rows of rank `owner` in `frame`: one
+// strided copy for the full strips, one plain copy for a partial last strip
+int place_strips(float *frame, const float *local, int rows, int owner, int world, int sh, int W, hipStream_t st) {
+  const size_t strip_floats = (size_t)3 * sh * W;
+  const int full = rows / sh, tail = rows - full * sh;
+  float *dst = frame + (size_t)owner * strip_floats;
+  if (full)
+    FHIP(hipMemcpy2DAsync(dst, sizeof(float) * strip_floats * world, local, sizeof(float) * strip_floats, sizeof(float) * strip_floats,
+                          (size_t)full, hipMemcpyDeviceToDevice, st));
+  if (tail)
+    FHIP(hipMemcpyAsync(dst + (size_t)full * world * strip_floats, local + (size_t)full * strip_floats, sizeof(float) * 3 * (size_t)tail * W,
+                        hipMemcpyDeviceToDevice, st));
+  return MGPU_OK;
+}
+
+// reads a finished slot's exchange timing into the frame's sums (rank 0's member only)
+void collect_timing(MgpuFrame *f, Slot &s, bool wait) {
+  if (!s.x_pending) return;
+  if (!wait && hipEventQuery(s.x1) != hipSuccess) { // still running: this frame's time is not booked
+    (void)hipGetLastError();
+    s.x_pending = false;
+    return;
+  }
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, s.x0, s.x1) == hipSuccess) {
+    f->x_ms_sum += ms;
+    f->x_frames += 1;
+  } else {
+    (void)hipGetLastError();
+  }
+  s.x_pending = false;
 }
 
 } // namespace
@@ -200,8 +271,11 @@ int mgpu_frame_destroy(MgpuFrame *f) {
     for (Slot &s : m.slot) {
       if (s.local) (void)hipFree(s.local);
       if (s.frame) (void)hipFree(s.frame);
+      if (s.staging) (void)hipFree(s.staging);
       if (s.rendered) (void)hipEventDestroy(s.rendered);
       if (s.exchanged) (void)hipEventDestroy(s.exchanged);
+      if (s.x0) (void)hipEventDestroy(s.x0);
+      if (s.x1) (void)hipEventDestroy(s.x1);
       if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     if (m.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m.comm);
@@ -225,13 +299,30 @@ static int frame_new(int world, int W, int H, int strip_h, int frames_in_flight,
   f->strip_h = strip_h;
   f->in_flight = frames_in_flight;
   if (const char *e = getenv("MGPU_FRAME_FORCE_EXCHANGE")) f->force_exchange = world == 1 && atoi(e) != 0;
+  if (const char *e = getenv("MGPU_FRAME_EXCHANGE")) {
+    if (!strcmp(e, "strips")) f->exchange_mode = MGPU_EXCHANGE_STRIPS;
+    else if (!strcmp(e, "block")) f->exchange_mode = MGPU_EXCHANGE_BLOCK;
+    else {
+      delete f;
+      return ffail(MGPU_ERR_INVALID, "MGPU_FRAME_EXCHANGE=%s (expected strips|block)", e);
+    }
+  }
   *out = f;
   return MGPU_OK;
 }
 
 int mgpu_frame_create(MgpuScene *const *scenes, const int *devices, int n, int W, int H, int strip_h, int frames_in_flight,
                       MgpuFrame **out) {
+  if (!out) return ffail(MGPU_ERR_INVALID, "out is NULL");
+  *out = nullptr;
   if (!scenes || !devices || n < 1) return ffail(MGPU_ERR_INVALID, "scenes / devices must name at least one GPU");
+  for (int r = 0; r < n; ++r) {
+    if (!scenes[r]) return ffail(MGPU_ERR_INVALID, "scenes[%d] is NULL", r);
+    if (mgpu_scene_device(scenes[r]) != devices[r])
+      return ffail(MGPU_ERR_INVALID, "scenes[%d] lives on device %d, not on devices[%d] = %d", r, mgpu_scene_device(scenes[r]), r, devices[r]);
+    for (int q = 0; q < r; ++q)
+      if (devices[q] == devices[r]) return ffail(MGPU_ERR_INVALID, "device %d is named twice", devices[r]);
+  }
   MgpuFrame *f = nullptr;
   int rc = frame_new(n, W, H, strip_h, frames_in_flight, &f);
   if (rc) return rc;
@@ -266,7 +357,10 @@ int mgpu_frame_create(MgpuScene *const *scenes, const int *devices, int n, int W
 
 int mgpu_frame_create_rank(MgpuScene *scene, int device, int rank, int world, const unsigned char id[128], int W, int H,
                            int strip_h, int frames_in_flight, MgpuFrame **out) {
+  if (!out) return ffail(MGPU_ERR_INVALID, "out is NULL");
+  *out = nullptr;
   if (!scene || rank < 0 || rank >= world) return ffail(MGPU_ERR_INVALID, "bad scene / rank");
+  if (mgpu_scene_device(scene) != device) return ffail(MGPU_ERR_INVALID, "the scene lives on device %d, not on device %d", mgpu_scene_device(scene), device);
   if (world > 1 && !id) return ffail(MGPU_ERR_INVALID, "a communicator id is needed for world > 1 (mgpu_frame_unique_id on one rank)");
   MgpuFrame *f = nullptr;
   int rc = frame_new(world, W, H, strip_h, frames_in_flight, &f);
@@ -298,22 +392,25 @@ int mgpu_frame_create_rank(MgpuScene *scene, int device, int rank, int world, co
 }
 
 // n frames (n = 1: mgpu_frame_render): every member renders its strips of all n frames with ONE launch on the first slot's
-// stream; then, on the communicator streams and frame by frame, the strips travel to rank 0's frame (grouped send / recv,
-// one pair per strip, received at the strip's final rows); rank 0's own strips are placed by one strided device copy.
-static int render_frames(MgpuFrame *f, const double cam[12], int maxPathLength, int passes, const float plane[4], int rng_mode,
-                         uint64_t seed, uint32_t pass_base, int n, int *slots_out) {
-  if (!f || !cam) return ffail(MGPU_ERR_INVALID, "NULL argument");
-  if (n < 1 || n > f->in_flight) return ffail(MGPU_ERR_INVALID, "n_frames must be 1..frames_in_flight (%d)", f->in_flight);
+// stream; then, on the communicator streams and frame by frame, the strips travel to rank 0 (one grouped exchange step per
+// frame, see MgpuFrame::exchange_mode); rank 0's own strips are placed by one strided device copy.
+// A failure after the first enqueue leaves streams, events and the frame counter out of step: the frame is marked broken and
+// every later call except mgpu_frame_destroy is refused (an RCCL group opened here is closed before returning).
+static int render_frames_enqueue(MgpuFrame *f, const double cam[12], int maxPathLength, int passes, const float plane[4], int rng_mode,
+                                 uint64_t seed, uint32_t pass_base, int n, int *slots_out) {
   int ks[kMaxInFlight];
   for (int i = 0; i < n; ++i) ks[i] = (int)((f->next + (unsigned long long)i) % (unsigned long long)f->in_flight);
   const int W = f->W, H = f->H, sh = f->strip_h, world = f->world;
-  const size_t strip_floats = (size_t)3 * sh * W;
   const bool exchange = world > 1 || f->force_exchange;
+  const bool block = f->exchange_mode == MGPU_EXCHANGE_BLOCK;
   for (Member &m : f->members) {
     FHIP(hipSetDevice(m.device));
     hipStream_t rs = m.slot[ks[0]].stream; // the launch and the copies of the whole batch
     // the slots' previous frames must have left their buffers: their exchange is the last thing that touched them
-    for (int i = 0; i < n; ++i) FHIP(hipStreamWaitEvent(rs, m.slot[ks[i]].exchanged, 0));
+    for (int i = 0; i < n; ++i) {
+      FHIP(hipStreamWaitEvent(rs, m.slot[ks[i]].exchanged, 0));
+      if (m.rank == 0) collect_timing(f, m.slot[ks[i]], false);
+    }
     if (m.n_rows) {
       float *images[kMaxInFlight];
       for (int i = 0; i < n; ++i) images[i] = m.slot[ks[i]].local;
@@ -323,15 +420,9 @@ static int render_frames(MgpuFrame *f, const double cam[12], int maxPathLength, 
     }
     for (int i = 0; i < n; ++i) {
       Slot &s = m.slot[ks[i]];
-      if (m.rank == 0 && m.n_rows && !f->force_exchange) {
-        // own strips to their final rows: local strip j -> frame rows [j * world * sh, +sh); the last one may be partial
-        const int full = m.n_rows / sh, tail = m.n_rows - full * sh;
-        if (full)
-          FHIP(hipMemcpy2DAsync(s.frame, sizeof(float) * strip_floats * world, s.local, sizeof(float) * strip_floats,
-                                sizeof(float) * strip_floats, (size_t)full, hipMemcpyDeviceToDevice, rs));
-        if (tail)
-          FHIP(hipMemcpyAsync(s.frame + (size_t)full * world * strip_floats, s.local + (size_t)full * strip_floats,
-                              sizeof(float) * 3 * (size_t)tail * W, hipMemcpyDeviceToDevice, rs));
+      if (m.rank == 0 && m.n_rows && !f->force_exchange) { // own strips to their final rows
+        int rc = place_strips(s.frame, s.local, m.n_rows, 0, world, sh, W, rs);
+        if (rc) return rc;
       }
       FHIP(hipEventRecord(s.rendered, rs));
     }
@@ -340,31 +431,88 @@ static int render_frames(MgpuFrame *f, const double cam[12], int maxPathLength, 
   for (int i = 0; i < n; ++i) {
     const int k = ks[i];
     if (exchange) {
+      for (Member &m : f->members)
+        if (m.rank == 0) {
+          FHIP(hipSetDevice(m.device));
+          FHIP(hipEventRecord(m.slot[k].x0, m.comm_stream));
+        }
       FNCCL(g_rccl.GroupStart());
+      // inside the group an error must not return before the group is closed
+      int grc = MGPU_OK;
+      unsigned long long ops = 0;
+      auto nccl_ok = [&](ncclResult_t r, const char *what) {
+        if (r != ncclSuccess && grc == MGPU_OK) grc = ffail(MGPU_ERR_HIP, "%s failed: %s", what, g_rccl.GetErrorString(r));
+        return r == ncclSuccess;
+      };
       for (Member &m : f->members) {
         Slot &s = m.slot[k];
         std::vector<Piece> plan;
-        if (m.rank != 0 || f->force_exchange) { // sends: this rank's strips, in strip order
-          plan_of(W, H, sh, world, m.rank, plan);
-          for (const Piece &p : plan) FNCCL(g_rccl.Send(s.local + p.local_off, p.count, ncclFloat, 0, m.comm, m.comm_stream));
+        if (m.rank != 0 || f->force_exchange) { // sends: this rank's strips -- as one block, or strip by strip in strip order
+          if (block) {
+            if (m.n_rows) nccl_ok(g_rccl.Send(s.local, (size_t)3 * m.n_rows * W, ncclFloat, 0, m.comm, m.comm_stream), "ncclSend");
+          } else {
+            plan_of(W, H, sh, world, m.rank, plan);
+            for (const Piece &p : plan)
+              if (!nccl_ok(g_rccl.Send(s.local + p.local_off, p.count, ncclFloat, 0, m.comm, m.comm_stream), "ncclSend")) break;
+          }
         }
-        if (m.rank == 0) { // receives: every other rank's strips (its own too when the exchange is forced), at their final rows
-          for (int r = f->force_exchange ? 0 : 1; r < world; ++r) {
-            plan_of(W, H, sh, world, r, plan);
-            for (const Piece &p : plan) FNCCL(g_rccl.Recv(s.frame + p.frame_off, p.count, ncclFloat, r, m.comm, m.comm_stream));
+        if (m.rank == 0) { // receives: every other rank's strips (its own too when the exchange is forced)
+          size_t stage_off = 0;
+          for (int r = f->force_exchange ? 0 : 1; r < world && grc == MGPU_OK; ++r) {
+            if (block) { // rank r's whole strip buffer, behind the previous rank's in the staging area
+              const size_t cnt = (size_t)3 * rows_of(H, sh, world, r) * W;
+              if (cnt) nccl_ok(g_rccl.Recv(s.staging + stage_off, cnt, ncclFloat, r, m.comm, m.comm_stream), "ncclRecv");
+              stage_off += cnt;
+              ops += cnt ? 1 : 0;
+            } else { // every strip at its final rows
+              plan_of(W, H, sh, world, r, plan);
+              for (const Piece &p : plan) {
+                if (!nccl_ok(g_rccl.Recv(s.frame + p.frame_off, p.count, ncclFloat, r, m.comm, m.comm_stream), "ncclRecv")) break;
+                ops += 1;
+              }
+            }
           }
         }
       }
-      FNCCL(g_rccl.GroupEnd());
+      const ncclResult_t ge = g_rccl.GroupEnd();
+      if (grc != MGPU_OK) return grc;
+      FNCCL(ge);
+      f->x_ops = ops;
+      if (block) // deal the staged buffers to their rows: one strided copy per rank, behind the receives on the same stream
+        for (Member &m : f->members)
+          if (m.rank == 0) {
+            FHIP(hipSetDevice(m.device));
+            size_t stage_off = 0;
+            for (int r = f->force_exchange ? 0 : 1; r < world; ++r) {
+              const int rows = rows_of(H, sh, world, r);
+              int rc = place_strips(m.slot[k].frame, m.slot[k].staging + stage_off, rows, r, world, sh, W, m.comm_stream);
+              if (rc) return rc;
+              stage_off += (size_t)3 * rows * W;
+            }
+          }
     }
     for (Member &m : f->members) {
       FHIP(hipSetDevice(m.device));
+      if (exchange && m.rank == 0) {
+        FHIP(hipEventRecord(m.slot[k].x1, m.comm_stream));
+        m.slot[k].x_pending = true;
+      }
       FHIP(hipEventRecord(m.slot[k].exchanged, exchange ? m.comm_stream : m.slot[ks[0]].stream));
     }
     if (slots_out) slots_out[i] = k;
   }
   f->next += (unsigned long long)n;
   return MGPU_OK;
+}
+
+static int render_frames(MgpuFrame *f, const double cam[12], int maxPathLength, int passes, const float plane[4], int rng_mode,
+                         uint64_t seed, uint32_t pass_base, int n, int *slots_out) {
+  if (!f || !cam) return ffail(MGPU_ERR_INVALID, "NULL argument");
+  if (f->broken) return ffail(MGPU_ERR_INVALID, "this frame object failed in an earlier render call and can only be destroyed");
+  if (n < 1 || n > f->in_flight) return ffail(MGPU_ERR_INVALID, "n_frames must be 1..frames_in_flight (%d)", f->in_flight);
+  const int rc = render_frames_enqueue(f, cam, maxPathLength, passes, plane, rng_mode, seed, pass_base, n, slots_out);
+  if (rc) f->broken = true;
+  return rc;
 }
 
 int mgpu_frame_render(MgpuFrame *f, const double cam[12], int maxPathLength, int passes, const float plane[4], int rng_mode,
@@ -383,12 +531,47 @@ int mgpu_frame_wait(MgpuFrame *f, int slot, float *host_image, float **device_im
   for (Member &m : f->members) {
     FHIP(hipSetDevice(m.device));
     FHIP(hipEventSynchronize(m.slot[slot].exchanged));
-    if (m.rank == 0) dev = m.slot[slot].frame;
+    if (m.rank == 0) {
+      dev = m.slot[slot].frame;
+      collect_timing(f, m.slot[slot], true);
+    }
   }
   if (device_image) *device_image = dev;
   if (host_image) {
     if (!dev) return ffail(MGPU_ERR_INVALID, "this process does not hold rank 0: the frame lives elsewhere");
     FHIP(hipMemcpy(host_image, dev, sizeof(float) * 3 * (size_t)f->W * f->H, hipMemcpyDeviceToHost));
+  }
+  return MGPU_OK;
+}
+
+int mgpu_frame_stats(MgpuFrame *f, MgpuFrameStats *out, int reset) {
+  if (!f || !out) return ffail(MGPU_ERR_INVALID, "NULL argument");
+  memset(out, 0, sizeof(*out));
+  out->world = f->world;
+  out->members = (int)f->members.size();
+  out->exchange_mode = f->exchange_mode;
+  out->frames = f->next;
+  for (Member &m : f->members) {
+    if (m.comm && out->rccl_ranks == 0) { // what the communicator itself says about its size
+      int cnt = 0;
+      FNCCL(g_rccl.CommCount(m.comm, &cnt));
+      out->rccl_ranks = cnt;
+    }
+    if (m.rank == 0) {
+      FHIP(hipSetDevice(m.device));
+      for (int k = 0; k < f->in_flight; ++k)
+        if (m.slot[k].x_pending) {
+          FHIP(hipEventSynchronize(m.slot[k].x1));
+          collect_timing(f, m.slot[k], true);
+        }
+    }
+  }
+  out->exchange_frames = f->x_frames;
+  out->exchange_ms = f->x_ms_sum;
+  out->exchange_ops_per_frame = f->x_ops;
+  if (reset) {
+    f->x_frames = 0;
+    f->x_ms_sum = 0.0;
   }
   return MGPU_OK;
 }

@@ -142,6 +142,16 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
     wstk.overflow = sc.wstack_overflow ? sc.wstack_overflow + gid * sc.woverflow_cap : nullptr;
   }
 
+  // ---- BVH in HBM, 1024-thread workgroup: the treelet (mgpu_device.hpp, kWTreelet) behind the far-child stacks ----
+  constexpr bool TL = !LDS_SCENE && BLOCK == 1024;
+  const unsigned char *lds_treelet = smem + (size_t)kWaves * WS::kWaveBytes;
+  if (TL) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(sc.treelet);
+    uint4 *dst = reinterpret_cast<uint4 *>(const_cast<unsigned char *>(lds_treelet));
+    const uint32_t n16 = P.lds_nodes_bytes >> 4;
+    for (uint32_t i = threadIdx.x; i < n16; i += BLOCK) dst[i] = src[i];
+    __syncthreads();
+  }
   // ---- optional: stage nodes + triangles into LDS -------------------------------------------------------------
   const unsigned char *lds_nodes = smem + (size_t)kWaves * CAP * 64 * sizeof(uint32_t);
   const unsigned char *lds_tris = lds_nodes + (size_t)P.lds_nodes_bytes;
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
   const uint32_t total_items = total_tiles * (uint32_t)P.passes;
   uint32_t in_item = 64;
   bool exhausted = false;
-  constexpr uint32_t kWgChunk = LDS_SCENE ? (uint32_t)MGPU_WG_CHUNK_LDS : (uint32_t)MGPU_WG_CHUNK_HBM;
+  constexpr uint32_t kWgChunk = LDS_SCENE ? (uint32_t)MGPU_WG_CHUNK_LDS : (uint32_t)MGPU_WG_CHUNK_HBM * (BLOCK == 1024 ? 2u : 1u);
   const uint32_t shard_items = (total_items + (uint32_t)kShards - 1) / (uint32_t)kShards;
   uint32_t home_shard = 0;
   uint32_t item_tile = 0, item_pass = 0; // wave-uniform: tile and pass of the current item
@@ -344,11 +354,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
         } else {
           int r;
           if (all_plain)
-            r = wide_node_step<true, MGPU_WIDE_PER_STEP, kWideStackLds>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, sgn, bt, cur, sp,
-                                                                       tri_cur, tri_end, n_nodes);
+            r = wide_node_step<true, MGPU_WIDE_PER_STEP, kWideStackLds, TL>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, sgn, bt, cur, sp,
+                                                                           tri_cur, tri_end, n_nodes, lds_treelet);
           else
-            r = wide_node_step<false, MGPU_WIDE_PER_STEP, kWideStackLds>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, sgn, bt, cur, sp,
-                                                                        tri_cur, tri_end, n_nodes);
+            r = wide_node_step<false, MGPU_WIDE_PER_STEP, kWideStackLds, TL>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, sgn, bt, cur, sp,
+                                                                            tri_cur, tri_end, n_nodes, lds_treelet);
           if (r == WT_TRI) st = ST_TRI;
           else if (r == WT_DONE) st = ST_SHADE;
         }
@@ -743,7 +753,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
           if constexpr (LDS_SCENE) {
             stk.put(0, 0u);
           } else {
-            cur = sc.wroot; // the super root: its child 0 is the tree's root (the reference's first pop)
+            cur = TL ? kWTreelet : sc.wroot; // the super root (record 0 of the treelet): its child 0 is the tree's root (the reference's first pop)
             n_nodes -= 1u;  // ... and its child 1 a dummy the reference never pops
           }
           have_ray = true;
@@ -1064,6 +1074,7 @@ hipError_t launch_render_sm(int cap, bool lds_scene, int block, dim3 grid, hipSt
     if (cap == 24 && block == 512) return launch_one<24, true, 512, false>(grid, s, shmem, sc, p);
   }
   if (!lds_scene && block == 256) return launch_one<1, false, 256, false>(grid, s, shmem, sc, p); // wide form: one variant
+  if (!lds_scene && block == 1024 && sc.treelet) return launch_one<1, false, 1024, false>(grid, s, shmem, sc, p); // ... + treelet in LDS
   return hipErrorInvalidConfiguration;
 }
 
