@@ -150,18 +150,19 @@ def cpu_baseline(cfg, frame, plane, mpl, pass_base, gpu_frame=None):
     threads = len(os.sched_getaffinity(0))
     model, physical = cpu_info()
     W, H, spp = cfg["width"], cfg["height"], cfg["spp"]
-    osc.render(frame, W, H, mpl, 1, plane, O.RNG_HASH, seed=cfg["seed"], window=(0, 512, W, 576), nthreads=threads)  # warm-up band
+    osc.render(frame, W, H, mpl, 1, plane, O.RNG_HASH, seed=cfg["seed"], window=(0, H // 2, W, H // 2 + 64), nthreads=threads)  # warm-up band
     done, dt, rays, same = 0, 0.0, 0, None
+    chunk = spp if cfg["name"] == "C2" else 1  # C2: whole frames (the first one is compared with the GPU's); larger configs pass by pass
     while dt < 10.0 and done < 4 * spp:
         t0 = time.perf_counter()
-        img, _, st, _ = osc.render(frame, W, H, mpl, spp, plane, O.RNG_HASH, seed=cfg["seed"], pass_base=pass_base + done,
+        img, _, st, _ = osc.render(frame, W, H, mpl, chunk, plane, O.RNG_HASH, seed=cfg["seed"], pass_base=pass_base + done,
                                    nthreads=threads)
         dt += time.perf_counter() - t0
-        if done == 0 and gpu_frame is not None:
+        if done == 0 and gpu_frame is not None and chunk == spp:
             # the first sample frame IS the last benchmarked frame (same seed and passes): the checker's image against the GPU's
             same = bool(img.tobytes() == gpu_frame.tobytes())
         rays += st["real_rays"]
-        done += spp
+        done += chunk
     return dict(gpu_frame_byte_equal=same, value=round(rays / dt / 1e6, 3), unit="Mrays/s", cores=threads, kind="port",
                 cpu_model=model, physical_cores=physical, threads=threads,
                 sample="%dx%d frames of the workload, %d passes in total (%d spp each), maxPathLength %d, OpenMP %d threads "
@@ -193,9 +194,31 @@ def time_frames(scene, render, steps, sync):
     return 1e3 * wall / steps, kernel_ms / max(launches, 1), st
 
 
+def hbm_roofline(key, st, steps, kms, lib_path):
+    """`roofline` of an HBM-resident configuration (C3 / C4 / C5): measured HBM bytes (PMC passes of THIS library) over the
+    kernel time against the HBM peak, the SURVEY 8(d) algorithmic bytes beside it."""
+    alg = (st["nodes"] * B_NODE + st["tris"] * B_TRI + st["real_rays"] * B_RAY) / steps
+    p, why = pmc_for(key, lib_path)
+    traffic = hbm_bytes(p)
+    wait = (round(p["SQ_WAIT_ANY"] / p["SQ_WAVE_CYCLES"], 3) if p and p.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in p else None)
+    return {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "achieved": round(traffic / (kms * 1e-3) / 1e9, 1) if traffic else None,
+            "frac": round(traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+            "traffic": traffic, "kernel": "k_render_sm", "kernel_avg_ms": round(kms, 3), "pmc_source": why,
+            "algorithmic_vs_hbm": {"bytes_per_launch": int(alg), "GBps": round(alg / (kms * 1e-3) / 1e9, 1),
+                                   "ratio_to_peak": round(alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "valu_issue_busy": (round(p["SQ_ACTIVE_INST_VALU"] * 4.0 / (kms * 1e-3 * CLOCK_HZ * N_SIMD), 3)
+                                if p and "SQ_ACTIVE_INST_VALU" in p else None),
+            "wave_cycles_waiting": wait,
+            "note": "BVH resident in HBM (wide 128-byte node records + 80-byte triangles through L1/L2, the top of the tree in an LDS "
+                    "treelet). `achieved` = measured HBM bytes (2*FETCH_SIZE + WRITE_SIZE per frame) / kernel time of a frame; the "
+                    "algorithmic bytes of SURVEY 8(d) are mostly L1/L2 hits. Neither HBM nor VALU issue is saturated (DESIGN.md 4.1, 7)."}
+
+
 def extra_config(key, lib_path, torch, steps=5):
-    """One single-GPU line for an HBM-resident BASELINE configuration (C3 / C4): frames rendered into HBM, HIP-event kernel
-    time, algorithmic bytes, and the counter-based HBM fraction when the committed PMC passes match this library."""
+    """One single-GPU line for an HBM-resident BASELINE configuration (C3 / C4 / C5): frames rendered into HBM, HIP-event kernel
+    time (summed over the launches of a frame), algorithmic bytes, and the counter-based HBM fraction when the committed PMC
+    passes match this library."""
     import mallie_amd as M
     from mallie_amd import workloads
     cfg = workloads.CONFIGS[key]
@@ -213,34 +236,27 @@ def extra_config(key, lib_path, torch, steps=5):
     torch.cuda.synchronize()
     ms, kms, st = time_frames(sc, render, steps, torch.cuda.synchronize)
     rays = st["real_rays"] / steps
-    alg = (st["nodes"] * B_NODE + st["tris"] * B_TRI + st["real_rays"] * B_RAY) / steps
-    p, why = pmc_for(key, lib_path)
-    traffic = hbm_bytes(p)
-    out = {"config": workloads.describe(cfg, len(workloads.mesh_arrays(cfg)[1]) if "grid" not in cfg else cfg["grid"] ** 2 * 968),
+    out = {"config": workloads.describe(cfg, workloads.n_tris(cfg)),
            "n_gpus": 1, "steps": steps, "ms_per_frame": round(ms, 3), "kernel_avg_ms": round(kms, 3),
            "value": round(rays / ms / 1e3, 1), "unit": "Mrays/s", "rays_per_frame": int(rays),
            "nodes_per_ray": round(st["nodes"] / st["real_rays"], 3), "tris_per_ray": round(st["tris"] / st["real_rays"], 3),
-           "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                        "achieved": round(traffic / (kms * 1e-3) / 1e9, 1) if traffic else None,
-                        "frac": round(traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                        "traffic": traffic, "pmc_source": why,
-                        "algorithmic_vs_hbm": {"bytes_per_launch": int(alg), "GBps": round(alg / (kms * 1e-3) / 1e9, 1),
-                                               "ratio_to_peak": round(alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                        "valu_issue_busy": (round(p["SQ_ACTIVE_INST_VALU"] * 4.0 / (kms * 1e-3 * CLOCK_HZ * N_SIMD), 3)
-                                            if p and "SQ_ACTIVE_INST_VALU" in p else None),
-                        "note": "BVH resident in HBM (wide 128-byte node records + 80-byte triangles through L1/L2). `achieved` = "
-                                "measured HBM bytes (2*FETCH_SIZE + WRITE_SIZE) / kernel time; the algorithmic bytes of SURVEY 8(d) "
-                                "are mostly L1/L2 hits. Neither HBM nor VALU issue is saturated: the walk is bound by dependent "
-                                "L1/L2 round trips (DESIGN.md 7)."}}
+           "device_MB": round(sc.device_bytes() / 1e6, 1),
+           "roofline": hbm_roofline(key, st, steps, kms, lib_path)}
     sc.close()
+    del buf
+    torch.cuda.empty_cache()
     return out
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="GPUs of this node. Under torch.distributed.run: one rank per GPU (WORLD_SIZE wins). Without a launcher and "
+                         "N > 1: this one process drives N devices through the C ABI's multi-GPU frame (mgpu_frame_create)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=("c2", "c3", "c4", "c5"), default="c2",
+                    help="BASELINE configuration rendered as the headline workload (default c2 = configs[1], the one the metric is quoted on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the occupancy pass, the read-back timing and extra_configs")
     ap.add_argument("--exchange", choices=("rccl", "torch"), default="rccl",
@@ -259,52 +275,66 @@ def main():
     from mallie_amd import workloads
     from mallie_amd.frame import FrameRenderer
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("MALLIE_FORCE_DEVICE0"):  # debugging aid: several ranks on one GPU (RCCL normally refuses this)
         local_rank = 0
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
     if not torch.cuda.is_available() or M.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # Two ways to N GPUs.  Under a launcher (WORLD_SIZE > 1): one process per GPU, `world` ranks.  Without one and --gpus N > 1:
+    # THIS process drives N devices (mgpu_frame_create: ncclCommInitAll, one RCCL rank per device) -- `single` below; torch then
+    # only provides the per-device synchronisation.
+    single = env_world == 1 and args.gpus > 1
+    if single and args.gpus > M.device_count():
+        raise SystemExit("--gpus %d: only %d HIP device(s) visible" % (args.gpus, M.device_count()))
+    world = args.gpus if single else env_world
+    n_gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # debugging aid: MALLIE_FORCE_GATHER=1 sends a single-GPU run through the N > 1 code path (RCCL gather of the one
-    # rank's strips + re-interleave), to price that machinery without a second GPU
+    # debugging aid: MALLIE_FORCE_GATHER=1 sends a single-GPU run through the torch.distributed N > 1 code path
     force_gather = world == 1 and bool(os.environ.get("MALLIE_FORCE_GATHER"))
-    if world > 1 or force_gather:
+    if env_world > 1 or force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=env_world, device_id=dev)
+    multi_proc = env_world > 1
 
-    cfg = workloads.CONFIGS["c2"]
+    key = args.config
+    cfg = workloads.CONFIGS[key]
     W, H = cfg["width"], cfg["height"]
     mpl, spp = cfg["bounces"] + 1, cfg["spp"]
-    verts, faces, mats, normals = workloads.mesh_arrays(cfg)
-    scene = M.Scene(verts, faces, mats, normals, None, device=local_rank)  # BVH: this library's host builder
+    n_tris = workloads.n_tris(cfg)
+    # scene(s): BVH by this library's builder (host below 65 536 triangles, device above), resident in HBM before the timed region
+    devices = list(range(world)) if single else [local_rank]
+    scenes = [workloads.make_scene(cfg, device=d) for d in devices]
+    scene = scenes[0]
+    torch.cuda.set_device(local_rank)
     frame = workloads.camera(cfg)
     plane = scene.plane() if cfg["plane"] else None
     # N > 1: a GPU renders 1/N of the frame, and the end of a persistent launch (waves running dry one by one, ~0.35 ms) does not
     # shrink with it -- so several frames share a launch (mgpu_frame_render_batch) and twice that many are in flight, the
     # exchange of one batch under the launch of the next.  N = 1: one frame per launch, one in flight (SURVEY 8(d)'s frame).
     fpl = args.frames_per_launch if args.frames_per_launch > 0 else (1 if world == 1 else 4)
-    if world > 1 and args.exchange != "rccl":
+    if multi_proc and args.exchange != "rccl":
         fpl = 1  # the torch.distributed formulation renders frame by frame
     fif = args.frames_in_flight if args.frames_in_flight > 0 else (min(8, 2 * fpl) if fpl > 1 else (1 if world == 1 else 3))
     fpl = min(fpl, fif)
-    fr = FrameRenderer(scene, frame, W, H, mpl, spp, plane, cfg["seed"], rank, world, dev, frames_in_flight=fif,
-                       force_collective=force_gather)
-    # N > 1: the exchange goes through the C ABI's multi-GPU frame (mgpu_frame_*: RCCL called directly, every strip received
-    # at its final rows of rank 0's frame); torch.distributed only carries the 128-byte communicator id and the barriers.
+    fr = None
+    if not single:
+        fr = FrameRenderer(scene, frame, W, H, mpl, spp, plane, cfg["seed"], rank, world, dev, frames_in_flight=fif,
+                           force_collective=force_gather)
+    # N > 1: the exchange goes through the C ABI's multi-GPU frame (mgpu_frame_*: RCCL called directly, see include/mgpu.h for
+    # the two exchange modes); torch.distributed only carries the 128-byte communicator id and the barriers.
     # --exchange torch keeps the torch.distributed gather of mallie_amd/frame.py.  All ranks take the same path.
     cframe, exchange = None, "none"
     if world == 1 and os.environ.get("MGPU_FRAME_FORCE_EXCHANGE"):  # debugging aid: the C ABI's exchange path on one GPU
         cframe = M.Frame.create_rank(scene, local_rank, 0, 1, None, W, H, strip_h=8, frames_in_flight=fif)
         exchange = "mgpu_frame_* forced on one GPU (RCCL send/recv to self)"
-    if world > 1:
+    if single:
+        cframe = M.Frame(scenes, devices, W, H, strip_h=8, frames_in_flight=fif)
+        exchange = "mgpu_frame_* (C ABI), one process driving %d devices (ncclCommInitAll)" % world
+    elif multi_proc:
         exchange = "torch.distributed gather + re-interleave (mallie_amd/frame.py)"
         if args.exchange == "rccl":
             uid = torch.zeros(128, dtype=torch.uint8, device=dev)
@@ -319,7 +349,7 @@ def main():
                 ok.zero_()
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 1:
-                exchange = "mgpu_frame_* (C ABI): grouped ncclSend/ncclRecv, strips received at their final rows"
+                exchange = "mgpu_frame_* (C ABI), one process per GPU (ncclCommInitRank)"
             elif cframe is not None:
                 cframe.close()
                 cframe = None
@@ -346,8 +376,9 @@ def main():
             del pending[:]
 
     def sync_all():
-        torch.cuda.synchronize(dev)
-        if world > 1:
+        for d in devices:
+            torch.cuda.synchronize(d)
+        if multi_proc:
             dist.barrier(device_ids=[local_rank])
             torch.cuda.synchronize(dev)
 
@@ -357,83 +388,115 @@ def main():
     finish_frames()
     sync_all()
     flush_c_stdio()  # the communicators exist by now: whatever RCCL had to say goes out before the measurement
-    scene.stats_read(reset=True)
-    scene.timing_enable(True)
+    for sc in scenes:
+        sc.stats_read(reset=True)
+        sc.timing_enable(True)
+    if cframe is not None:
+        cframe.stats(reset=True)
+    sync_all()
     t0 = time.perf_counter()
     for k0 in range(0, args.steps, fpl if batched else 1):  # frame k = passes [k*spp, (k+1)*spp): the next 16 samples per pixel
         render_frames(k0, min(fpl, args.steps - k0) if batched else 1)
     finish_frames()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize(dev)
+    sync_all()
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches = scene.timing_read()
-    scene.timing_enable(False)
-    st = scene.stats_read(reset=True)
+    per_rank_kernel, launch_counts, sts = [], [], []
+    for sc in scenes:
+        kernel_ms, launches = sc.timing_read()
+        sc.timing_enable(False)
+        per_rank_kernel.append(kernel_ms / max(launches, 1))
+        launch_counts.append(launches)
+        sts.append(sc.stats_read(reset=True))
+    st = sts[0]
+    fstats = cframe.stats() if cframe is not None else None
     last_pass_base = (args.steps - 1) * spp
 
     # max elapsed over ranks, sum of work over ranks
-    red = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    work = torch.tensor([st["real_rays"], st["nodes"], st["tris"], st["trace_calls"], st["paths"]], dtype=torch.float64,
-                        device=dev)
-    kern = torch.tensor([kernel_ms / max(launches, 1)], dtype=torch.float64, device=dev)
-    if world > 1:
+    work = [float(sum(s[k] for s in sts)) for k in ("real_rays", "nodes", "tris", "trace_calls", "paths")]
+    if multi_proc:
+        red = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        wk = torch.tensor(work, dtype=torch.float64, device=dev)
+        kern = torch.zeros(world, dtype=torch.float64, device=dev)
+        kern[rank] = per_rank_kernel[0]
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
-        dist.all_reduce(work, op=dist.ReduceOp.SUM)
-    elapsed = float(red.item())
-    rays, nodes, tris, trace_calls, paths = [float(x) for x in work.tolist()]
+        dist.all_reduce(wk, op=dist.ReduceOp.SUM)
+        dist.all_reduce(kern, op=dist.ReduceOp.SUM)
+        elapsed = float(red.item())
+        work = [float(x) for x in wk.tolist()]
+        per_rank_kernel = [float(x) for x in kern.tolist()]
+    rays, nodes, tris, trace_calls, paths = work
 
     if rank == 0:
         lib_path = M.lib_path()
         ms_per_step = 1e3 * elapsed / args.steps
         value = rays / elapsed / 1e6
-        # the dominant kernel (k_render_sm) on THIS rank: algorithmic bytes of one launch / its mean duration
-        alg_bytes_launch = (st["nodes"] * B_NODE + st["tris"] * B_TRI + st["real_rays"] * B_RAY) / max(launches, 1)
-        kernel_avg_ms = float(kern.item())
+        # the dominant kernel (k_render_sm) on rank 0: algorithmic bytes of one launch / its mean duration
+        n_launch = max(launch_counts[0], 1)
+        alg_bytes_launch = (st["nodes"] * B_NODE + st["tris"] * B_TRI + st["real_rays"] * B_RAY) / n_launch
+        kernel_avg_ms = per_rank_kernel[0]
         ksec = kernel_avg_ms * 1e-3
-        p, why = pmc_for("c2", lib_path) if world == 1 else (None, "PMC passes are single-GPU")
-        traffic = hbm_bytes(p)
-        alg_gbs = alg_bytes_launch / ksec / 1e9 if ksec > 0 else 0.0
-        ginst = p["SQ_INSTS_VALU"] / ksec / 1e9 if p and "SQ_INSTS_VALU" in p and ksec > 0 else None
-        roof = {"bound": "valu", "unit": "Ginst/s", "peak": round(VALU_PEAK_GINST, 1),
-                "achieved": round(ginst, 1) if ginst else None, "frac": round(ginst / VALU_PEAK_GINST, 4) if ginst else None,
-                "traffic": traffic, "kernel": "k_render_sm", "kernel_avg_ms": round(kernel_avg_ms, 3), "pmc_source": why,
-                "valu": None, "hbm": None,
-                "algorithmic_vs_hbm": {"bytes_per_launch": int(alg_bytes_launch), "GBps": round(alg_gbs, 1),
-                                       "ratio_to_peak": round(alg_gbs / HBM_PEAK_GBS, 4),
-                                       "note": "SURVEY 8(d): nodes*64 + tris*76 + rays*80 over the kernel time against 8 TB/s. Not a "
-                                               "roofline here: this scene's BVH is staged in LDS and those bytes never leave the CU"},
-                "note": "bound = fp64 VALU issue: `achieved` = executed VALU wave-instructions (SQ_INSTS_VALU per frame = per launch here) / mean kernel "
-                        "time of THIS run (HIP events on the launch stream); `peak` = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 fp64 "
-                        "instruction. `valu.issue_busy` = SQ_ACTIVE_INST_VALU x 4 cycles / SIMD cycles; `lane_occupancy` = active lanes "
-                        "per executed instruction, measured in this run; their product is the useful share of the issue peak."}
-        if p and "SQ_ACTIVE_INST_VALU" in p and ksec > 0:
-            roof["valu"] = {"insts_per_frame": int(p["SQ_INSTS_VALU"]),
-                            "wave_insts_per_ray": round(p["SQ_INSTS_VALU"] / max(st["real_rays"] / max(launches, 1), 1), 2),
-                            "issue_busy": round(p["SQ_ACTIVE_INST_VALU"] * 4.0 / (ksec * CLOCK_HZ * N_SIMD), 3),
-                            "salu_insts_per_frame": int(p["SQ_INSTS_SALU"]) if "SQ_INSTS_SALU" in p else None}
-        if traffic and ksec > 0:
-            roof["hbm"] = {"measured_GBps": round(traffic / ksec / 1e9, 1), "frac_of_peak": round(traffic / ksec / 1e9 / HBM_PEAK_GBS, 4),
-                           "fetch_bytes": int(2 * p["FETCH_SIZE"] * 1024), "write_bytes": int(p["WRITE_SIZE"] * 1024),
-                           "needed_write_bytes": int(12 * W * H * spp),
-                           "note": "2*FETCH_SIZE + WRITE_SIZE per frame (one launch) of k_render_sm; needed_write = the per-pass radiance planes it produces"}
+        if key != "c2":
+            # HBM-resident configurations: kernel time of a FRAME (a frame whose planes exceed 1 GiB takes several launches)
+            roof = hbm_roofline(key, st, args.steps, kernel_avg_ms * n_launch / args.steps, lib_path) if world == 1 else \
+                {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": None, "frac": None, "traffic": None,
+                 "kernel": "k_render_sm", "kernel_avg_ms": round(kernel_avg_ms, 3), "pmc_source": "PMC passes are single-GPU"}
+        else:
+            p, why = pmc_for("c2", lib_path) if world == 1 else (None, "PMC passes are single-GPU")
+            traffic = hbm_bytes(p)
+            alg_gbs = alg_bytes_launch / ksec / 1e9 if ksec > 0 else 0.0
+            ginst = p["SQ_INSTS_VALU"] / ksec / 1e9 if p and "SQ_INSTS_VALU" in p and ksec > 0 else None
+            roof = {"bound": "valu", "unit": "Ginst/s", "peak": round(VALU_PEAK_GINST, 1),
+                    "achieved": round(ginst, 1) if ginst else None, "frac": round(ginst / VALU_PEAK_GINST, 4) if ginst else None,
+                    "traffic": traffic, "kernel": "k_render_sm", "kernel_avg_ms": round(kernel_avg_ms, 3), "pmc_source": why,
+                    "valu": None, "hbm": None,
+                    "algorithmic_vs_hbm": {"bytes_per_launch": int(alg_bytes_launch), "GBps": round(alg_gbs, 1),
+                                           "ratio_to_peak": round(alg_gbs / HBM_PEAK_GBS, 4),
+                                           "note": "SURVEY 8(d): nodes*64 + tris*76 + rays*80 over the kernel time against 8 TB/s. Not a "
+                                                   "roofline here: this scene's BVH is staged in LDS and those bytes never leave the CU"},
+                    "note": "bound = fp64 VALU issue: `achieved` = executed VALU wave-instructions (SQ_INSTS_VALU per frame = per launch here) / mean kernel "
+                            "time of THIS run (HIP events on the launch stream); `peak` = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 fp64 "
+                            "instruction. `valu.issue_busy` = SQ_ACTIVE_INST_VALU x 4 cycles / SIMD cycles; `lane_occupancy` = active lanes "
+                            "per executed instruction, measured in this run; their product is the useful share of the issue peak."}
+            if p and "SQ_ACTIVE_INST_VALU" in p and ksec > 0:
+                roof["valu"] = {"insts_per_frame": int(p["SQ_INSTS_VALU"]),
+                                "wave_insts_per_ray": round(p["SQ_INSTS_VALU"] / max(st["real_rays"] / n_launch, 1), 2),
+                                "issue_busy": round(p["SQ_ACTIVE_INST_VALU"] * 4.0 / (ksec * CLOCK_HZ * N_SIMD), 3),
+                                "salu_insts_per_frame": int(p["SQ_INSTS_SALU"]) if "SQ_INSTS_SALU" in p else None}
+            if traffic and ksec > 0:
+                roof["hbm"] = {"measured_GBps": round(traffic / ksec / 1e9, 1), "frac_of_peak": round(traffic / ksec / 1e9 / HBM_PEAK_GBS, 4),
+                               "fetch_bytes": int(2 * p["FETCH_SIZE"] * 1024), "write_bytes": int(p["WRITE_SIZE"] * 1024),
+                               "needed_write_bytes": int(12 * W * H * spp),
+                               "note": "2*FETCH_SIZE + WRITE_SIZE per frame (one launch) of k_render_sm; needed_write = the per-pass radiance "
+                                       "planes it produces; WRITE_SIZE is uncalibrated on gfx950 (profiles/README.md)"}
+        conf = {"workload": workloads.describe(cfg, n_tris) + "; 1 step = 1 frame = the next %d passes per pixel "
+                            "(pass_base advances by %d per step)" % (spp, spp),
+                "parallelism": "replicated scene, interleaved 8-row strips x%d, 1 RCCL exchange/frame: %s" % (world, exchange)
+                               if world > 1 else "single GPU, persistent-threads kernel",
+                "frames_in_flight": fif, "frames_per_launch": fpl if batched else 1,
+                "rays_per_frame": int(rays / args.steps), "trace_calls_per_frame": int(trace_calls / args.steps),
+                "nodes_per_ray": round(nodes / rays, 3), "tris_per_ray": round(tris / rays, 3),
+                "mtrace_calls_per_s": round(trace_calls / elapsed / 1e6, 2),
+                # what the multi-GPU machinery says about itself: communicator size read back from RCCL (ncclCommCount), the
+                # exchange step's device time per frame (HIP events on rank 0's communicator stream) and mean kernel time per
+                # launch on every rank (a launch carries frames_per_launch frames)
+                "rccl_ranks": fstats["rccl_ranks"] if fstats else (env_world if multi_proc else 0),
+                "kernel_ms_per_launch_by_rank": [round(x, 3) for x in per_rank_kernel]}
+        if fstats:
+            conf["exchange_mode"] = fstats["exchange_mode"]
+            conf["exchange_recvs_per_frame"] = fstats["exchange_ops_per_frame"]
+            conf["exchange_ms_per_frame"] = (round(fstats["exchange_ms"] / fstats["exchange_frames"], 4)
+                                             if fstats["exchange_frames"] else None)
+            conf["exchange_frames_timed"] = fstats["exchange_frames"]
         out = {
             "metric": "Mrays/sec + ms/frame at 1920x1080, cornellbox_suzanne, 1/2/4/8 GPU",
-            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workloads.describe(cfg, len(faces)) + "; 1 step = 1 frame = the next %d passes per pixel "
-                                   "(pass_base advances by %d per step)" % (spp, spp),
-                       "parallelism": "replicated scene, interleaved 8-row strips x%d, 1 RCCL exchange/frame: %s" % (world, exchange)
-                                      if world > 1 else "single GPU, persistent-threads kernel",
-                       "frames_in_flight": fif, "frames_per_launch": fpl if batched else 1,
-                       "rays_per_frame": int(rays / args.steps), "trace_calls_per_frame": int(trace_calls / args.steps),
-                       "nodes_per_ray": round(nodes / rays, 3), "tris_per_ray": round(tris / rays, 3),
-                       "mtrace_calls_per_s": round(trace_calls / elapsed / 1e6, 2)},
+            "config": conf,
             "roofline": roof,
         }
-        if world == 1 and not args.no_extras:
+        verts, faces, mats, normals = workloads.mesh_arrays(cfg) if key == "c2" else (None, None, None, None)
+        if world == 1 and not args.no_extras and key == "c2":
             occ = occupancy_pass("c2")
             roof["lane_occupancy"] = occ
             if occ and occ.get("weighted") and roof.get("valu"):
@@ -461,6 +524,9 @@ def main():
             out["tile_order_off"] = {"ms_per_frame": round(ms_no, 3), "note": "MGPU_TILE_ORDER=0 (image-order hand-out), same frames"}
             del fr0
             scene0.close()
+            # the C ABI's exchange step priced on this one GPU (MGPU_FRAME_FORCE_EXCHANGE: the frame's strips are sent to
+            # ourselves through RCCL), both exchange modes, 1080p (135 strips) -- device time of the step per frame
+            out["exchange_on_one_gpu"] = forced_exchange_timing(M, scene, frame, W, H, mpl, spp, plane, cfg["seed"], local_rank, torch, dev)
             # the fast mode (MGPU_PRECISION_FP32, SURVEY 7 step 6 "report both"): the same frames in float.  Never `value`:
             # its frames are close to the reference's, not equal to them -- the distance is measured here, on the last frame.
             try:
@@ -493,13 +559,16 @@ def main():
             torch.cuda.synchronize(dev)
             gpu_frame = fr.frame_buffer.detach().cpu().numpy()
         if world == 1 and not args.no_extras:
-            del fr
+            fr = None
+            torch.cuda.empty_cache()
             extras = {}
-            for key in ("c3", "c4"):
+            for k2 in ("c3", "c4", "c5"):
+                if k2 == key:
+                    continue
                 try:
-                    extras[key] = extra_config(key, lib_path, torch)
+                    extras[k2] = extra_config(k2, lib_path, torch, steps=3 if k2 == "c5" else 5)
                 except Exception as e:  # an extra line must never take the headline down
-                    extras[key] = {"error": repr(e)}
+                    extras[k2] = {"error": repr(e)}
             out["extra_configs"] = extras
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, frame, plane, mpl, last_pass_base, gpu_frame)
@@ -507,7 +576,7 @@ def main():
         out = None
     if cframe is not None:
         cframe.close()
-    if world > 1 or force_gather:
+    if multi_proc or force_gather:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
     # RCCL prints a version banner through C stdio, which sits in libc's buffer when stdout is a pipe and would otherwise
@@ -515,6 +584,42 @@ def main():
     flush_c_stdio()
     if out is not None:
         print(json.dumps(out), flush=True)
+
+
+def forced_exchange_timing(M, scene, frame, W, H, mpl, spp, plane, seed, device, torch, dev, frames=6):
+    """Device time of the C ABI's exchange step with the frame's strips sent to ourselves, for both exchange modes."""
+    res = {}
+    old = {k: os.environ.get(k) for k in ("MGPU_FRAME_FORCE_EXCHANGE", "MGPU_FRAME_EXCHANGE")}
+    try:
+        os.environ["MGPU_FRAME_FORCE_EXCHANGE"] = "1"
+        for mode in ("block", "strips"):
+            os.environ["MGPU_FRAME_EXCHANGE"] = mode
+            try:
+                cf = M.Frame.create_rank(scene, device, 0, 1, None, W, H, strip_h=8, frames_in_flight=1)
+                cf.wait(cf.render(frame, mpl, spp, plane, seed=seed, pass_base=0))
+                cf.stats(reset=True)
+                t0 = time.perf_counter()
+                for k in range(frames):
+                    cf.wait(cf.render(frame, mpl, spp, plane, seed=seed, pass_base=k * spp))
+                torch.cuda.synchronize(dev)
+                wall = time.perf_counter() - t0
+                fs = cf.stats()
+                res[mode] = {"exchange_ms_per_frame": round(fs["exchange_ms"] / max(fs["exchange_frames"], 1), 4),
+                             "recvs_per_frame": fs["exchange_ops_per_frame"], "rccl_ranks": fs["rccl_ranks"],
+                             "ms_per_frame_wall": round(1e3 * wall / frames, 3)}
+                cf.close()
+            except Exception as e:  # noqa: BLE001
+                res[mode] = {"error": repr(e)}
+        res["note"] = ("MGPU_FRAME_FORCE_EXCHANGE=1 on one GPU: the whole frame (%dx%d float RGB, %d strips of 8 rows) sent to rank 0 = "
+                       "ourselves through RCCL; device time of the exchange step (HIP events on the communicator stream); one frame in flight"
+                       % (W, H, (H + 7) // 8))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return res
 
 
 if __name__ == "__main__":

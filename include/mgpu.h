@@ -126,6 +126,13 @@ int mgpu_scene_device(const MgpuScene *scene);
 /* For each of n rays: out[i] = the Intersection Traverse would fill, hit[i] = its bool result. On a miss out[i] has
  * t = DBL_MAX, u = v = 0, faceID = 0xFFFFFFFF and all other fields zero. stats may be NULL. */
 int mgpu_trace(MgpuScene *scene, const MgpuRay *rays, size_t n, MgpuIntersection *out, uint8_t *hit, MgpuStats *stats);
+/* Calls of mgpu_trace with 1..64 rays and stats == NULL -- what Scene::Trace / BVHAccel::Traverse make, one ray per call from
+ * every OpenMP thread of the reference (scene.cc:253-315, render.cc:403) -- go through a submission queue: the calls that are
+ * inside mgpu_trace at the same time are served by ONE launch (one of the callers packs everybody's rays into host memory the
+ * device maps, the traversal writes the records straight back, no copy engine in the path), a caller that is alone waits for
+ * nobody.  Same records as a launch per call.  MGPU_TRACE_QUEUE=0 (read when the scene is created) switches it off.
+ * mgpu_trace_queue_stats: combined launches so far and the calls they served. */
+int mgpu_trace_queue_stats(MgpuScene *scene, uint64_t *launches, uint64_t *calls);
 /* The same with rays, records and hit flags resident in device memory (d_out 16-byte aligned), enqueued on `stream`
  * (a hipStream_t, NULL = default stream) without synchronising; with stats != NULL the call waits for the kernel and
  * returns its counters and time. */

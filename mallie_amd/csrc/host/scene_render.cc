@@ -224,8 +224,13 @@ MgpuFrame *multi_frame(Scene &scene, int n, int W, int H) {
   MgpuScene *first = scene.DeviceScene();
   if (!first) return NULL;
   gMulti.scenes.push_back(first);
-  std::vector<int> devices(1, 0);
-  for (int d = 1; d < n; d++) {
+  // rank 0 is wherever the Scene's own device copy lives (MALLIE_DEVICE, or LOCAL_RANK under a launcher: bvh_build.cc); the
+  // replicas go to the next devices round the ring, so every member's streams and buffers sit on its scene's device
+  const int have = mgpu_device_count();
+  const int dev0 = mgpu_scene_device(first);
+  std::vector<int> devices(1, dev0);
+  for (int k = 1; k < n; k++) {
+    const int d = (dev0 + k) % (have > 0 ? have : 1);
     MgpuScene *r = scene.CreateDeviceScene(d);
     if (!r) {
       gMulti.release();

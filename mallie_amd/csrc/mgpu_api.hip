@@ -6,7 +6,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -54,6 +56,18 @@ constexpr int kCounterRing = 64;
 // stream takes an unused slot or re-binds the least recently used one after waiting (on the device) for its last launch.
 constexpr int kRenderSlots = 4;
 constexpr size_t kTracePinnedRays = 4096; // mgpu_trace: batches up to this size use the pinned staging
+// mgpu_trace, calls of up to kTraceCoalesceMax rays: concurrent callers are served together (see trace_coalesced)
+constexpr size_t kTraceCoalesceMax = 64;
+constexpr size_t kTraceZeroCopyRays = 1024; // rays per combined launch; they and their records live in host memory the GPU maps
+struct TraceTicket {
+  const MgpuRay *rays;
+  size_t n;
+  MgpuIntersection *out;
+  uint8_t *hit;
+  int rc = MGPU_OK;
+  char err[256];
+  std::atomic<int> done{0};
+};
 struct RenderSlot {
   hipStream_t stream = nullptr;
   bool used = false;
@@ -108,6 +122,15 @@ struct MgpuScene {
   void *p_trace = nullptr;          // mgpu_trace: device staging of the host-buffer entry point (grow-only)
   size_t trace_cap = 0;             // rays it holds
   void *p_trace_pinned = nullptr;   // mgpu_trace, small batches: pinned host mirror of the staging (kTracePinnedRays rays)
+  // submission queue of the single-ray callers (trace_coalesced)
+  std::mutex q_mutex;
+  std::condition_variable q_cv;
+  std::vector<TraceTicket *> q;
+  std::atomic<int> q_inside{0};  // host threads inside mgpu_trace's small-call path right now
+  std::atomic<int> q_waiting{0}; // tickets queued and not yet taken by a leader
+  bool q_leader = false;
+  void *p_trace_zc = nullptr;    // host memory mapped into the device: rays in, records + hit flags out (kTraceZeroCopyRays)
+  unsigned long long q_batches = 0, q_tickets = 0; // combined launches and the calls they served (mgpu_trace_queue_stats)
   void *p_host_img = nullptr;       // mgpu_render: device landing buffer of the host-buffer entry point (grow-only)
   size_t host_img_bytes = 0;
   int last_slot = 0;                // slot of the last render launch (mgpu_debug_tile_order)
@@ -115,6 +138,7 @@ struct MgpuScene {
   double *probe_buf = nullptr; // set only for the duration of mgpu_probe_path
   uint32_t probe_pixel = 0, probe_pass = 0;
   int pix_step = 1;            // set only for the duration of mgpu_render_step
+  bool trace_queue_on = true;  // MGPU_TRACE_QUEUE=0: every small mgpu_trace call launches on its own (A/B measurements, tests)
   bool tile_order_on = true;   // MGPU_TILE_ORDER (read once, when the scene is created)
   unsigned tile_order_every = 4; // MGPU_TILE_ORDER_EVERY
 };
@@ -355,6 +379,114 @@ void read_stats(const unsigned long long *w, MgpuStats *st) {
   st->stack_overflow = 0;
 }
 
+// ---- mgpu_trace for callers that bring ONE ray at a time from many threads ------------------------------------------------------
+// The reference calls Scene::Trace per ray from every OpenMP thread (scene.cc:253-315, render.cc:403).  A device launch per
+// call, serialised by a mutex, prices every ray at a launch + two copies + a synchronisation.  Instead the calls that are
+// inside this function at the same time are combined: each caller queues a ticket; one of them becomes the leader, gives the
+// others that are already on their way a moment (<= 20 us, and only when some are) to queue theirs, packs all queued rays
+// into host memory the device maps, launches ONE traversal over them that writes the records straight back into that memory
+// (no copy engine in the path: two DMA round trips cost more than the traversal of a handful of rays), waits, and hands every
+// ticket its records.  A caller that is alone pays no waiting time.  Results are the records the per-call path returns: the
+// same kernel traces the same rays, only their grouping into launches changes.
+int trace_batch_zero_copy(MgpuScene *s, std::vector<TraceTicket *> &batch, size_t total) {
+  std::lock_guard<std::mutex> host_lock(s->host_mutex); // the device staging and stream 0 are shared with the large-batch path
+  int rc = set_device(s);
+  if (rc) return rc;
+  const size_t per_ray = sizeof(MgpuRay) + sizeof(MgpuIntersection) + 16;
+  if (!s->p_trace_zc) {
+    hipError_t e = hipHostMalloc(&s->p_trace_zc, kTraceZeroCopyRays * per_ray + 64, hipHostMallocMapped);
+    if (e != hipSuccess) {
+      s->p_trace_zc = nullptr;
+      return fail(MGPU_ERR_OOM, "hipHostMalloc(trace queue): %s", hipGetErrorString(e));
+    }
+  }
+  unsigned char *host = (unsigned char *)s->p_trace_zc;
+  void *dev_base = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(&dev_base, host, 0));
+  unsigned char *dev = (unsigned char *)dev_base;
+  const size_t out_bytes = sizeof(MgpuIntersection) * kTraceZeroCopyRays, hit_bytes = kTraceZeroCopyRays;
+  MgpuRay *h_rays = (MgpuRay *)(host + out_bytes + hit_bytes);
+  size_t off = 0;
+  for (TraceTicket *t : batch) {
+    memcpy(h_rays + off, t->rays, sizeof(MgpuRay) * t->n);
+    off += t->n;
+  }
+  rc = mgpu_trace_device(s, (const MgpuRay *)(dev + out_bytes + hit_bytes), total, (MgpuIntersection *)dev, dev + out_bytes, nullptr, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  off = 0;
+  for (TraceTicket *t : batch) {
+    memcpy(t->out, host + sizeof(MgpuIntersection) * off, sizeof(MgpuIntersection) * t->n);
+    memcpy(t->hit, host + out_bytes + off, t->n);
+    off += t->n;
+  }
+  return MGPU_OK;
+}
+
+int trace_coalesced(MgpuScene *s, TraceTicket &t) {
+  using clock = std::chrono::steady_clock;
+  s->q_inside.fetch_add(1);
+  std::unique_lock<std::mutex> lk(s->q_mutex);
+  s->q.push_back(&t);
+  s->q_waiting.fetch_add(1);
+  while (!t.done.load(std::memory_order_acquire)) {
+    if (s->q_leader) {
+      // somebody else is serving a batch: spin briefly on our own flag (a batch takes tens of microseconds; a condition
+      // variable's wake-up alone costs that much), then sleep
+      lk.unlock();
+      const auto t0 = clock::now();
+      bool done = false;
+      while (!(done = t.done.load(std::memory_order_acquire)) && clock::now() - t0 < std::chrono::microseconds(200)) {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+      }
+      lk.lock();
+      if (done) break;
+      if (s->q_leader && !t.done.load(std::memory_order_acquire)) s->q_cv.wait_for(lk, std::chrono::milliseconds(1));
+      continue;
+    }
+    s->q_leader = true;
+    // callers that are inside this function and have not queued yet are about to: give them up to 20 us
+    if (s->q_inside.load() > s->q_waiting.load()) {
+      lk.unlock();
+      const auto t0 = clock::now();
+      while (s->q_inside.load() > s->q_waiting.load() && clock::now() - t0 < std::chrono::microseconds(20)) {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+      }
+      lk.lock();
+    }
+    std::vector<TraceTicket *> batch;
+    size_t total = 0, taken = 0;
+    for (TraceTicket *q : s->q) {
+      if (total + q->n > kTraceZeroCopyRays) break;
+      batch.push_back(q);
+      total += q->n;
+      ++taken;
+    }
+    s->q.erase(s->q.begin(), s->q.begin() + (long)taken);
+    s->q_waiting.fetch_sub((int)taken);
+    s->q_batches += 1;
+    s->q_tickets += taken;
+    lk.unlock();
+    const int rc = trace_batch_zero_copy(s, batch, total);
+    for (TraceTicket *b : batch) {
+      b->rc = rc;
+      if (rc) snprintf(b->err, sizeof(b->err), "%s", g_err); // the failure text is thread-local to the leader
+      b->done.store(1, std::memory_order_release); // `b` may be gone as soon as this is visible: nothing touches it afterwards
+    }
+    lk.lock();
+    s->q_leader = false;
+    s->q_cv.notify_all();
+  }
+  lk.unlock();
+  s->q_inside.fetch_sub(1);
+  if (t.rc) fail(t.rc, "%s", t.err);
+  return t.rc;
+}
+
 } // namespace
 
 extern "C" {
@@ -519,6 +651,7 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
     if (atoi(e) == 0) s->d.grey = 0;
   if (const char *e = getenv("MGPU_PLAIN_SLABS")) // 0: literal slab test only (A/B measurements, tests)
     if (atoi(e) == 0) s->d.boxes_ordered = 0;
+  if (const char *e = getenv("MGPU_TRACE_QUEUE")) s->trace_queue_on = atoi(e) != 0;
   if (const char *e = getenv("MGPU_TILE_ORDER")) s->tile_order_on = atoi(e) != 0;
   if (const char *e = getenv("MGPU_TILE_ORDER_EVERY")) s->tile_order_every = atoi(e) < 1 ? 1u : (unsigned)atoi(e);
   *out = s;
@@ -536,6 +669,7 @@ int mgpu_scene_destroy(MgpuScene *s) {
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (s->p_trace_pinned) (void)hipHostFree(s->p_trace_pinned);
+  if (s->p_trace_zc) (void)hipHostFree(s->p_trace_zc);
   for (RenderSlot &r : s->slot) {
     void *rp[] = {r.p_planes, r.p_tile_cost, r.p_tile_order, r.p_overflow, r.p_woverflow};
     for (void *p : rp)
@@ -652,6 +786,12 @@ int mgpu_trace_device(MgpuScene *s, const MgpuRay *d_rays, size_t n, MgpuInterse
 int mgpu_trace(MgpuScene *s, const MgpuRay *rays, size_t n, MgpuIntersection *out, uint8_t *hit, MgpuStats *stats) {
   if (!s) return fail(MGPU_ERR_INVALID, "scene is NULL");
   if (n && (!rays || !out || !hit)) return fail(MGPU_ERR_INVALID, "rays/out/hit must be non-NULL");
+  if (n >= 1 && n <= kTraceCoalesceMax && !stats && s->trace_queue_on) { // Scene::Trace / BVHAccel::Traverse: one ray per call
+    TraceTicket t;
+    t.rays = rays; t.n = n; t.out = out; t.hit = hit;
+    t.err[0] = 0;
+    return trace_coalesced(s, t);
+  }
   std::lock_guard<std::mutex> host_lock(s->host_mutex);
   const double t0 = now_ms();
   int rc = set_device(s);
@@ -1064,7 +1204,8 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
       if (rc) return rc;
     }
     for (int g0 = 0; g0 < passes; g0 += group) {
-      if (use_order && g0 > 0) {
+      if (use_order && g0 > 0 && P.tile_cost) { // only a launch that recorded costs has anything to sort by (a sort of the
+        // zeroed table would put the later groups, and the following frames, back into image order)
         launch_order_tiles(st, R.p_tile_cost, (uint32_t)tiles, R.p_tile_order);
         HIP_TRY(hipGetLastError());
       }
@@ -1227,10 +1368,13 @@ int mgpu_render_stream(MgpuScene *s, const double origin[3], const double corner
     }                                                                           \
   } while (0)
   const size_t table_bytes = (size_t)passes * W * H * 16;
+  // one lock over both phases (the state pass and the frame), and the caller's stream_state is advanced only when the frame
+  // has been rendered: a failed call leaves the reference stream where it was
+  std::lock_guard<std::mutex> host_lock(s->host_mutex);
+  uint32_t next_state[4];
+  int rc = set_device(s);
+  if (rc) return rc;
   {
-    std::lock_guard<std::mutex> host_lock(s->host_mutex);
-    int rc = set_device(s);
-    if (rc) return rc;
     static std::vector<uint32_t> jump; // T^(2^j) over GF(2), computed once per process
     static std::mutex jump_mutex;
     {
@@ -1272,14 +1416,10 @@ int mgpu_render_stream(MgpuScene *s, const double origin[3], const double corner
     P.state = d_state;
     P.table = d_table;
     TRY_S(launch_stream_states(s->cap, 0, s->d, P));
-    TRY_S(hipMemcpy(stream_state, d_state, 16, hipMemcpyDeviceToHost)); // waits for the kernel
-    if (states_out) TRY_S(hipMemcpy(states_out, d_table, table_bytes, hipMemcpyDeviceToHost));
+    TRY_S(hipMemcpy(next_state, d_state, 16, hipMemcpyDeviceToHost)); // waits for the kernel
   }
-  // the frame itself: the ordinary renderer from that table (host_mutex is taken inside)
-  int rc;
+  // the frame itself: the ordinary renderer from that table, which stays on the device
   {
-    // mgpu_render uploads a host table; keep the device one instead by going through the device entry point
-    std::lock_guard<std::mutex> host_lock(s->host_mutex);
     const size_t img_bytes = sizeof(float) * 3 * (size_t)W * H;
     if (img_bytes > s->host_img_bytes) {
       if (s->p_host_img) {
@@ -1309,8 +1449,10 @@ int mgpu_render_stream(MgpuScene *s, const double origin[3], const double corner
       return rc;
     }
     TRY_S(hipMemcpy(image_out, s->p_host_img, img_bytes, hipMemcpyDeviceToHost));
+    if (states_out) TRY_S(hipMemcpy(states_out, d_table, table_bytes, hipMemcpyDeviceToHost));
     if (stats) *stats = local;
   }
+  memcpy(stream_state, next_state, 16);
   cleanup();
   if (count_out)
     for (size_t i = 0; i < (size_t)W * H; i++) count_out[i] += passes;
@@ -1626,6 +1768,14 @@ int mgpu_render_panoramic(MgpuScene *s, const double origin[3], int W, int H, in
   }
   return MGPU_OK;
 #undef TRY_R
+}
+
+int mgpu_trace_queue_stats(MgpuScene *s, uint64_t *launches, uint64_t *calls) {
+  if (!s || !launches || !calls) return fail(MGPU_ERR_INVALID, "NULL argument");
+  std::lock_guard<std::mutex> lk(s->q_mutex);
+  *launches = s->q_batches;
+  *calls = s->q_tickets;
+  return MGPU_OK;
 }
 
 int mgpu_stats_read(MgpuScene *s, MgpuStats *out, int reset) {

@@ -35,6 +35,12 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class FrameStats(C.Structure):
+    _fields_ = [("world", C.c_int), ("members", C.c_int), ("rccl_ranks", C.c_int), ("exchange_mode", C.c_int),
+                ("frames", C.c_uint64), ("exchange_frames", C.c_uint64), ("exchange_ops_per_frame", C.c_uint64),
+                ("exchange_ms", C.c_double)]
+
+
 _lib = None
 
 
@@ -75,6 +81,8 @@ def load_library():
     L.mgpu_scene_bbox.restype = i32
     L.mgpu_scene_device_bytes.argtypes = [vp]
     L.mgpu_scene_device_bytes.restype = sz
+    L.mgpu_scene_device.argtypes = [vp]
+    L.mgpu_scene_device.restype = i32
     L.mgpu_trace.argtypes = [vp, vp, sz, vp, vp, vp]
     L.mgpu_trace.restype = i32
     L.mgpu_render.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, u64, u32, vp, vp,
@@ -113,6 +121,8 @@ def load_library():
     L.mgpu_frame_wait.restype = i32
     L.mgpu_frame_done_event_wait.argtypes = [vp, i32, vp]
     L.mgpu_frame_done_event_wait.restype = i32
+    L.mgpu_frame_stats.argtypes = [vp, C.POINTER(FrameStats), i32]
+    L.mgpu_frame_stats.restype = i32
     L.mgpu_frame_rows.argtypes = [i32, i32, i32, i32]
     L.mgpu_frame_rows.restype = i32
     L.mgpu_frame_plan.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, i32]
@@ -330,6 +340,17 @@ class Frame:
             raise MgpuError(rc, "mgpu_frame_wait", L.mgpu_frame_last_error().decode())
         return host if to_host else (dev.value or 0)
 
+    def stats(self, reset=False):
+        """mgpu_frame_stats: world, members of this process, rccl_ranks (read back from the communicator), exchange mode
+        ("block" / "strips"), frames enqueued, and the timed exchange steps (frames, receives per frame, summed device ms)."""
+        st = FrameStats()
+        rc = load_library().mgpu_frame_stats(self.h, C.byref(st), 1 if reset else 0)
+        if rc:
+            raise MgpuError(rc, "mgpu_frame_stats", load_library().mgpu_frame_last_error().decode())
+        d = {n: getattr(st, n) for n, _ in st._fields_}
+        d["exchange_mode"] = {0: "block", 1: "strips"}.get(st.exchange_mode, str(st.exchange_mode))
+        return d
+
     def stream_wait(self, slot, stream):
         rc = load_library().mgpu_frame_done_event_wait(self.h, slot, C.c_void_p(stream))
         if rc:
@@ -381,6 +402,9 @@ class Scene:
 
     def device_bytes(self):
         return load_library().mgpu_scene_device_bytes(self.h)
+
+    def device_index(self):
+        return load_library().mgpu_scene_device(self.h)
 
     def trace(self, rays, want_stats=False):
         """Batched Scene::Trace. rays: (n,6) [org,dir] or a RAY_DT array. -> (ISECT_DT array, hit uint8 array[, stats])"""

@@ -36,6 +36,13 @@ def mesh_arrays(cfg):
     return g["verts"].astype(np.float64), g["faces"], g["matIDs"], g["normals"]
 
 
+def n_tris(cfg):
+    """Triangles of a configuration's mesh (without building it)."""
+    if "grid" in cfg:
+        return cfg["grid"] ** 2 * 968
+    return int(len(_golden(cfg["mesh"])["faces"]))
+
+
 def make_scene(cfg, device=0):
     """Scene of a configuration on `device`: BVH by this library's builder (device builder from 65 536 triangles up)."""
     verts, faces, mats, normals = mesh_arrays(cfg)

@@ -25,15 +25,23 @@ def gpu_scene(name, own_bvh=False, **kw):
 
 def assert_images_match(img, ref, what):
     """Bit-exact is the expectation (radiance is a sum of exactly representable products, so ulp-level differences in
-    device acos/sin/cos cannot reach it unless a hit/miss decision flips).  Report precisely if not."""
+    device acos/sin/cos cannot reach it unless a hit/miss decision flips), and by default it is the REQUIREMENT
+    (MALLIE_STRICT_PARITY, on unless set to 0): an image that is not byte-equal fails.  With MALLIE_STRICT_PARITY=0 the
+    tolerance north_star allows (1e-4 per-pixel L2) is accepted -- and booked, so that the test report says how often
+    (tests/conftest.py: terminal summary line + junit property)."""
+    import conftest
     if img.tobytes() == ref.tobytes():
+        conftest.PARITY["byte_equal"] += 1
         return
     d = (img.astype(np.float64) - ref.astype(np.float64))
     l2 = np.sqrt((d ** 2).sum(-1))
     bad = int((l2 > 0).sum())
     rms = float(np.sqrt((l2 ** 2).mean()))
-    assert rms <= TOL_L2 and bad <= max(1, img.shape[0] * img.shape[1] // 100000), \
-        "%s: %d pixels differ, max L2 %.3g, rms L2 %.3g" % (what, bad, l2.max(), rms)
+    msg = "%s: %d pixels differ, max L2 %.3g, rms L2 %.3g" % (what, bad, l2.max(), rms)
+    assert not conftest.strict_parity(), msg + " (strict parity: only byte-equal passes; MALLIE_STRICT_PARITY=0 accepts 1e-4)"
+    assert rms <= TOL_L2 and bad <= max(1, img.shape[0] * img.shape[1] // 100000), msg
+    conftest.PARITY["within_tolerance"] += 1
+    conftest.PARITY["notes"].append(msg)
 
 
 def assert_same_work(st, ost):
@@ -451,6 +459,23 @@ def test_render_hash_mode_vs_oracle(mpl, passes):
     assert (st["trace_calls"], st["paths"]) == (ost["trace_calls"], ost["paths"])
     assert_same_work(st, ost)
     assert ost["garbage_hits"] == 0
+
+
+def test_c1_one_bounce_512_frame_vs_oracle():
+    """BASELINE configs[0] at its own size: cornellbox_suzanne, 512 x 512, 1 spp, ONE bounce (maxPathLength 2), plane on -- the
+    whole frame against the oracle's, images byte-equal and every work counter equal (the 16-segment form of the same config is
+    pinned to the reference's own sha256 by test_reference_default_config_from_its_seed_alone)."""
+    sc, osc = gpu_scene("cornell_obj"), O.scene_from_golden("cornell_obj")
+    W = H = 512
+    frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    plane = osc.plane()
+    img, count, st = sc.render(frame, W, H, 2, 1, plane, M.RNG_HASH, seed=1)
+    oimg, ocount, ost, _ = osc.render(frame, W, H, 2, 1, plane, O.RNG_HASH, seed=1)
+    assert_images_match(img, oimg, "C1 512x512 mpl 2")
+    assert np.array_equal(count, ocount) and int(count.min()) == 1
+    assert (st["trace_calls"], st["paths"], st["real_rays"]) == (ost["trace_calls"], ost["paths"], ost["real_rays"])
+    assert_same_work(st, ost)
+    assert float(img.mean()) > 0.05 and ost["garbage_hits"] == 0
 
 
 def test_pass_groups_keep_the_accumulation_order(monkeypatch):
@@ -949,15 +974,17 @@ print("RCCL_PATH_OK")
     assert r.returncode == 0 and "RCCL_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-@pytest.mark.parametrize("force", [0, 1])
+@pytest.mark.parametrize("force", [0, "block", "strips"])
 def test_c_abi_frame_on_one_gpu(force, monkeypatch):
     """mgpu_frame_* (the multi-GPU frame behind the C ABI) on the one GPU there is: world = 1 through the plain path, and
-    with MGPU_FRAME_FORCE_EXCHANGE=1 through the N > 1 machinery -- ncclCommInitAll, a group of ncclSend / ncclRecv of every
-    strip to its final rows, communicator stream, events -- with three frames in flight on a ragged frame height.  Every
-    frame must equal the single-launch frame of the same passes byte for byte."""
+    with MGPU_FRAME_FORCE_EXCHANGE=1 through the N > 1 machinery -- ncclCommInitAll, the grouped exchange step in both of its
+    modes (block: the strip buffer as one message into the staging area + one strided copy; strips: one ncclSend / ncclRecv
+    per strip to its final rows), communicator stream, events -- with three frames in flight on a ragged frame height.
+    Every frame must equal the single-launch frame of the same passes byte for byte; mgpu_frame_stats reports what ran."""
     import torch
     if force:
         monkeypatch.setenv("MGPU_FRAME_FORCE_EXCHANGE", "1")
+        monkeypatch.setenv("MGPU_FRAME_EXCHANGE", force)
     sc = gpu_scene("cornell_obj")
     W, H, mpl, passes = 320, 203, 5, 3
     cam = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
@@ -973,7 +1000,17 @@ def test_c_abi_frame_on_one_gpu(force, monkeypatch):
         sc.render_strips_device(cam, W, H, ref.data_ptr(), H, maxPathLength=mpl, passes=passes, plane=plane, seed=7,
                                 pass_base=k * passes)
         assert img.tobytes() == ref.cpu().numpy().tobytes(), k
+    fs = fr.stats()
+    assert fs["world"] == 1 and fs["members"] == 1 and fs["frames"] == 5
+    if force:  # the communicator exists and says so itself; every frame's exchange was timed (each slot was waited for)
+        assert fs["rccl_ranks"] == 1 and fs["exchange_mode"] == force and fs["exchange_frames"] == 5 and fs["exchange_ms"] > 0
+        assert fs["exchange_ops_per_frame"] == (1 if force == "block" else (H + 7) // 8)
+    else:
+        assert fs["rccl_ranks"] == 0 and fs["exchange_frames"] == 0
     fr.close()
+    # a scene that lives on another device than the one named for it is refused
+    with pytest.raises(M.MgpuError):
+        M.Frame([sc], [1], W, H, strip_h=8, frames_in_flight=1)
 
 
 @pytest.mark.parametrize("scene_name,budget_mb", [("cornell_obj", None), ("cornell_obj", "1"), ("teapot_obj", None)])
@@ -1199,7 +1236,11 @@ def test_bench_line_is_well_formed(tmp_path):
     occ = roof["lane_occupancy"]
     assert occ and 0.2 < occ["node_frac"] < 1 and 0.2 < occ["tri_frac"] < 1 and 0.2 < occ["shade_frac"] <= 1
     assert d["cpu_baseline"]["gpu_frame_byte_equal"] is True and d["cpu_baseline"]["kind"] == "port"
-    assert set(d["extra_configs"]) == {"c3", "c4"} and all("error" not in v for v in d["extra_configs"].values())
+    assert set(d["extra_configs"]) == {"c3", "c4", "c5"} and all("error" not in v for v in d["extra_configs"].values())
+    assert d["extra_configs"]["c5"]["roofline"]["bound"] == "hbm" and d["extra_configs"]["c5"]["rays_per_frame"] > 5e8
+    xo = d["exchange_on_one_gpu"]
+    assert all("error" not in xo[m] and xo[m]["rccl_ranks"] == 1 and xo[m]["exchange_ms_per_frame"] > 0 for m in ("block", "strips"))
+    assert xo["block"]["recvs_per_frame"] == 1 and xo["strips"]["recvs_per_frame"] == 135
     fast = d["fast_mode_fp32"]
     assert "error" not in fast and fast["ms_per_frame"] < d["ms_per_step"] and fast["distance_to_fp64_frame"]["rms_per_pixel_l2"] <= 1e-4
     assert d["frame_with_readback"]["ms_per_frame"] >= d["ms_per_step"] * 0.9
@@ -1219,6 +1260,29 @@ def test_bench_batched_frames_through_the_c_abi_exchange():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["steps"] == 5 and d["config"]["frames_per_launch"] == 3 and d["config"]["frames_in_flight"] == 6
     assert d["value"] > 1000 and d["cpu_baseline"]["gpu_frame_byte_equal"] is True
+    assert d["config"]["rccl_ranks"] == 1 and d["config"]["exchange_ms_per_frame"] > 0 and d["config"]["exchange_mode"] == "block"
+
+
+def test_bench_gpus_n_without_a_launcher():
+    """`python bench.py --gpus N` with no torch.distributed.run around it: this one process drives N devices through
+    mgpu_frame_create.  With two or more GPUs visible: N = 2, and the line must say that RCCL really had two ranks and what the
+    exchange cost.  On a one-GPU box: N larger than the device count is refused with a clear message (and the N = 1 machinery
+    with the exchange forced is covered by the test above)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    if M.device_count() >= 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "4"],
+                           capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and len(d["config"]["kernel_ms_per_launch_by_rank"]) == 2
+        assert d["config"]["exchange_ms_per_frame"] is not None and d["value"] > 1000
+    else:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                           capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+        assert r.returncode != 0 and "only 1 HIP device" in (r.stdout + r.stderr)
 
 
 def _l2_stats(a, b, spp):
