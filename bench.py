@@ -170,6 +170,57 @@ def cpu_baseline(cfg, frame, plane, mpl, pass_base, gpu_frame=None):
                        % (W, H, done, spp, mpl, threads, physical, model, dt, 1e3 * dt / done))
 
 
+def cpu_reference(cfg, frame, plane):
+    """Mallie's OWN OpenMP CPU path on this host (north_star: "next to Mallie's own OpenMP CPU path timed on the same box's host
+    cores"): oracle/_ref/ref_driver = the unmodified reference sources compiled where they lie under /root/reference
+    (oracle/Makefile) -- the binary travels to the GPU box, the sources do not.  It loads an .obj written here from the committed
+    mesh arrays and times calls of mallie::Render() on all host threads.  The reference's kMaxPathLength is compiled in (16) and
+    it counts nothing: the rays of a pass are counted by the oracle with the same path length (hash seeding; the reference's
+    per-thread random streams give statistically the same paths).  Returns None when the binary is not there."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    if not os.path.exists(exe) or cfg.get("mesh") is None:
+        return None
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from mallie_amd import workloads
+    verts, faces, mats, normals = workloads.mesh_arrays(cfg)
+    W, H = cfg["width"], cfg["height"]
+    threads = len(os.sched_getaffinity(0))
+    model, physical = cpu_info()
+    with tempfile.TemporaryDirectory() as tmp:
+        obj = os.path.join(tmp, "scene.obj")
+        with open(obj, "w") as f:
+            for v in verts:
+                f.write("v %r %r %r\n" % (float(v[0]), float(v[1]), float(v[2])))
+            for a, b, c in faces:
+                f.write("f %d %d %d\n" % (a + 1, b + 1, c + 1))
+        env = {k: v for k, v in os.environ.items() if k != "OMP_NUM_THREADS"}
+        passes = 12
+        args = [exe, "bench", "obj", obj, str(W), str(H), "1" if cfg["plane"] else "0", str(passes)] + \
+               [repr(float(x)) for x in cfg["eye"]] + [repr(float(x)) for x in cfg["lookat"]]
+        try:
+            r = subprocess.run(args, cwd=tmp, env=env, capture_output=True, text=True, timeout=300)
+        except (OSError, subprocess.SubprocessError) as e:
+            return {"error": repr(e)}
+        m = re.search(r"ref_bench passes=(\d+) seconds=([0-9.]+) threads=(\d+)", r.stdout)
+        if r.returncode != 0 or not m:
+            return {"error": "ref_driver bench failed (rc %d): %s" % (r.returncode, (r.stdout + r.stderr)[-300:])}
+        per_pass = sorted(float(x) for x in re.findall(r"ref_bench_pass \d+ ([0-9.]+)", r.stdout))
+    n, sec, thr = int(m.group(1)), float(m.group(2)), int(m.group(3))
+    # rays of one reference pass: the oracle at the reference's path length (16), same frame, same plane
+    nodes, idx, _ = O.bvh_build(verts, faces)
+    osc = O.OracleScene(verts, faces, mats, normals, None, nodes, idx)
+    _, _, st, _ = osc.render(frame, W, H, 16, 1, plane, O.RNG_HASH, seed=cfg["seed"], nthreads=threads)
+    return dict(value=round(st["real_rays"] * n / sec / 1e6, 3), unit="Mrays/s", cores=thr, kind="reference",
+                cpu_model=model, physical_cores=physical, threads=thr, ms_per_pass=round(1e3 * sec / n, 2),
+                ms_per_pass_median=round(1e3 * per_pass[len(per_pass) // 2], 2), mtrace_calls_per_s=round(st["trace_calls"] * n / sec / 1e6, 2),
+                sample="%d calls of the unmodified reference's mallie::Render() (oracle/_ref/ref_driver bench; OpenMP %d threads, %s physical "
+                       "cores, %s), %dx%d, plane %s, kMaxPathLength 16 as compiled into the reference (the GPU workload stops at %d): %.2f s; rays "
+                       "per pass = %d real rays (%d Trace() calls) counted by the oracle at the same path length"
+                       % (n, thr, physical, model, W, H, "on" if cfg["plane"] else "off", cfg["bounces"] + 1, sec, st["real_rays"], st["trace_calls"]))
+
+
 def flush_c_stdio():
     try:
         import ctypes
@@ -572,6 +623,9 @@ def main():
             out["extra_configs"] = extras
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, frame, plane, mpl, last_pass_base, gpu_frame)
+            ref = cpu_reference(cfg, frame, plane)
+            if ref is not None:
+                out["cpu_reference"] = ref
     else:
         out = None
     if cframe is not None:

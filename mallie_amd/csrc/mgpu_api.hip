@@ -129,6 +129,7 @@ struct MgpuScene {
   std::atomic<int> q_inside{0};  // host threads inside mgpu_trace's small-call path right now
   std::atomic<int> q_waiting{0}; // tickets queued and not yet taken by a leader
   bool q_leader = false;
+  int q_expect = 1;              // callers the recent combined launches served: how many tickets a leader waits for (<= 20 us)
   void *p_trace_zc = nullptr;    // host memory mapped into the device: rays in, records + hit flags out (kTraceZeroCopyRays)
   unsigned long long q_batches = 0, q_tickets = 0; // combined launches and the calls they served (mgpu_trace_queue_stats)
   void *p_host_img = nullptr;       // mgpu_render: device landing buffer of the host-buffer entry point (grow-only)
@@ -447,11 +448,15 @@ int trace_coalesced(MgpuScene *s, TraceTicket &t) {
       continue;
     }
     s->q_leader = true;
-    // callers that are inside this function and have not queued yet are about to: give them up to 20 us
-    if (s->q_inside.load() > s->q_waiting.load()) {
+    // Callers that are inside this function and have not queued yet are about to; and callers that were served by the last
+    // launches are, as a rule, on their way back with their next ray (a loop over Scene::Trace in every thread): wait until as
+    // many tickets are queued as the recent launches served, 20 us at most.  A caller that has been alone waits for nobody.
+    const int expect = s->q_expect;
+    if (s->q_inside.load() > s->q_waiting.load() || s->q_waiting.load() < expect) {
       lk.unlock();
       const auto t0 = clock::now();
-      while (s->q_inside.load() > s->q_waiting.load() && clock::now() - t0 < std::chrono::microseconds(20)) {
+      while ((s->q_inside.load() > s->q_waiting.load() || s->q_waiting.load() < expect) &&
+             clock::now() - t0 < std::chrono::microseconds(20)) {
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
@@ -470,6 +475,8 @@ int trace_coalesced(MgpuScene *s, TraceTicket &t) {
     s->q_waiting.fetch_sub((int)taken);
     s->q_batches += 1;
     s->q_tickets += taken;
+    s->q_expect = (int)taken >= s->q_expect ? (int)taken : (s->q_expect + (int)taken) / 2; // follows the callers up at once, down by halves
+    if (s->q_expect < 1) s->q_expect = 1;
     lk.unlock();
     const int rc = trace_batch_zero_copy(s, batch, total);
     for (TraceTicket *b : batch) {

@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <stdint.h>
+#include <omp.h>
 
 #include "common.h"
 #include "scene.h"
@@ -302,6 +303,39 @@ int cmd_plane(int argc, char **argv) {
   return 0;
 }
 
+// bench <kind> <file> <W> <H> <plane> <passes> <eye[3]> <lookat[3]>
+// Times `passes` calls of the reference's own mallie::Render() (its OpenMP loop on every host thread the environment
+// gives it, render.cc:593-708) after one untimed call, and prints one line per pass and a summary: the "kind": "reference"
+// CPU baseline of bench.py.  Nothing is written; the images are the reference's business.
+int cmd_bench(int argc, char **argv) {
+  if (argc < 14) die("bench kind file W H plane passes eye[3] lookat[3]");
+  SceneProbe scene;
+  if (!init_scene(scene, argv[2], argv[3], 1.0)) die("Scene::Init failed");
+  mallie::RenderConfig config;
+  config.width = atoi(argv[4]);
+  config.height = atoi(argv[5]);
+  config.plane = atoi(argv[6]) != 0;
+  const int passes = atoi(argv[7]);
+  for (int k = 0; k < 3; k++) {
+    config.eye[k] = atof(argv[8 + k]);
+    config.lookat[k] = atof(argv[11 + k]);
+  }
+  std::vector<float> image(3 * (size_t)config.width * config.height);
+  std::vector<int> count((size_t)config.width * config.height, 0);
+  mallie::Render(scene, config, image, count, config.eye, config.lookat, config.up, config.quat, 1); // first call: static init
+  double total = 0.0;
+  for (int p = 0; p < passes; p++) {
+    const double t0 = omp_get_wtime();
+    mallie::Render(scene, config, image, count, config.eye, config.lookat, config.up, config.quat, 1);
+    const double dt = omp_get_wtime() - t0;
+    total += dt;
+    printf("\nref_bench_pass %d %.6f\n", p, dt);
+  }
+  printf("\nref_bench passes=%d seconds=%.6f threads=%d width=%d height=%d\n", passes, total, omp_get_max_threads(), config.width,
+         config.height);
+  return 0;
+}
+
 } // namespace
 
 int main(int argc, char **argv) {
@@ -313,6 +347,7 @@ int main(int argc, char **argv) {
   if (!strcmp(argv[1], "camera")) return cmd_camera(argc, argv);
   if (!strcmp(argv[1], "render")) return cmd_render(argc, argv);
   if (!strcmp(argv[1], "panoramic")) return cmd_panoramic(argc, argv);
+  if (!strcmp(argv[1], "bench")) return cmd_bench(argc, argv);
   die("unknown command");
   return 2;
 }

@@ -10,6 +10,7 @@
 //   facade_driver plane  <a> <b> <c> <d> <rays.bin> <out.bin>                  (CPU: Plane::intersect)
 //   facade_driver step   <obj|eson|vox> <file> <W> <H> <plane> <calls> <maxPathLength> <seed> <step> <out.bin>   (GPU)
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 #include <cstdio>
@@ -22,6 +23,9 @@
 #include "render.h"
 #include "camera.h"
 #include "prim-plane.h"
+
+// one diagnostic of the C ABI underneath (include/mgpu.h), declared here so that the driver needs the Mallie headers only
+extern "C" int mgpu_trace_queue_stats(MgpuScene *scene, uint64_t *launches, uint64_t *calls);
 
 static bool init(mallie::Scene &scene, const char *kind, const char *file, double scale) {
   std::string obj, eson, vox, mat;
@@ -170,10 +174,20 @@ int main(int argc, char **argv) {
     std::vector<Intersection> rec(n);
     std::vector<uint32_t> hits(n, 0);
     memset(&rec[0], 0, sizeof(Intersection) * n);
+    const int nthreads = argc >= 7 ? atoi(argv[6]) : 4;
+    { // first call outside the clock: device scene upload, staging
+      Ray ray;
+      ray.org = real3(rays[0], rays[1], rays[2]);
+      ray.dir = real3(rays[3], rays[4], rays[5]);
+      Intersection warm;
+      memset(&warm, 0, sizeof(warm));
+      scene.Trace(warm, ray);
+    }
+    const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> pool;
-    for (int t = 0; t < 4; t++)
+    for (int t = 0; t < nthreads; t++)
       pool.push_back(std::thread([&, t]() {
-        for (size_t i = t; i < n; i += 4) {
+        for (size_t i = t; i < n; i += nthreads) {
           Ray ray;
           ray.org = real3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
           ray.dir = real3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
@@ -181,6 +195,12 @@ int main(int argc, char **argv) {
         }
       }));
     for (size_t t = 0; t < pool.size(); t++) pool[t].join();
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    printf("\ntrace_mt: %d threads, %zu Scene::Trace calls, %.1f us per call (wall / calls), %.0f calls/s\n", nthreads, n, us / n, 1e6 * n / us);
+    uint64_t launches = 0, calls = 0;
+    if (mgpu_trace_queue_stats(scene.DeviceScene(), &launches, &calls) == 0 && launches)
+      printf("trace_mt: submission queue: %llu calls in %llu launches (%.2f per launch)\n", (unsigned long long)calls,
+             (unsigned long long)launches, (double)calls / (double)launches);
     FILE *fo = fopen(argv[5], "wb");
     for (size_t i = 0; i < n; i++) {
       wr(fo, &hits[i], 4); wr(fo, &rec[i].faceID, 4); wr(fo, &rec[i].t, 8); wr(fo, &rec[i].u, 8); wr(fo, &rec[i].v, 8);

@@ -252,6 +252,30 @@ def test_facade_render_and_trace_on_gpu(driver, tmp_path):
     r = subprocess.run([driver, "trace_mt", "obj", obj, rp, op2], capture_output=True, text=True, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout + r.stderr
     assert open(op2, "rb").read() == open(op, "rb").read()
+    # ... and what the submission queue of mgpu_trace buys those callers (include/mgpu.h): the same 2 000 single-ray calls from
+    # 1, 4 and 16 threads with the queue and without it (MGPU_TRACE_QUEUE=0: a launch per call behind a mutex); records
+    # identical every time, calls/s reported in the test log
+    import re
+    rays2 = np.tile(t["rays"][:500], (4, 1))
+    rp2 = str(tmp_path / "rays2.bin")
+    rays2.tofile(rp2)
+    rate, ref_bytes = {}, None
+    for queue in ("1", "0"):
+        for nt in (1, 4, 16):
+            opq = str(tmp_path / ("hits_q%s_%d.bin" % (queue, nt)))
+            r = subprocess.run([driver, "trace_mt", "obj", obj, rp2, opq, str(nt)], capture_output=True, text=True, cwd=str(tmp_path),
+                               env=dict(os.environ, MGPU_TRACE_QUEUE=queue))
+            assert r.returncode == 0, r.stdout + r.stderr
+            rate[(queue, nt)] = float(re.search(r"([0-9.]+) calls/s", r.stdout).group(1))
+            print("MGPU_TRACE_QUEUE=%s: %s" % (queue, " | ".join(l for l in r.stdout.splitlines() if l.startswith("trace_mt"))))
+            b = open(opq, "rb").read()
+            ref_bytes = ref_bytes or b
+            assert b == ref_bytes, (queue, nt)
+    print("Scene::Trace calls/s  queue on: 1 thread %.0f, 4 threads %.0f, 16 threads %.0f | queue off: %.0f / %.0f / %.0f" % (
+        rate[("1", 1)], rate[("1", 4)], rate[("1", 16)], rate[("0", 1)], rate[("0", 4)], rate[("0", 16)]))
+    # measured on the round-3 box: 41 k / 94 k / 134 k calls/s with the queue against 30 k / 29 k / 29 k without
+    assert rate[("1", 4)] >= 2.0 * rate[("0", 4)] and rate[("1", 16)] >= 3.0 * rate[("0", 16)], rate
+    assert rate[("1", 1)] >= 0.9 * rate[("0", 1)], rate  # a caller that is alone waits for nobody
 
 
 @pytest.mark.gpu

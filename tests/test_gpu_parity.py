@@ -1236,6 +1236,8 @@ def test_bench_line_is_well_formed(tmp_path):
     occ = roof["lane_occupancy"]
     assert occ and 0.2 < occ["node_frac"] < 1 and 0.2 < occ["tri_frac"] < 1 and 0.2 < occ["shade_frac"] <= 1
     assert d["cpu_baseline"]["gpu_frame_byte_equal"] is True and d["cpu_baseline"]["kind"] == "port"
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_driver")):  # the unmodified reference, built where /root/reference exists
+        assert d["cpu_reference"]["kind"] == "reference" and d["cpu_reference"]["value"] > 0.1, d.get("cpu_reference")
     assert set(d["extra_configs"]) == {"c3", "c4", "c5"} and all("error" not in v for v in d["extra_configs"].values())
     assert d["extra_configs"]["c5"]["roofline"]["bound"] == "hbm" and d["extra_configs"]["c5"]["rays_per_frame"] > 5e8
     xo = d["exchange_on_one_gpu"]
