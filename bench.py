@@ -84,7 +84,9 @@ def pmc_for(workload, lib_path):
 
 
 def hbm_bytes(p):
-    """HBM bytes per frame: 2 x FETCH_SIZE (gfx950 correction of the guide) + WRITE_SIZE, both reported in KiB."""
+    """HBM bytes per frame: 2 x FETCH_SIZE (gfx950 correction of the guide) + WRITE_SIZE, both reported in KiB.  The committed
+    calibration passes (profiles/pmc_current.json "calibration": known byte counts in this library's access patterns) confirm
+    the factor 2 for 16-byte reads and give ~1 for writes; they are reported by profiles/*_summary.txt, not applied here."""
     if not p or "FETCH_SIZE" not in p or "WRITE_SIZE" not in p:
         return None
     return int(2 * p["FETCH_SIZE"] * 1024 + p["WRITE_SIZE"] * 1024)
