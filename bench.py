@@ -315,7 +315,7 @@ def main():
     ap.add_argument("--exchange", choices=("rccl", "torch"), default="rccl",
                     help="N > 1: rccl = the C ABI's multi-GPU frame (RCCL called directly), torch = torch.distributed gather")
     ap.add_argument("--frames-per-launch", type=int, default=0,
-                    help="frames rendered by one persistent launch per GPU (mgpu_frame_render_batch); default 1 at N=1, 4 at N>1")
+                    help="frames rendered by one persistent launch per GPU (mgpu_frame_render_batch); default 1 at N=1, 8 at N>1")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames enqueued concurrently (own stream and buffers each); default 1 on one GPU -- kernel time "
                          "then is what rocprofv3 shows -- and 3 on N > 1, where the RCCL gather and the end of a launch "
@@ -338,7 +338,8 @@ def main():
     # Two ways to N GPUs.  Under a launcher (WORLD_SIZE > 1): one process per GPU, `world` ranks.  Without one and --gpus N > 1:
     # THIS process drives N devices (mgpu_frame_create: ncclCommInitAll, one RCCL rank per device) -- `single` below; torch then
     # only provides the per-device synchronisation.
-    single = env_world == 1 and args.gpus > 1
+    # (MALLIE_BENCH_SINGLE=1: that code path with N = 1 -- what the one-GPU test box can exercise of it)
+    single = env_world == 1 and (args.gpus > 1 or bool(os.environ.get("MALLIE_BENCH_SINGLE")))
     if single and args.gpus > M.device_count():
         raise SystemExit("--gpus %d: only %d HIP device(s) visible" % (args.gpus, M.device_count()))
     world = args.gpus if single else env_world
@@ -368,13 +369,13 @@ def main():
     # N > 1: a GPU renders 1/N of the frame, and the end of a persistent launch (waves running dry one by one, ~0.35 ms) does not
     # shrink with it -- so several frames share a launch (mgpu_frame_render_batch) and twice that many are in flight, the
     # exchange of one batch under the launch of the next.  N = 1: one frame per launch, one in flight (SURVEY 8(d)'s frame).
-    fpl = args.frames_per_launch if args.frames_per_launch > 0 else (1 if world == 1 else 4)
+    fpl = args.frames_per_launch if args.frames_per_launch > 0 else (1 if world == 1 else 8)
     if multi_proc and args.exchange != "rccl":
         fpl = 1  # the torch.distributed formulation renders frame by frame
-    fif = args.frames_in_flight if args.frames_in_flight > 0 else (min(8, 2 * fpl) if fpl > 1 else (1 if world == 1 else 3))
+    fif = args.frames_in_flight if args.frames_in_flight > 0 else (min(16, 2 * fpl) if fpl > 1 else (1 if world == 1 else 3))
     fpl = min(fpl, fif)
     fr = None
-    if not single:
+    if not single or world == 1:
         fr = FrameRenderer(scene, frame, W, H, mpl, spp, plane, cfg["seed"], rank, world, dev, frames_in_flight=fif,
                            force_collective=force_gather)
     # N > 1: the exchange goes through the C ABI's multi-GPU frame (mgpu_frame_*: RCCL called directly, see include/mgpu.h for

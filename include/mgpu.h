@@ -227,7 +227,7 @@ int mgpu_render_frames_device(MgpuScene *scene, const double frame[12], int W, i
  *    that device); every GPU renders its strips (Render() semantics, MGPU_RNG_HASH seeding, so the frame does not depend on
  *    the GPU count) and ONE exchange step per frame -- grouped ncclSend / ncclRecv over RCCL / xGMI, each strip received
  *    at its final rows -- assembles the float RGB frame in rank 0's HBM.  RCCL is loaded on first use (dlopen), and not
- *    at all for one GPU.  Up to 8 frames may be in flight (own streams and buffers each): mgpu_frame_render only
+ *    at all for one GPU.  Up to 16 frames may be in flight (own streams and buffers each): mgpu_frame_render only
  *    enqueues, mgpu_frame_wait blocks until a slot's frame is complete. -------------------------------------------------- */
 typedef struct MgpuFrame MgpuFrame;
 /* How the strips travel to rank 0 (MGPU_FRAME_EXCHANGE=block|strips when the frame is created; default block):
@@ -282,6 +282,13 @@ int mgpu_frame_rows(int H, int strip_h, int world, int rank);
  * number of pieces (the arrays receive at most max_pieces of them; any may be NULL), -1 on bad arguments. */
 int mgpu_frame_plan(int W, int H, int strip_h, int world, int owner, size_t *local_off, size_t *frame_off, size_t *count,
                     int max_pieces);
+/* The block exchange of rank `owner` as numbers (host-only; the device code uses the same function): out[0] = offset (floats)
+ * of its strip buffer in rank 0's staging area, out[1] = floats of the one message it sends, out[2..6] = dst offset, dst pitch,
+ * src pitch, width (all bytes) and height (rows) of the strided 2-D copy that deals its full strips to their rows of the frame,
+ * out[7..9] = dst offset, src offset and bytes of the plain copy of a partial last strip (0 bytes: none).  Rank 0's own strips
+ * are placed with the same numbers straight from its strip buffer (no message) unless force_exchange != 0.  -1 on bad
+ * arguments. */
+int mgpu_frame_block_plan(int W, int H, int strip_h, int world, int owner, int force_exchange, size_t out[10]);
 const char *mgpu_frame_last_error(void);
 
 /* -- RenderPanoramic (render.cc:710-763; PathTraceEnv render.cc:518-590; Camera::GenerateEnvRay / GenerateStereoEnvRay

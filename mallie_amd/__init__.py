@@ -6,8 +6,8 @@ importing works anywhere (the library only needs the HIP runtime), but every com
 """
 from .mgpu import (MgpuError, Scene, Stats, RNG_HASH, RNG_STREAM, RNG_TABLE, NODE_DT, RAY_DT, ISECT_DT, abi_version,
                    bvh_build, camera_frame, device_count, hash_state, lib_path, plane_from_bbox, load_library, tonemap_device,
-                   TONEMAP_LINEAR_RGB8, TONEMAP_GAMMA22_BGRA8, Frame, frame_rows, frame_unique_id, frame_plan)
+                   TONEMAP_LINEAR_RGB8, TONEMAP_GAMMA22_BGRA8, Frame, frame_rows, frame_unique_id, frame_plan, frame_block_plan)
 
 __all__ = ["MgpuError", "Scene", "Stats", "RNG_HASH", "RNG_STREAM", "RNG_TABLE", "NODE_DT", "RAY_DT", "ISECT_DT",
            "abi_version", "bvh_build", "camera_frame", "device_count", "hash_state", "lib_path", "plane_from_bbox",
-           "load_library", "tonemap_device", "TONEMAP_LINEAR_RGB8", "TONEMAP_GAMMA22_BGRA8", "Frame", "frame_rows", "frame_unique_id", "frame_plan"]
+           "load_library", "tonemap_device", "TONEMAP_LINEAR_RGB8", "TONEMAP_GAMMA22_BGRA8", "Frame", "frame_rows", "frame_unique_id", "frame_plan", "frame_block_plan"]

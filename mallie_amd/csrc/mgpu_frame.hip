@@ -99,7 +99,7 @@ int load_rccl() {
     if (r_ != ncclSuccess) return ffail(MGPU_ERR_HIP, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
   } while (0)
 
-constexpr int kMaxInFlight = 8;
+constexpr int kMaxInFlight = 16;
 
 // what one device keeps for one frame in flight
 struct Slot {
@@ -164,6 +164,14 @@ void plan_of(int W, int H, int strip_h, int world, int owner, std::vector<Piece>
   }
 }
 
+// floats in front of rank `owner`'s strip buffer in rank 0's staging area: the buffers of ranks 1 .. owner - 1 (0 .. with the
+// exchange forced on one GPU), rank after rank
+size_t staging_offset(int W, int H, int sh, int world, int owner, bool force) {
+  size_t off = 0;
+  for (int r = force ? 0 : 1; r < owner; ++r) off += (size_t)3 * rows_of(H, sh, world, r) * W;
+  return off;
+}
+
 // rows the block exchange stages on rank 0: every other rank's (with the exchange forced on one GPU: its own)
 size_t staging_rows(const MgpuFrame *f) {
   size_t rows = 0;
@@ -195,18 +203,35 @@ int create_common(MgpuFrame *f) {
   return MGPU_OK;
 }
 
-// local strips of `rows` rows (strip j at local rows [j * sh, ...)) to their final rows of rank `owner` in `frame`: one
-// strided copy for the full strips, one plain copy for a partial last strip
-int place_strips(float *frame, const float *local, int rows, int owner, int world, int sh, int W, hipStream_t st) {
-  const size_t strip_floats = (size_t)3 * sh * W;
+// Where the strips of rank `owner` go when its strip buffer (local rows contiguous: strip j at local rows [j * sh, ...)) is
+// dealt to the frame: ONE strided 2-D copy for the full strips (strip j -> frame rows [(j * world + owner) * sh, +sh)) and one
+// plain copy for a partial last strip.  All numbers in BYTES except `staging_off` / `msg_floats`; the device code below and
+// mgpu_frame_block_plan (CPU tests execute it with numpy) both come through here.
+struct BlockPlace {
+  size_t dst_off, dst_pitch, src_pitch, width, height; // the hipMemcpy2D of the full strips (height 0: none)
+  size_t tail_dst_off, tail_src_off, tail_bytes;       // the partial last strip (tail_bytes 0: none)
+};
+BlockPlace block_place(int rows, int owner, int world, int sh, int W) {
+  const size_t strip_bytes = sizeof(float) * 3 * (size_t)sh * W;
   const int full = rows / sh, tail = rows - full * sh;
-  float *dst = frame + (size_t)owner * strip_floats;
-  if (full)
-    FHIP(hipMemcpy2DAsync(dst, sizeof(float) * strip_floats * world, local, sizeof(float) * strip_floats, sizeof(float) * strip_floats,
-                          (size_t)full, hipMemcpyDeviceToDevice, st));
-  if (tail)
-    FHIP(hipMemcpyAsync(dst + (size_t)full * world * strip_floats, local + (size_t)full * strip_floats, sizeof(float) * 3 * (size_t)tail * W,
-                        hipMemcpyDeviceToDevice, st));
+  BlockPlace p;
+  p.dst_off = (size_t)owner * strip_bytes;
+  p.dst_pitch = strip_bytes * world;
+  p.src_pitch = strip_bytes;
+  p.width = strip_bytes;
+  p.height = (size_t)full;
+  p.tail_dst_off = p.dst_off + (size_t)full * p.dst_pitch;
+  p.tail_src_off = (size_t)full * strip_bytes;
+  p.tail_bytes = sizeof(float) * 3 * (size_t)tail * W;
+  return p;
+}
+
+int place_strips(float *frame, const float *local, int rows, int owner, int world, int sh, int W, hipStream_t st) {
+  const BlockPlace p = block_place(rows, owner, world, sh, W);
+  unsigned char *dst = reinterpret_cast<unsigned char *>(frame);
+  const unsigned char *src = reinterpret_cast<const unsigned char *>(local);
+  if (p.height) FHIP(hipMemcpy2DAsync(dst + p.dst_off, p.dst_pitch, src, p.src_pitch, p.width, p.height, hipMemcpyDeviceToDevice, st));
+  if (p.tail_bytes) FHIP(hipMemcpyAsync(dst + p.tail_dst_off, src + p.tail_src_off, p.tail_bytes, hipMemcpyDeviceToDevice, st));
   return MGPU_OK;
 }
 
@@ -250,6 +275,19 @@ int mgpu_frame_plan(int W, int H, int strip_h, int world, int owner, size_t *loc
     if (count) count[i] = plan[i].count;
   }
   return (int)plan.size();
+}
+
+int mgpu_frame_block_plan(int W, int H, int strip_h, int world, int owner, int force_exchange, size_t out[10]) {
+  if (W <= 0 || H <= 0 || strip_h <= 0 || world <= 0 || owner < 0 || owner >= world || !out) return -1;
+  // the staging area holds the strip buffers of ranks 1 .. world - 1 (0 .. with the exchange forced on one GPU), rank after rank
+  const size_t off = staging_offset(W, H, strip_h, world, owner, force_exchange != 0);
+  const int rows = rows_of(H, strip_h, world, owner);
+  const BlockPlace p = block_place(rows, owner, world, strip_h, W);
+  out[0] = off;
+  out[1] = (size_t)3 * rows * W;
+  out[2] = p.dst_off; out[3] = p.dst_pitch; out[4] = p.src_pitch; out[5] = p.width; out[6] = p.height;
+  out[7] = p.tail_dst_off; out[8] = p.tail_src_off; out[9] = p.tail_bytes;
+  return 0;
 }
 
 int mgpu_frame_unique_id(unsigned char id[128]) {
@@ -457,12 +495,10 @@ static int render_frames_enqueue(MgpuFrame *f, const double cam[12], int maxPath
           }
         }
         if (m.rank == 0) { // receives: every other rank's strips (its own too when the exchange is forced)
-          size_t stage_off = 0;
           for (int r = f->force_exchange ? 0 : 1; r < world && grc == MGPU_OK; ++r) {
             if (block) { // rank r's whole strip buffer, behind the previous rank's in the staging area
               const size_t cnt = (size_t)3 * rows_of(H, sh, world, r) * W;
-              if (cnt) nccl_ok(g_rccl.Recv(s.staging + stage_off, cnt, ncclFloat, r, m.comm, m.comm_stream), "ncclRecv");
-              stage_off += cnt;
+              if (cnt) nccl_ok(g_rccl.Recv(s.staging + staging_offset(W, H, sh, world, r, f->force_exchange), cnt, ncclFloat, r, m.comm, m.comm_stream), "ncclRecv");
               ops += cnt ? 1 : 0;
             } else { // every strip at its final rows
               plan_of(W, H, sh, world, r, plan);
@@ -482,12 +518,11 @@ static int render_frames_enqueue(MgpuFrame *f, const double cam[12], int maxPath
         for (Member &m : f->members)
           if (m.rank == 0) {
             FHIP(hipSetDevice(m.device));
-            size_t stage_off = 0;
             for (int r = f->force_exchange ? 0 : 1; r < world; ++r) {
               const int rows = rows_of(H, sh, world, r);
-              int rc = place_strips(m.slot[k].frame, m.slot[k].staging + stage_off, rows, r, world, sh, W, m.comm_stream);
+              int rc = place_strips(m.slot[k].frame, m.slot[k].staging + staging_offset(W, H, sh, world, r, f->force_exchange), rows, r, world, sh, W,
+                                    m.comm_stream);
               if (rc) return rc;
-              stage_off += (size_t)3 * rows * W;
             }
           }
     }

@@ -127,6 +127,8 @@ def load_library():
     L.mgpu_frame_rows.restype = i32
     L.mgpu_frame_plan.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, i32]
     L.mgpu_frame_plan.restype = i32
+    L.mgpu_frame_block_plan.argtypes = [i32, i32, i32, i32, i32, i32, vp]
+    L.mgpu_frame_block_plan.restype = i32
     L.mgpu_frame_last_error.restype = C.c_char_p
     L.mgpu_occupancy_read.argtypes = [vp, vp]
     L.mgpu_occupancy_read.restype = i32
@@ -256,6 +258,16 @@ def frame_plan(W, H, strip_h, world, owner):
     lo, fo, cnt = np.zeros(n, "<u8"), np.zeros(n, "<u8"), np.zeros(n, "<u8")
     L.mgpu_frame_plan(W, H, strip_h, world, owner, _p(lo), _p(fo), _p(cnt), n)
     return lo, fo, cnt
+
+
+def frame_block_plan(W, H, strip_h, world, owner, force_exchange=False):
+    """mgpu_frame_block_plan as a dict: where rank `owner`'s strip buffer lands in rank 0's staging area and the copies that deal
+    it to the frame (offsets / pitches in bytes except staging_off / msg_floats, which count floats)."""
+    out = np.zeros(10, "<u8")
+    if load_library().mgpu_frame_block_plan(W, H, strip_h, world, owner, 1 if force_exchange else 0, _p(out)) != 0:
+        raise ValueError("bad frame geometry")
+    keys = ("staging_off", "msg_floats", "dst_off", "dst_pitch", "src_pitch", "width", "height", "tail_dst_off", "tail_src_off", "tail_bytes")
+    return {k: int(v) for k, v in zip(keys, out)}
 
 
 def frame_unique_id():

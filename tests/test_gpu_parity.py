@@ -1285,6 +1285,16 @@ def test_bench_gpus_n_without_a_launcher():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
                            capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
         assert r.returncode != 0 and "only 1 HIP device" in (r.stdout + r.stderr)
+        # the same code path with the one device there is (MALLIE_BENCH_SINGLE=1: scenes[] / devices[] through mgpu_frame_create,
+        # all devices synchronised around the timed region, per-rank kernel times) and the exchange forced through RCCL
+        env2 = dict(env, MALLIE_BENCH_SINGLE="1", MGPU_FRAME_FORCE_EXCHANGE="1")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-extras",
+                            "--frames-per-launch", "2", "--frames-in-flight", "4"], capture_output=True, text=True, cwd=ROOT, timeout=600, env=env2)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["n_gpus"] == 1 and d["config"]["rccl_ranks"] == 1 and d["config"]["exchange_mode"] == "block"
+        assert len(d["config"]["kernel_ms_per_launch_by_rank"]) == 1 and d["config"]["exchange_ms_per_frame"] > 0
+        assert d["cpu_baseline"]["gpu_frame_byte_equal"] is True and d["value"] > 1000
 
 
 def _l2_stats(a, b, spp):

@@ -50,6 +50,49 @@ def test_frame_exchange_plan_reassembles_any_frame():
             assert covered.all() and out.tobytes() == frame.tobytes(), (W, H, sh, world)
 
 
+def test_block_exchange_plan_reassembles_any_frame():
+    """The default exchange (MGPU_EXCHANGE_BLOCK): every rank's strip buffer is ONE message into rank 0's staging area and one
+    strided 2-D copy (+ a plain copy for a partial last strip) deals it to the frame.  mgpu_frame_block_plan hands out the very
+    numbers the device code passes to ncclRecv / hipMemcpy2DAsync / hipMemcpyAsync; executed here with numpy on byte arrays for
+    world sizes 1 (exchange forced) .. 8 on ragged frames, they must rebuild the frame exactly, staging areas must tile without
+    overlap, and rank 0's own strips (placed from its strip buffer, no message) must land where its plan says."""
+    from mallie_amd.frame import strip_rows
+    rng = np.random.default_rng(4)
+
+    def copy2d(dst, dst_off, dst_pitch, src, src_off, src_pitch, width, height):
+        for r in range(height):
+            dst[dst_off + r * dst_pitch: dst_off + r * dst_pitch + width] = src[src_off + r * src_pitch: src_off + r * src_pitch + width]
+
+    for W, H, sh in ((7, 61, 8), (16, 64, 8), (5, 203, 13), (3, 9, 1), (4, 1080, 8), (2, 5, 8)):
+        frame = rng.random((H, W, 3)).astype("<f4")
+        for world, force in ((1, True), (2, False), (3, False), (4, False), (8, False)):
+            out = np.zeros(H * W * 12, "u1")
+            written = np.zeros(H * W * 12, bool)
+            n_stage = sum(3 * W * M.frame_rows(H, sh, world, r) for r in range(0 if force else 1, world))
+            staging = np.zeros(n_stage * 4, "u1")
+            staged = np.zeros(n_stage, bool)
+            for r in range(world):
+                rows = strip_rows(H, world, r, sh)
+                local = np.ascontiguousarray(frame[rows]).view("u1").reshape(-1)   # rank r's strip buffer, bytes
+                p = M.frame_block_plan(W, H, sh, world, r, force)
+                assert p["msg_floats"] * 4 == local.size
+                if r == 0 and not force:
+                    src = local                                                    # own strips: straight from the strip buffer
+                else:
+                    a, n = p["staging_off"], p["msg_floats"]                       # ncclSend(local, n) -> ncclRecv(staging + a, n)
+                    assert not staged[a:a + n].any()
+                    staged[a:a + n] = True
+                    staging[4 * a:4 * (a + n)] = local
+                    src = staging[4 * a:4 * (a + n)]
+                mark = np.ones(local.size, "u1")
+                for buf, s_ in ((out, src), (written.view("u1"), mark)):
+                    copy2d(buf, p["dst_off"], p["dst_pitch"], s_, 0, p["src_pitch"], p["width"], p["height"])
+                    if p["tail_bytes"]:
+                        buf[p["tail_dst_off"]:p["tail_dst_off"] + p["tail_bytes"]] = s_[p["tail_src_off"]:p["tail_src_off"] + p["tail_bytes"]]
+            assert staged.all() and written.all(), (W, H, sh, world)
+            assert out.tobytes() == frame.tobytes(), (W, H, sh, world)
+
+
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "mgpu.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
