@@ -138,7 +138,10 @@ void launch_scene_layout(hipStream_t s, const double *verts, const uint32_t *fac
                          const uint32_t *matIDs, const double *fv_normals, size_t nf, DTri *tris, double *slot_normal);
 // WNode records of the wide traversal (nn + 1 of them, the last is the super root)
 void launch_wide_layout(hipStream_t s, const MgpuNode *nodes, size_t nn, WNode *out);
-constexpr int kWideStackLds = 8; // far-child stack entries per lane kept in LDS by the wide traversal (16 bytes each)
+#ifndef MGPU_WIDE_STACK_LDS
+#define MGPU_WIDE_STACK_LDS 8 // (6 / 5 measured in round 3 with the treelet grown into the freed LDS: within 2 % either way)
+#endif
+constexpr int kWideStackLds = MGPU_WIDE_STACK_LDS; // far-child stack entries per lane kept in LDS by the wide traversal (16 bytes each)
 // ---- fast mode (mgpu_render_f32.hip): the scene in float --------------------------------------------------------------
 struct alignas(16) FNode { // 32 bytes: box (rounded outward), a / b = children or leaf run (see k_layout_f32)
   float bmin[3], bmax[3];

@@ -1354,8 +1354,10 @@ def test_fast_mode_fp32_stays_close_to_the_fp64_frame(name, force_hbm, monkeypat
 
 
 def test_fast_mode_c2_frame_within_north_star_distance():
-    """The C2 frame (1920x1080, 16 spp) in the fast mode against the fp64 frame of the same passes (itself byte-equal to the
-    oracle's, test_c2_full_frame_digest_vs_oracle): rms per-pixel L2 <= 1e-4, north_star's figure."""
+    """The C2 frame (1920x1080, 16 spp) in the fast mode against the ORACLE's frame of the same passes (a 256-row band through
+    Suzanne and the floor, rendered by the checker itself) and against the whole fp64 frame (byte-equal to the oracle's,
+    test_c2_full_frame_digest_vs_oracle): rms per-pixel L2 <= 1e-4, north_star's figure.  The HBM-resident configurations do not
+    meet it in this mode (C4 1.7e-4, C3 4.1e-4: DESIGN.md 4.8), which is why it is never the headline."""
     import torch
     from mallie_amd import workloads
     cfg = workloads.CONFIGS["c2"]
@@ -1371,6 +1373,13 @@ def test_fast_mode_c2_frame_within_north_star_distance():
         out[prec] = buf.cpu().numpy()
     rms, moved = _l2_stats(out["fp32"], out["fp64"], spp)
     assert rms <= 1e-4 and moved <= 1e-4, (rms, moved)
+    nodes, idx, _ = O.bvh_build(verts, faces)
+    osc = O.OracleScene(verts, faces, mats, normals, None, nodes, idx)
+    y0, y1 = 400, 656
+    oimg, _, _, _ = osc.render(cam, W, H, mpl, spp, osc.plane(), O.RNG_HASH, seed=cfg["seed"], window=(0, y0, W, y1), nthreads=0)
+    assert out["fp64"][y0:y1].tobytes() == oimg[y0:y1].tobytes()
+    rms_o, moved_o = _l2_stats(out["fp32"][y0:y1], oimg[y0:y1], spp)
+    assert rms_o <= 1e-4 and moved_o <= 1e-4, (rms_o, moved_o)
 
 
 @pytest.mark.parametrize("mpl", [3, 17, 40])
