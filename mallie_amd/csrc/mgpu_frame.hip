@@ -545,6 +545,10 @@ static int render_frames(MgpuFrame *f, const double cam[12], int maxPathLength, 
   if (!f || !cam) return ffail(MGPU_ERR_INVALID, "NULL argument");
   if (f->broken) return ffail(MGPU_ERR_INVALID, "this frame object failed in an earlier render call and can only be destroyed");
   if (n < 1 || n > f->in_flight) return ffail(MGPU_ERR_INVALID, "n_frames must be 1..frames_in_flight (%d)", f->in_flight);
+  // what can be refused before anything is enqueued is refused here and leaves the frame object usable
+  if (maxPathLength < 1 || passes < 1) return ffail(MGPU_ERR_INVALID, "maxPathLength and passes must be >= 1");
+  if (rng_mode != MGPU_RNG_HASH)
+    return ffail(MGPU_ERR_UNSUPPORTED, "multi-GPU frames are seeded per (pixel, pass) (MGPU_RNG_HASH): the image must not depend on the GPU count");
   const int rc = render_frames_enqueue(f, cam, maxPathLength, passes, plane, rng_mode, seed, pass_base, n, slots_out);
   if (rc) f->broken = true;
   return rc;
