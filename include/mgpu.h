@@ -236,6 +236,11 @@ typedef struct MgpuFrame MgpuFrame;
  *   MGPU_EXCHANGE_STRIPS  one send / receive pair per strip, received at its final rows (no staging; 118 pairs per 1080p
  *                         frame at eight ranks, 236 at 3840x2160) */
 enum { MGPU_EXCHANGE_BLOCK = 0, MGPU_EXCHANGE_STRIPS = 1 };
+/* What carries the bytes (MGPU_FRAME_TRANSPORT=rccl|copy when the frame is created; default rccl): with `copy`, and only for a
+ * frame whose ranks are all driven by this process (mgpu_frame_create), every send / receive pair of the exchange step is a
+ * device-to-device copy on rank 0's communicator stream instead -- same plan, staging, placement and events.  Nothing in it
+ * needs one GPU per rank, so devices[] may then name a device several times: the N > 1 machinery for N = 2 .. 8 on a box with
+ * one GPU (tests).  mgpu_frame_stats reports exchange_mode + 2 for it. */
 /* One process driving n GPUs (ncclCommInitAll): scenes[r] must live on devices[r] (MGPU_ERR_INVALID otherwise) and becomes
  * rank r. */
 int mgpu_frame_create(MgpuScene *const *scenes, const int *devices, int n, int W, int H, int strip_h, int frames_in_flight,

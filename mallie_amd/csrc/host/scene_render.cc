@@ -212,7 +212,8 @@ int wanted_gpus() {
   if (!e) return 1;
   int n = atoi(e);
   const int have = mgpu_device_count();
-  if (n > have) n = have;
+  const char *t = getenv("MGPU_FRAME_TRANSPORT"); // copy transport: ranks may share a device (include/mgpu.h; tests)
+  if (n > have && !(t && !strcmp(t, "copy") && n <= 16)) n = have;
   return n < 1 ? 1 : n;
 }
 

@@ -131,6 +131,11 @@ struct MgpuFrame {
   // STRIPS: one send / receive pair per strip, received at its final rows -- no staging, but 118 (1080p) or 236 (4K) pairs
   // per frame at eight ranks.  MGPU_FRAME_EXCHANGE=strips|block; measured in profiles/ (DESIGN.md 6).
   int exchange_mode = MGPU_EXCHANGE_BLOCK;
+  // What carries the bytes.  RCCL (default): ncclSend / ncclRecv over xGMI.  COPY (MGPU_FRAME_TRANSPORT=copy, one process
+  // driving all ranks only): device-to-device copies on rank 0's communicator stream in place of every send / receive pair --
+  // same plan, same staging, same placement, same events; and because nothing in it needs one GPU per rank, several ranks may
+  // then share a device: the way the N > 1 partition, staging and slot machinery is exercised for N = 2 .. 8 on a one-GPU box.
+  bool transport_copy = false;
   std::vector<Member> members;  // the ranks this process drives (all of them, or one)
   unsigned long long next = 0;  // frames enqueued so far
   // exchange timing (rank 0's communicator stream): summed when a slot is waited for or reused
@@ -337,6 +342,13 @@ static int frame_new(int world, int W, int H, int strip_h, int frames_in_flight,
   f->strip_h = strip_h;
   f->in_flight = frames_in_flight;
   if (const char *e = getenv("MGPU_FRAME_FORCE_EXCHANGE")) f->force_exchange = world == 1 && atoi(e) != 0;
+  if (const char *e = getenv("MGPU_FRAME_TRANSPORT")) {
+    if (!strcmp(e, "copy")) f->transport_copy = true;
+    else if (strcmp(e, "rccl") != 0) {
+      delete f;
+      return ffail(MGPU_ERR_INVALID, "MGPU_FRAME_TRANSPORT=%s (expected rccl|copy)", e);
+    }
+  }
   if (const char *e = getenv("MGPU_FRAME_EXCHANGE")) {
     if (!strcmp(e, "strips")) f->exchange_mode = MGPU_EXCHANGE_STRIPS;
     else if (!strcmp(e, "block")) f->exchange_mode = MGPU_EXCHANGE_BLOCK;
@@ -358,12 +370,17 @@ int mgpu_frame_create(MgpuScene *const *scenes, const int *devices, int n, int W
     if (!scenes[r]) return ffail(MGPU_ERR_INVALID, "scenes[%d] is NULL", r);
     if (mgpu_scene_device(scenes[r]) != devices[r])
       return ffail(MGPU_ERR_INVALID, "scenes[%d] lives on device %d, not on devices[%d] = %d", r, mgpu_scene_device(scenes[r]), r, devices[r]);
-    for (int q = 0; q < r; ++q)
-      if (devices[q] == devices[r]) return ffail(MGPU_ERR_INVALID, "device %d is named twice", devices[r]);
   }
   MgpuFrame *f = nullptr;
   int rc = frame_new(n, W, H, strip_h, frames_in_flight, &f);
   if (rc) return rc;
+  if (!f->transport_copy) // RCCL wants one GPU per rank; the copy transport does not care
+    for (int r = 0; r < n; ++r)
+      for (int q = 0; q < r; ++q)
+        if (devices[q] == devices[r]) {
+          mgpu_frame_destroy(f);
+          return ffail(MGPU_ERR_INVALID, "device %d is named twice (MGPU_FRAME_TRANSPORT=copy lets ranks share a device)", devices[r]);
+        }
   f->members.resize(n);
   for (int r = 0; r < n; ++r) {
     if (!scenes[r]) {
@@ -375,7 +392,7 @@ int mgpu_frame_create(MgpuScene *const *scenes, const int *devices, int n, int W
     f->members[r].scene = scenes[r];
   }
   rc = create_common(f);
-  if (!rc && (n > 1 || f->force_exchange)) {
+  if (!rc && (n > 1 || f->force_exchange) && !f->transport_copy) {
     rc = load_rccl();
     if (!rc) {
       std::vector<ncclComm_t> comms(n);
@@ -403,6 +420,11 @@ int mgpu_frame_create_rank(MgpuScene *scene, int device, int rank, int world, co
   MgpuFrame *f = nullptr;
   int rc = frame_new(world, W, H, strip_h, frames_in_flight, &f);
   if (rc) return rc;
+  if (f->transport_copy && world > 1) {
+    mgpu_frame_destroy(f);
+    return ffail(MGPU_ERR_UNSUPPORTED, "MGPU_FRAME_TRANSPORT=copy needs all ranks in one process (mgpu_frame_create)");
+  }
+  f->transport_copy = false; // world == 1 from here: RCCL to ourselves when the exchange is forced
   f->members.resize(1);
   f->members[0].rank = rank;
   f->members[0].device = device;
@@ -466,8 +488,56 @@ static int render_frames_enqueue(MgpuFrame *f, const double cam[12], int maxPath
     }
     if (exchange) FHIP(hipStreamWaitEvent(m.comm_stream, m.slot[ks[n - 1]].rendered, 0));
   }
+  Member *root = nullptr; // the member that holds rank 0 (copy transport: the one that moves everybody's bytes)
+  for (Member &m : f->members)
+    if (m.rank == 0) root = &m;
+  if (exchange && f->transport_copy) {
+    if (!root) return ffail(MGPU_ERR_INVALID, "copy transport without rank 0 in this process");
+    FHIP(hipSetDevice(root->device));
+    for (Member &m : f->members) // rank 0's communicator stream moves the bytes: it waits for every rank's launch
+      if (&m != root) FHIP(hipStreamWaitEvent(root->comm_stream, m.slot[ks[n - 1]].rendered, 0));
+  }
   for (int i = 0; i < n; ++i) {
     const int k = ks[i];
+    if (exchange && f->transport_copy) {
+      // the exchange step with device-to-device copies in place of the send / receive pairs: same plan, staging and placement
+      FHIP(hipSetDevice(root->device));
+      FHIP(hipEventRecord(root->slot[k].x0, root->comm_stream));
+      unsigned long long ops = 0;
+      std::vector<Piece> plan;
+      for (Member &m : f->members) {
+        if (m.rank == 0 && !f->force_exchange) continue;
+        Slot &src = m.slot[k];
+        if (block) {
+          const size_t cnt = (size_t)3 * m.n_rows * W;
+          if (cnt)
+            FHIP(hipMemcpyAsync(root->slot[k].staging + staging_offset(W, H, sh, world, m.rank, f->force_exchange), src.local, sizeof(float) * cnt,
+                                hipMemcpyDefault, root->comm_stream));
+          ops += cnt ? 1 : 0;
+          int rc = place_strips(root->slot[k].frame, root->slot[k].staging + staging_offset(W, H, sh, world, m.rank, f->force_exchange), m.n_rows,
+                                m.rank, world, sh, W, root->comm_stream);
+          if (rc) return rc;
+        } else {
+          plan_of(W, H, sh, world, m.rank, plan);
+          for (const Piece &p : plan) {
+            FHIP(hipMemcpyAsync(root->slot[k].frame + p.frame_off, src.local + p.local_off, sizeof(float) * p.count, hipMemcpyDefault, root->comm_stream));
+            ops += 1;
+          }
+        }
+      }
+      f->x_ops = ops;
+      FHIP(hipEventRecord(root->slot[k].x1, root->comm_stream));
+      root->slot[k].x_pending = true;
+      FHIP(hipEventRecord(root->slot[k].exchanged, root->comm_stream));
+      for (Member &m : f->members) // a rank's strip buffer is free when rank 0 has taken its bytes
+        if (&m != root) {
+          FHIP(hipSetDevice(m.device));
+          FHIP(hipStreamWaitEvent(m.comm_stream, root->slot[k].exchanged, 0));
+          FHIP(hipEventRecord(m.slot[k].exchanged, m.comm_stream));
+        }
+      if (slots_out) slots_out[i] = k;
+      continue;
+    }
     if (exchange) {
       for (Member &m : f->members)
         if (m.rank == 0) {
@@ -588,7 +658,7 @@ int mgpu_frame_stats(MgpuFrame *f, MgpuFrameStats *out, int reset) {
   memset(out, 0, sizeof(*out));
   out->world = f->world;
   out->members = (int)f->members.size();
-  out->exchange_mode = f->exchange_mode;
+  out->exchange_mode = f->exchange_mode + (f->transport_copy ? 2 : 0);
   out->frames = f->next;
   for (Member &m : f->members) {
     if (m.comm && out->rccl_ranks == 0) { // what the communicator itself says about its size

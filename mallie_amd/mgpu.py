@@ -360,7 +360,8 @@ class Frame:
         if rc:
             raise MgpuError(rc, "mgpu_frame_stats", load_library().mgpu_frame_last_error().decode())
         d = {n: getattr(st, n) for n, _ in st._fields_}
-        d["exchange_mode"] = {0: "block", 1: "strips"}.get(st.exchange_mode, str(st.exchange_mode))
+        d["transport"] = "copy" if st.exchange_mode >= 2 else "rccl"
+        d["exchange_mode"] = {0: "block", 1: "strips"}.get(st.exchange_mode % 2, str(st.exchange_mode))
         return d
 
     def stream_wait(self, slot, stream):

@@ -300,6 +300,27 @@ def test_facade_render_through_the_multi_gpu_frame(driver, tmp_path):
 
 
 @pytest.mark.gpu
+def test_facade_render_on_four_ranks_sharing_the_gpu(driver, tmp_path):
+    """MALLIE_GPUS=4 on a one-GPU box (MGPU_FRAME_TRANSPORT=copy: four ranks share the device, copies in place of the RCCL
+    pairs): mallie::Render / RenderPasses through a four-rank frame object -- replicas of the scene, strips, staging, placement,
+    read-back -- must give the oracle's image."""
+    obj = str(tmp_path / "cornell_like.obj")
+    _write_cornell_obj(obj)
+    W, H, passes, mpl, seed = 96, 61, 3, 6, 5
+    out = str(tmp_path / "img.f32")
+    r = subprocess.run([driver, "render", "obj", obj, str(W), str(H), "1", str(passes), str(mpl), str(seed), out],
+                       capture_output=True, text=True, cwd=str(tmp_path), env=dict(os.environ, MGPU_FRAME_TRANSPORT="copy", MALLIE_GPUS="4"))
+    assert r.returncode == 0 and "Render on 4 GPUs" in r.stdout, r.stdout + r.stderr
+    raw = np.fromfile(out, "<f4")
+    img, count = raw[: 3 * W * H].reshape(H, W, 3), raw[3 * W * H:].view("<i4").reshape(H, W)
+    g = O.load_golden("cornell_obj")
+    osc = O.OracleScene(g["verts"].astype(np.float64), g["faces"], np.full(len(g["faces"]), 0xFFFFFFFF, "u4"), g["normals"], None)
+    frame = O.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    oimg, _, _, _ = osc.render(frame, W, H, mpl, passes, osc.plane(), O.RNG_HASH, seed=seed)
+    assert img.tobytes() == oimg.tobytes() and np.all(count == passes)
+
+
+@pytest.mark.gpu
 def test_facade_render_in_the_fast_mode(driver, tmp_path):
     """MALLIE_FAST=1: mallie::Render / RenderPasses in fp32 (plain and through the multi-GPU frame): close to the oracle's
     frame -- rms per-pixel L2 of the pixel means <= 1e-3 at this tiny size, under 0.5 % of the pixels moved by more than

@@ -1013,6 +1013,43 @@ def test_c_abi_frame_on_one_gpu(force, monkeypatch):
         M.Frame([sc], [1], W, H, strip_h=8, frames_in_flight=1)
 
 
+@pytest.mark.parametrize("world,mode", [(2, "block"), (3, "strips"), (8, "block"), (8, "strips")])
+def test_c_abi_frame_with_several_ranks_on_one_gpu(world, mode, monkeypatch):
+    """The N > 1 machinery of mgpu_frame_* with N = 2, 3, 8 ranks on the ONE GPU of the test box: MGPU_FRAME_TRANSPORT=copy puts a
+    device-to-device copy where every ncclSend / ncclRecv pair would be and lets the ranks share a device; everything else is
+    the production path -- one scene per rank, every rank renders ITS interleaved strips (ragged height: the last strip is
+    partial and some ranks own one strip more than others), rank 0's staging area and strided placement (block) or per-strip
+    pieces (strips), slot events, three frames in flight, a batch of three frames per launch.  Every assembled frame must equal
+    the single-launch frame of the same passes byte for byte."""
+    import torch
+    monkeypatch.setenv("MGPU_FRAME_TRANSPORT", "copy")
+    monkeypatch.setenv("MGPU_FRAME_EXCHANGE", mode)
+    scenes = [gpu_scene("cornell_obj") for _ in range(world)]
+    W, H, mpl, passes = 200, 203, 5, 2
+    cam = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    plane = scenes[0].plane()
+    fr = M.Frame(scenes, [0] * world, W, H, strip_h=8, frames_in_flight=3)
+    slots = [fr.render(cam, mpl, passes, plane, seed=9, pass_base=k * passes) for k in range(2)]
+    frames = [fr.wait(s, to_host=True) for s in slots]
+    slots = fr.render_batch(cam, mpl, passes, 3, plane, seed=9, pass_base=2 * passes)  # wraps round the three slots
+    frames += [fr.wait(s, to_host=True) for s in slots]
+    fs = fr.stats()
+    assert fs["world"] == world and fs["members"] == world and fs["transport"] == "copy" and fs["exchange_mode"] == mode
+    assert fs["rccl_ranks"] == 0 and fs["frames"] == 5 and fs["exchange_frames"] == 5
+    n_strips_others = sum(len(M.frame_plan(W, H, 8, world, r)[0]) for r in range(1, world))
+    assert fs["exchange_ops_per_frame"] == (world - 1 if mode == "block" else n_strips_others)
+    for k, img in enumerate(frames):
+        ref = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        scenes[0].render_strips_device(cam, W, H, ref.data_ptr(), H, maxPathLength=mpl, passes=passes, plane=plane, seed=9,
+                                       pass_base=k * passes)
+        assert img.tobytes() == ref.cpu().numpy().tobytes(), (world, mode, k)
+    fr.close()
+    # without the copy transport, ranks cannot share a device
+    monkeypatch.delenv("MGPU_FRAME_TRANSPORT")
+    with pytest.raises(M.MgpuError):
+        M.Frame(scenes[:2], [0, 0], W, H, strip_h=8, frames_in_flight=1)
+
+
 @pytest.mark.parametrize("scene_name,budget_mb", [("cornell_obj", None), ("cornell_obj", "1"), ("teapot_obj", None)])
 def test_frames_per_launch_equal_single_frames(scene_name, budget_mb, monkeypatch):
     """mgpu_render_frames_device: n consecutive frames in one call -- as many per launch as the plane budget holds (all five
