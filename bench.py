@@ -340,7 +340,8 @@ def main():
     # only provides the per-device synchronisation.
     # (MALLIE_BENCH_SINGLE=1: that code path with N = 1 -- what the one-GPU test box can exercise of it)
     single = env_world == 1 and (args.gpus > 1 or bool(os.environ.get("MALLIE_BENCH_SINGLE")))
-    if single and args.gpus > M.device_count():
+    share_devices = os.environ.get("MGPU_FRAME_TRANSPORT") == "copy"  # test aid: ranks may share a device (include/mgpu.h)
+    if single and args.gpus > M.device_count() and not share_devices:
         raise SystemExit("--gpus %d: only %d HIP device(s) visible" % (args.gpus, M.device_count()))
     world = args.gpus if single else env_world
     n_gpus = world
@@ -360,7 +361,7 @@ def main():
     mpl, spp = cfg["bounces"] + 1, cfg["spp"]
     n_tris = workloads.n_tris(cfg)
     # scene(s): BVH by this library's builder (host below 65 536 triangles, device above), resident in HBM before the timed region
-    devices = list(range(world)) if single else [local_rank]
+    devices = [d % M.device_count() for d in range(world)] if single else [local_rank]
     scenes = [workloads.make_scene(cfg, device=d) for d in devices]
     scene = scenes[0]
     torch.cuda.set_device(local_rank)
@@ -430,7 +431,7 @@ def main():
             del pending[:]
 
     def sync_all():
-        for d in devices:
+        for d in sorted(set(devices)):
             torch.cuda.synchronize(d)
         if multi_proc:
             dist.barrier(device_ids=[local_rank])
@@ -464,6 +465,21 @@ def main():
     st = sts[0]
     fstats = cframe.stats() if cframe is not None else None
     last_pass_base = (args.steps - 1) * spp
+    # N > 1 checks itself: the last timed frame once more through the N-rank frame object, and the same passes by rank 0's GPU
+    # alone (the single-GPU path, which the test-suite pins to the oracle) -- per-(pixel, pass) seeding makes them the same bytes
+    same_as_one_gpu = None
+    if cframe is not None and world > 1:
+        slot = cframe.render(frame, mpl, spp, plane, seed=cfg["seed"], pass_base=last_pass_base)
+        got = cframe.wait(slot, to_host=(rank == 0))
+        if rank == 0:
+            ref = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+            scene.render_strips_device(frame, W, H, ref.data_ptr(), H, maxPathLength=mpl, passes=spp, plane=plane, seed=cfg["seed"],
+                                       pass_base=last_pass_base)
+            torch.cuda.synchronize(dev)
+            same_as_one_gpu = bool(got.tobytes() == ref.cpu().numpy().tobytes())
+            del ref
+        for sc in scenes:
+            sc.stats_read(reset=True)
 
     # max elapsed over ranks, sum of work over ranks
     work = [float(sum(s[k] for s in sts)) for k in ("real_rays", "nodes", "tris", "trace_calls", "paths")]
@@ -535,7 +551,10 @@ def main():
                 # launch on every rank (a launch carries frames_per_launch frames)
                 "rccl_ranks": fstats["rccl_ranks"] if fstats else (env_world if multi_proc else 0),
                 "kernel_ms_per_launch_by_rank": [round(x, 3) for x in per_rank_kernel]}
+        if same_as_one_gpu is not None:
+            conf["frame_equals_single_gpu_frame"] = same_as_one_gpu
         if fstats:
+            conf["transport"] = fstats["transport"]
             conf["exchange_mode"] = fstats["exchange_mode"]
             conf["exchange_recvs_per_frame"] = fstats["exchange_ops_per_frame"]
             conf["exchange_ms_per_frame"] = (round(fstats["exchange_ms"] / fstats["exchange_frames"], 4)

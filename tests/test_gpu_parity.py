@@ -1332,6 +1332,16 @@ def test_bench_gpus_n_without_a_launcher():
         assert d["n_gpus"] == 1 and d["config"]["rccl_ranks"] == 1 and d["config"]["exchange_mode"] == "block"
         assert len(d["config"]["kernel_ms_per_launch_by_rank"]) == 1 and d["config"]["exchange_ms_per_frame"] > 0
         assert d["cpu_baseline"]["gpu_frame_byte_equal"] is True and d["value"] > 1000
+        # ... and bench.py's N = 4 loop itself with four ranks sharing that device (MGPU_FRAME_TRANSPORT=copy): the line is what an
+        # N-GPU run prints, and the frame the four ranks assembled equals the one GPU's own frame of the same passes
+        env4 = dict(env, MGPU_FRAME_TRANSPORT="copy")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "8", "--warmup", "2"],
+                           capture_output=True, text=True, cwd=ROOT, timeout=600, env=env4)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["n_gpus"] == 4 and d["config"]["transport"] == "copy" and d["config"]["frames_per_launch"] == 8
+        assert len(d["config"]["kernel_ms_per_launch_by_rank"]) == 4 and d["config"]["exchange_recvs_per_frame"] == 3
+        assert d["config"]["frame_equals_single_gpu_frame"] is True and d["config"]["exchange_ms_per_frame"] > 0
 
 
 def _l2_stats(a, b, spp):
