@@ -211,7 +211,7 @@ int mgpu_render_strips_device(MgpuScene *scene, const double frame[12], int W, i
                               uint32_t pass_base, float *d_image, int32_t *d_count, void *stream, MgpuStats *stats);
 /* n_frames consecutive frames of the same window in one call: frame f renders passes pass_base + f * passes ... into
  * d_images[f] (and d_counts[f]; d_counts may be NULL) -- bit for bit what n_frames calls of mgpu_render_strips_device with
- * pass_base advancing by `passes` produce.  As many frames as the scratch budget holds (1 GiB of per-pass planes unless
+ * pass_base advancing by `passes` produce.  As many frames as the scratch budget holds (8 GiB of per-pass planes unless
  * MGPU_PLANES_MAX_MB says otherwise) share ONE persistent launch, so the end of a launch -- waves running out of work one
  * after the other -- is paid once per launch and not once per frame: rank 0's eighth of the 1080p Cornell frame takes 1.10
  * ms alone and 0.80 ms as one of four.  MGPU_RNG_TABLE: d_rng_states holds n_frames * passes tables, frame-major.  `stats`

@@ -1030,14 +1030,17 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
   P.out = d_images[0];
   P.pass_stride = 0;
   const size_t n_floats = 3 * (size_t)n_rows * (size_t)win_w;
-  // Passes are rendered `group` at a time so that the per-pass planes stay below a fixed budget (1 GiB unless
+  // Passes are rendered `group` at a time so that the per-pass planes stay below a fixed budget (8 GiB of the 288 unless
   // MGPU_PLANES_MAX_MB says otherwise); k_accumulate_tiled carries the running float sum from one group to the next, so the
   // additions and their order are those of a single launch.
   if (tiles >= ((uint64_t)1 << 28)) return fail(MGPU_ERR_INVALID, "window too large: %llu tiles", (unsigned long long)tiles);
   int group = passes;
   int fpl = 1; // frames per launch
   if (kern != 0 && passes > 1) {
-    size_t budget = (size_t)1 << 30;
+    // 8 GiB: the 64 passes of the 3840x2160 configuration (6.4 GB) fit one launch.  Every launch ends with a drain (its last
+    // paths finishing on a mostly idle GPU), so fewer, longer launches are faster: at 1 GiB the C5 frame took seven launches and
+    // 272.5 ms, now one and 258.6; C3's 64 passes two launches and 18.0 ms, now one and 17.4.
+    size_t budget = (size_t)8 << 30;
     if (const char *e = getenv("MGPU_PLANES_MAX_MB")) budget = (size_t)(atoll(e) < 1 ? 1 : atoll(e)) << 20;
     const size_t plane_floats = (size_t)tiles * 192; // tile-major planes: 64 pixel slots per 8x8 tile (edge tiles padded)
     const size_t fit = budget / (plane_floats * sizeof(float));
