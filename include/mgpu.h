@@ -166,7 +166,10 @@ int mgpu_render(MgpuScene *scene, const double origin[3], const double corner[3]
  * device (mgpu_stream.hip: a pixel consumes 2 or 2 + 3 (maxPathLength - 1) draws depending on whether its primary ray hits,
  * so start states follow from the primary hit flags of all earlier pixels; one workgroup settles them by speculation), then
  * the frame is rendered from the resulting start-state table.  With the default seed the image is the reference's image.
- * states_out (nullable): the passes * W * H * 4 words of that table (MGPU_RNG_TABLE layout). */
+ * states_out (nullable): the passes * W * H * 4 words of that table (MGPU_RNG_TABLE layout).
+ * The table lives on the device for the duration of the call: 16 bytes per (pass, pixel), i.e. 33 MB per 1080p pass (the
+ * reference renders one pass per Render() call).  One lock is held over both phases, and stream_state is advanced only when
+ * the frame has been rendered: a failed call leaves the reference stream where it was. */
 int mgpu_render_stream(MgpuScene *scene, const double origin[3], const double corner[3], const double du[3],
                        const double dv[3], int W, int H, int maxPathLength, int passes, const float plane[4],
                        uint32_t stream_state[4], float *image_out, int32_t *count_out, uint32_t *states_out, MgpuStats *stats);
