@@ -126,13 +126,27 @@ int mgpu_scene_device(const MgpuScene *scene);
 /* For each of n rays: out[i] = the Intersection Traverse would fill, hit[i] = its bool result. On a miss out[i] has
  * t = DBL_MAX, u = v = 0, faceID = 0xFFFFFFFF and all other fields zero. stats may be NULL. */
 int mgpu_trace(MgpuScene *scene, const MgpuRay *rays, size_t n, MgpuIntersection *out, uint8_t *hit, MgpuStats *stats);
-/* Calls of mgpu_trace with 1..64 rays and stats == NULL -- what Scene::Trace / BVHAccel::Traverse make, one ray per call from
- * every OpenMP thread of the reference (scene.cc:253-315, render.cc:403) -- go through a submission queue: the calls that are
+/* Calls of mgpu_trace with 2..64 rays and stats == NULL (and one-ray calls when the resident server below is switched off) --
+ * small requests from many host threads, as the reference's OpenMP loops make them (scene.cc:253-315, render.cc:403) -- go
+ * through a submission queue: the calls that are
  * inside mgpu_trace at the same time are served by ONE launch (one of the callers packs everybody's rays into host memory the
  * device maps, the traversal writes the records straight back, no copy engine in the path), a caller that is alone waits for
  * nobody.  Same records as a launch per call.  MGPU_TRACE_QUEUE=0 (read when the scene is created) switches it off.
  * mgpu_trace_queue_stats: combined launches so far and the calls they served. */
 int mgpu_trace_queue_stats(MgpuScene *scene, uint64_t *launches, uint64_t *calls);
+/* Calls of mgpu_trace with exactly ONE ray and stats == NULL -- Scene::Trace as the reference calls it -- launch nothing while a
+ * RESIDENT SERVER is alive: the caller writes its ray and a request number into a mailbox slot in host memory the device maps, a
+ * resident wave (k_trace_server, 16 waves, the same traversal as the batched kernel) writes the Intersection back beside its
+ * acknowledgement.  The first call (and the first after a pause) launches the server; it leaves by itself after
+ * MGPU_TRACE_SERVER_IDLE_US (default 1000) without requests and at the latest MGPU_TRACE_SERVER_LIFE_US (default 100000) after
+ * its launch, so a hipDeviceSynchronize / hipFree elsewhere in the process waits at most that long; the render entry points
+ * retire it before they launch.  Same records as the batched path.  MGPU_TRACE_SERVER=0 (read when the scene is created) sends
+ * one-ray calls through the submission queue instead.
+ * mgpu_trace_server_stats: launches of the server so far, calls it served, whether a launch is alive right now, and (device_us,
+ * may be NULL) the mean device time of a call from the poll that found it to its acknowledgement.
+ * mgpu_trace_server_retire: asks a live launch to leave and returns when it has (a few tens of microseconds). */
+int mgpu_trace_server_stats(MgpuScene *scene, uint64_t *launches, uint64_t *calls, int *alive, double *device_us);
+int mgpu_trace_server_retire(MgpuScene *scene);
 /* The same with rays, records and hit flags resident in device memory (d_out 16-byte aligned), enqueued on `stream`
  * (a hipStream_t, NULL = default stream) without synchronising; with stats != NULL the call waits for the kernel and
  * returns its counters and time. */

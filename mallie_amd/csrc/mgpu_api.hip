@@ -140,6 +140,21 @@ struct MgpuScene {
   uint32_t probe_pixel = 0, probe_pass = 0;
   int pix_step = 1;            // set only for the duration of mgpu_render_step
   bool trace_queue_on = true;  // MGPU_TRACE_QUEUE=0: every small mgpu_trace call launches on its own (A/B measurements, tests)
+  // resident trace server of the one-ray callers (trace_served; kernel: mgpu_trace_server.hip)
+  bool srv_on = true;                 // MGPU_TRACE_SERVER=0: one-ray calls go through the submission queue instead
+  bool srv_stage = true;              // MGPU_TRACE_SERVER_LDS=0: the server never copies the scene into LDS
+  std::mutex srv_mutex;               // set-up, launches and retirements
+  TraceMailbox *srv_mb = nullptr;     // host address of the mailbox (mapped, coherent)
+  TraceMailbox *srv_mb_dev = nullptr; // the device's address of it
+  TraceServerCtl *srv_ctl = nullptr;  // device
+  void *srv_overflow = nullptr;       // the server's own stack overflow columns (deep trees only)
+  hipStream_t srv_stream = nullptr;   // non-blocking: the default stream's work must not wait for a resident kernel
+  std::atomic<uint32_t> srv_epoch{0}; // number of the latest launch (0: none yet); the mailbox says which one has ended
+  std::atomic<bool> srv_ready{false};
+  std::atomic<unsigned char> srv_busy[kSrvSlots]; // a caller owns a slot while its call lasts
+  uint32_t srv_seq[kSrvSlots] = {};   // request numbers, written by the slot's owner
+  std::atomic<unsigned long long> srv_launches{0}, srv_calls{0}, srv_ticks{0}; // ticks: device time of the served calls, 10 ns units
+  unsigned long long srv_idle_us = 1000, srv_life_us = 100000; // MGPU_TRACE_SERVER_IDLE_US / _LIFE_US
   bool tile_order_on = true;   // MGPU_TILE_ORDER (read once, when the scene is created)
   unsigned tile_order_every = 4; // MGPU_TILE_ORDER_EVERY
 };
@@ -494,6 +509,193 @@ int trace_coalesced(MgpuScene *s, TraceTicket &t) {
   return t.rc;
 }
 
+// ---- mgpu_trace with ONE ray: the resident server (mgpu_trace_server.hip) -------------------------------------------------------
+// The submission queue above shares a launch among the callers that happen to be inside mgpu_trace together; a caller that is
+// alone still pays the launch + completion round trip (~22 us).  Here no call launches anything as long as a server launch is
+// alive: the caller takes a mailbox slot, writes its ray and a request number into host memory the device maps, and spins on the
+// acknowledgement the device writes next to the finished record.  A launch leaves by itself after srv_idle_us without requests
+// (and at the latest after srv_life_us), so hipDeviceSynchronize / hipFree elsewhere in the process wait at most that long; the
+// render entry points retire it before they launch, because their persistent kernels want every CU to themselves.
+inline void cpu_relax() {
+#if defined(__x86_64__)
+  __builtin_ia32_pause();
+#endif
+}
+
+std::mutex g_srv_mutex;
+std::vector<MgpuScene *> g_srv_scenes; // scenes whose server has been set up (any device)
+
+int server_init_locked(MgpuScene *s) {
+  if (s->srv_ready.load()) return MGPU_OK;
+  int rc = set_device(s);
+  if (rc) return rc;
+  void *host = nullptr;
+  hipError_t e = hipHostMalloc(&host, sizeof(TraceMailbox), hipHostMallocMapped | hipHostMallocCoherent);
+  if (e != hipSuccess) return fail(MGPU_ERR_OOM, "hipHostMalloc(trace mailbox): %s", hipGetErrorString(e));
+  memset(host, 0, sizeof(TraceMailbox));
+  void *dev = nullptr;
+  e = hipHostGetDevicePointer(&dev, host, 0);
+  if (e == hipSuccess) e = hipMalloc((void **)&s->srv_ctl, sizeof(TraceServerCtl));
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->srv_stream, hipStreamNonBlocking);
+  const int extra = s->stack_need - s->cap;
+  if (e == hipSuccess && extra > 0) e = hipMalloc(&s->srv_overflow, (size_t)kSrvWaves * 64 * (size_t)extra * sizeof(uint32_t));
+  if (e != hipSuccess) {
+    (void)hipHostFree(host);
+    if (s->srv_ctl) (void)hipFree(s->srv_ctl);
+    if (s->srv_stream) (void)hipStreamDestroy(s->srv_stream);
+    s->srv_ctl = nullptr; s->srv_stream = nullptr;
+    return fail(MGPU_ERR_HIP, "trace server set-up: %s", hipGetErrorString(e));
+  }
+  for (int i = 0; i < kSrvSlots; i++) s->srv_busy[i].store(0);
+  s->srv_mb = (TraceMailbox *)host;
+  s->srv_mb_dev = (TraceMailbox *)dev;
+  return MGPU_OK;
+}
+
+int server_init(MgpuScene *s) {
+  std::lock_guard<std::mutex> g(g_srv_mutex); // lock order everywhere: registry, then scene
+  std::lock_guard<std::mutex> lk(s->srv_mutex);
+  if (s->srv_ready.load()) return MGPU_OK;
+  int rc = server_init_locked(s);
+  if (rc) return rc;
+  g_srv_scenes.push_back(s);
+  s->srv_ready.store(true, std::memory_order_release);
+  return MGPU_OK;
+}
+
+inline bool server_alive(const MgpuScene *s) {
+  const uint32_t ep = s->srv_epoch.load(std::memory_order_acquire);
+  return ep != 0 && __atomic_load_n(&s->srv_mb->exited_epoch, __ATOMIC_ACQUIRE) != ep;
+}
+
+// Launches server number seen_epoch + 1 unless somebody else already has.
+int server_launch(MgpuScene *s, uint32_t seen_epoch) {
+  std::lock_guard<std::mutex> lk(s->srv_mutex);
+  if (s->srv_epoch.load() != seen_epoch) return MGPU_OK;
+  int rc = set_device(s);
+  if (rc) return rc;
+  DScene d = s->d; // the scene as the batched trace sees it, with the server's own overflow columns
+  const int extra = s->stack_need - s->cap;
+  d.stack_overflow = extra > 0 ? (uint32_t *)s->srv_overflow : nullptr;
+  d.overflow_cap = extra > 0 ? (uint32_t)extra : 0u;
+  HIP_TRY(hipMemsetAsync(s->srv_ctl, 0, sizeof(TraceServerCtl), s->srv_stream));
+  const unsigned long long ticks_per_us = 100; // wall_clock64(): the constant 100 MHz counter
+  // a scene whose nodes and triangles fit beside the stacks is walked from LDS (MGPU_TRACE_SERVER_LDS=0: never)
+  const size_t nodes_bytes = sizeof(MgpuNode) * s->nn, tris_bytes = sizeof(DTri) * s->nf;
+  const bool stage = s->srv_stage && nodes_bytes + tris_bytes + (size_t)s->cap * 256 + 1024 <= 160 * 1024;
+  HIP_TRY(launch_trace_server(s->cap, s->srv_stream, d, s->srv_mb_dev, s->srv_ctl, seen_epoch + 1, s->srv_idle_us * ticks_per_us,
+                              s->srv_life_us * ticks_per_us, s->srv_life_us * 20ull + 1000ull, stage ? (uint32_t)nodes_bytes : 0u,
+                              stage ? (uint32_t)tris_bytes : 0u));
+  s->srv_launches.fetch_add(1);
+  s->srv_epoch.store(seen_epoch + 1, std::memory_order_release);
+  return MGPU_OK;
+}
+
+// Asks a live launch to leave and waits until it has (tens of microseconds).  Called before anything that wants the whole
+// device (persistent render kernels) or frees what the server reads.
+int server_retire(MgpuScene *s) {
+  if (!s->srv_ready.load() || !server_alive(s)) return MGPU_OK;
+  std::lock_guard<std::mutex> lk(s->srv_mutex);
+  if (!server_alive(s)) return MGPU_OK;
+  __atomic_store_n(&s->srv_mb->stop, 1u, __ATOMIC_RELEASE);
+  const double t0 = now_ms();
+  while (server_alive(s)) {
+    cpu_relax();
+    if (now_ms() - t0 > 5000.0) {
+      __atomic_store_n(&s->srv_mb->stop, 0u, __ATOMIC_RELEASE);
+      return fail(MGPU_ERR_HIP, "trace server did not leave within 5 s");
+    }
+  }
+  __atomic_store_n(&s->srv_mb->stop, 0u, __ATOMIC_RELEASE);
+  return MGPU_OK;
+}
+
+// Every live server on `device` leaves: the persistent render kernels size themselves for a whole device.
+int servers_retire_device(int device) {
+  std::lock_guard<std::mutex> g(g_srv_mutex);
+  for (MgpuScene *o : g_srv_scenes)
+    if (o->device == device) {
+      int rc = server_retire(o);
+      if (rc) return rc;
+    }
+  return MGPU_OK;
+}
+
+void server_destroy(MgpuScene *s) {
+  if (!s->srv_ready.load()) return;
+  {
+    std::lock_guard<std::mutex> g(g_srv_mutex);
+    for (size_t i = 0; i < g_srv_scenes.size(); i++)
+      if (g_srv_scenes[i] == s) { g_srv_scenes.erase(g_srv_scenes.begin() + (long)i); break; }
+  }
+  (void)server_retire(s);
+  (void)hipStreamSynchronize(s->srv_stream);
+  (void)hipStreamDestroy(s->srv_stream);
+  (void)hipFree(s->srv_ctl);
+  if (s->srv_overflow) (void)hipFree(s->srv_overflow);
+  (void)hipHostFree(s->srv_mb);
+  s->srv_ready.store(false);
+  s->srv_mb = nullptr;
+}
+
+int trace_served(MgpuScene *s, const MgpuRay *ray, MgpuIntersection *out, uint8_t *hit) {
+  if (!s->srv_ready.load(std::memory_order_acquire)) {
+    int rc = server_init(s);
+    if (rc) return rc;
+  }
+  TraceMailbox *mb = s->srv_mb;
+  // a slot of our own for the call: threads start from different waves' slots, so as many waves as callers work at once
+  static std::atomic<unsigned> next_thread{0};
+  thread_local unsigned my = next_thread.fetch_add(1);
+  unsigned slot = 0;
+  for (unsigned tries = 0;; ++tries) {
+    const unsigned j = my + tries; // waves first, then lanes: all kSrvSlots slots in kSrvSlots tries
+    slot = (j % kSrvWaves) * kSrvSlotsPerWave + (j / kSrvWaves) % kSrvSlotsPerWave;
+    unsigned char expected = 0;
+    if (s->srv_busy[slot].compare_exchange_strong(expected, 1, std::memory_order_acquire)) break;
+    if (tries >= (unsigned)kSrvSlots) cpu_relax(); // more callers than slots: wait for one
+  }
+  const uint32_t seq = ++s->srv_seq[slot];
+  memcpy(&mb->ray[slot][0], ray->org, sizeof(double) * 3);
+  memcpy(&mb->ray[slot][3], ray->dir, sizeof(double) * 3);
+  __atomic_store_n(&mb->req[slot], seq, __ATOMIC_RELEASE);
+  int rc = MGPU_OK;
+  const double t0 = now_ms();
+  for (unsigned spins = 0;; ++spins) {
+    if (__atomic_load_n(&mb->ack[slot], __ATOMIC_ACQUIRE) == seq) break;
+    const uint32_t ep = s->srv_epoch.load(std::memory_order_acquire);
+    if (ep == 0 || __atomic_load_n(&mb->exited_epoch, __ATOMIC_ACQUIRE) == ep) {
+      // nobody is serving (no launch yet, or the last one left before it saw this request): one of the waiting callers launches
+      if (__atomic_load_n(&mb->ack[slot], __ATOMIC_ACQUIRE) == seq) break; // served by the launch that has just left
+      rc = server_launch(s, ep);
+      if (rc) break;
+    }
+    cpu_relax();
+    if ((spins & 0xFFFu) == 0xFFFu && now_ms() - t0 > 10000.0) {
+      rc = fail(MGPU_ERR_HIP, "trace server did not answer within 10 s");
+      break;
+    }
+  }
+  if (!rc) {
+    memcpy(out, &mb->rec[slot], sizeof(MgpuIntersection));
+    *hit = (uint8_t)mb->hit[slot];
+    s->srv_calls.fetch_add(1, std::memory_order_relaxed);
+    s->srv_ticks.fetch_add(mb->ticks[slot], std::memory_order_relaxed);
+#ifdef MGPU_SRV_PROFILE
+    {
+      static std::atomic<unsigned long long> pr[4], pn;
+      for (int k = 0; k < 4; k++) pr[k].fetch_add(mb->prof[slot][k]);
+      const unsigned long long n = pn.fetch_add(1) + 1;
+      if (n % 2000 == 0)
+        fprintf(stderr, "srv profile after %llu calls: ray load %.2f us, traversal %.2f us (%.1f nodes + %.1f tris), whole call on the device %.2f us\n", n,
+                0.01 * pr[0] / n, 0.01 * pr[1] / n, (double)pr[2] / n, (double)pr[3] / n, 0.01 * s->srv_ticks.load() / s->srv_calls.load());
+    }
+#endif
+  }
+  s->srv_busy[slot].store(0, std::memory_order_release);
+  return rc;
+}
+
 } // namespace
 
 extern "C" {
@@ -659,6 +861,10 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
   if (const char *e = getenv("MGPU_PLAIN_SLABS")) // 0: literal slab test only (A/B measurements, tests)
     if (atoi(e) == 0) s->d.boxes_ordered = 0;
   if (const char *e = getenv("MGPU_TRACE_QUEUE")) s->trace_queue_on = atoi(e) != 0;
+  if (const char *e = getenv("MGPU_TRACE_SERVER")) s->srv_on = atoi(e) != 0;
+  if (const char *e = getenv("MGPU_TRACE_SERVER_LDS")) s->srv_stage = atoi(e) != 0;
+  if (const char *e = getenv("MGPU_TRACE_SERVER_IDLE_US")) s->srv_idle_us = (unsigned long long)(atoll(e) < 1 ? 1 : atoll(e));
+  if (const char *e = getenv("MGPU_TRACE_SERVER_LIFE_US")) s->srv_life_us = (unsigned long long)(atoll(e) < 100 ? 100 : atoll(e));
   if (const char *e = getenv("MGPU_TILE_ORDER")) s->tile_order_on = atoi(e) != 0;
   if (const char *e = getenv("MGPU_TILE_ORDER_EVERY")) s->tile_order_every = atoi(e) < 1 ? 1u : (unsigned)atoi(e);
   *out = s;
@@ -669,6 +875,7 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
 int mgpu_scene_destroy(MgpuScene *s) {
   if (!s) return MGPU_OK;
   (void)hipSetDevice(s->device);
+  server_destroy(s);
   (void)hipDeviceSynchronize();
   void *ptrs[] = {s->p_nodes, s->p_tris, s->p_slotn, s->p_mat, s->p_verts, s->p_faces, s->p_fvn, s->p_fvuv,
                   s->p_overflow, s->p_counters, s->p_stats, s->p_wave_log, s->p_host_img, s->p_trace, s->p_wnodes,
@@ -793,7 +1000,8 @@ int mgpu_trace_device(MgpuScene *s, const MgpuRay *d_rays, size_t n, MgpuInterse
 int mgpu_trace(MgpuScene *s, const MgpuRay *rays, size_t n, MgpuIntersection *out, uint8_t *hit, MgpuStats *stats) {
   if (!s) return fail(MGPU_ERR_INVALID, "scene is NULL");
   if (n && (!rays || !out || !hit)) return fail(MGPU_ERR_INVALID, "rays/out/hit must be non-NULL");
-  if (n >= 1 && n <= kTraceCoalesceMax && !stats && s->trace_queue_on) { // Scene::Trace / BVHAccel::Traverse: one ray per call
+  if (n == 1 && !stats && s->srv_on) return trace_served(s, rays, out, hit); // Scene::Trace / BVHAccel::Traverse: one ray per call
+  if (n >= 1 && n <= kTraceCoalesceMax && !stats && s->trace_queue_on) { // a few rays per call, possibly from many threads
     TraceTicket t;
     t.rays = rays; t.n = n; t.out = out; t.hit = hit;
     t.err[0] = 0;
@@ -928,6 +1136,7 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
   }
   const double t0 = now_ms();
   int rc = set_device(s);
+  if (!rc) rc = servers_retire_device(s->device); // a resident trace server leaves first: this launch wants every CU
   if (rc) return rc;
   if (stats) memset(stats, 0, sizeof(*stats));
   const int win_w = x1 - x0;
@@ -1383,6 +1592,7 @@ int mgpu_render_stream(MgpuScene *s, const double origin[3], const double corner
   std::lock_guard<std::mutex> host_lock(s->host_mutex);
   uint32_t next_state[4];
   int rc = set_device(s);
+  if (!rc) rc = servers_retire_device(s->device); // a resident trace server leaves first: this launch wants every CU
   if (rc) return rc;
   {
     static std::vector<uint32_t> jump; // T^(2^j) over GF(2), computed once per process
@@ -1566,6 +1776,7 @@ int mgpu_render_aov(MgpuScene *s, const double origin[3], const double corner[3]
   std::lock_guard<std::mutex> host_lock(s->host_mutex);
   const double t0 = now_ms();
   int rc = set_device(s);
+  if (!rc) rc = servers_retire_device(s->device); // a resident trace server leaves first: this launch wants every CU
   if (rc) return rc;
   if (stats) memset(stats, 0, sizeof(*stats));
   const size_t npix = (size_t)W * H, img_bytes = sizeof(float) * 3 * npix;
@@ -1653,6 +1864,7 @@ int mgpu_render_panoramic_device(MgpuScene *s, const double origin[3], int W, in
   if (rng_mode == MGPU_RNG_TABLE && !d_rng_states) return fail(MGPU_ERR_INVALID, "MGPU_RNG_TABLE needs rng_states");
   const double t0 = now_ms();
   int rc = set_device(s);
+  if (!rc) rc = servers_retire_device(s->device); // a resident trace server leaves first: this launch wants every CU
   if (rc) return rc;
   if (stats) memset(stats, 0, sizeof(*stats));
   const int ww = x1 - x0, wh = y1 - y0;
@@ -1778,6 +1990,20 @@ int mgpu_render_panoramic(MgpuScene *s, const double origin[3], int W, int H, in
   }
   return MGPU_OK;
 #undef TRY_R
+}
+
+int mgpu_trace_server_stats(MgpuScene *s, uint64_t *launches, uint64_t *calls, int *alive, double *device_us) {
+  if (!s || !launches || !calls || !alive) return fail(MGPU_ERR_INVALID, "NULL argument");
+  *launches = s->srv_launches.load();
+  *calls = s->srv_calls.load();
+  if (device_us) *device_us = *calls ? 0.01 * (double)s->srv_ticks.load() / (double)*calls : 0.0;
+  *alive = s->srv_ready.load() && server_alive(s) ? 1 : 0;
+  return MGPU_OK;
+}
+
+int mgpu_trace_server_retire(MgpuScene *s) {
+  if (!s) return fail(MGPU_ERR_INVALID, "scene is NULL");
+  return server_retire(s);
 }
 
 int mgpu_trace_queue_stats(MgpuScene *s, uint64_t *launches, uint64_t *calls) {

@@ -56,48 +56,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(DScene sc, const MgpuRay *__re
     for (int q = 0; q < 4; ++q) {
       if (live && (lane >> 4) == q) {
         MgpuIntersection *is = reinterpret_cast<MgpuIntersection *>(stage + (lane & 15) * kIsectWords);
-        // a miss leaves t = DBL_MAX, u = v = 0, faceID = -1 (bvh_accel.cc:782-786); every other field is zeroed here
-        is->t = h.t; is->u = h.u; is->v = h.v;
-        uint32_t faceID = 0xFFFFFFFFu, materialID = 0, f0 = 0, f1 = 0, f2 = 0;
-        V3 pos = v3(0, 0, 0), gn = v3(0, 0, 0), sn = v3(0, 0, 0);
-        double tc0 = 0.0, tc1 = 0.0;
-        if (!hit && h.slot != kNoHit) {
-          faceID = sc.tris[h.slot].face;
-          materialID = sc.tris[h.slot].mat;
-        }
-        if (hit) {
-          // BuildIntersection, bvh_accel.cc:699-769
-          const DTri *tp = sc.tris + h.slot;
-          const uint32_t face = tp->face;
-          faceID = face;
-          materialID = tp->mat;
-          f0 = sc.faces[3 * (size_t)face + 0];
-          f1 = sc.faces[3 * (size_t)face + 1];
-          f2 = sc.faces[3 * (size_t)face + 2];
-          pos = v3(org.x + h.t * dir.x, org.y + h.t * dir.y, org.z + h.t * dir.z);
-          const V3 e1 = v3(tp->e1[0], tp->e1[1], tp->e1[2]), e2 = v3(tp->e2[0], tp->e2[1], tp->e2[2]);
-          gn = normalized(cross(e1, e2));
-          if (sc.fv_normals) {
-            const double *nn = sc.fv_normals + 9 * (size_t)face;
-            const double w = 1.0 - h.u - h.v;
-            sn = v3(w * nn[0] + h.u * nn[3] + h.v * nn[6], w * nn[1] + h.u * nn[4] + h.v * nn[7],
-                    w * nn[2] + h.u * nn[5] + h.v * nn[8]);
-          } else {
-            sn = gn;
-          }
-          if (sc.fv_uvs) {
-            const double *uv = sc.fv_uvs + 6 * (size_t)face;
-            const double w = 1.0 - h.u - h.v;
-            tc0 = w * uv[0] + h.u * uv[2] + h.v * uv[4];
-            tc1 = w * uv[1] + h.u * uv[3] + h.v * uv[5];
-          }
-        }
-        is->faceID = faceID; is->materialID = materialID; is->f0 = f0; is->f1 = f1; is->f2 = f2; is->pad_ = 0;
-        is->position[0] = pos.x; is->position[1] = pos.y; is->position[2] = pos.z;
-        is->geometricNormal[0] = gn.x; is->geometricNormal[1] = gn.y; is->geometricNormal[2] = gn.z;
-        is->normal[0] = sn.x; is->normal[1] = sn.y; is->normal[2] = sn.z;
-        for (int k = 0; k < 3; ++k) { is->tangent[k] = 0.0; is->binormal[k] = 0.0; }
-        is->texcoord[0] = tc0; is->texcoord[1] = tc1;
+        fill_intersection(sc, org, dir, h, hit, is);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();

@@ -127,6 +127,33 @@ void stream_jump_matrices(uint32_t *out /* kStreamJumpBits * 128 * 4 words */);
 hipError_t launch_trace_sm(dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, uint32_t n,
                            MgpuIntersection *out, uint8_t *hit, uint32_t *counter, unsigned long long *stats,
                            const uint32_t *select);
+// k_trace_server (mgpu_trace_server.hip): resident traversal for one-ray-per-call callers.  The mailbox lives in host memory
+// the device maps (hipHostMallocMapped | hipHostMallocCoherent); every word has ONE writer.
+constexpr int kSrvWaves = 16;         // one 64-thread workgroup each
+constexpr int kSrvSlotsPerWave = 16;  // the 64 bytes of request numbers a wave polls with one load
+constexpr int kSrvSlots = kSrvWaves * kSrvSlotsPerWave;
+struct alignas(64) TraceMailbox {
+  uint32_t req[kSrvSlots];  // host: number of the slot's latest request (a caller owns the slot while its call lasts)
+  uint32_t ack[kSrvSlots];  // device: number of the latest request served; written after rec / hit
+  uint32_t hit[kSrvSlots];  // device: Traverse's bool
+  uint32_t ticks[kSrvSlots]; // device: 10 ns ticks from the poll that found the request to its acknowledgement
+  uint32_t stop;            // host: != 0 asks the running launch to leave (render entry points, scene destruction)
+  uint32_t pad0_[15];
+  uint32_t exited_epoch;    // device: epoch of the last launch all of whose waves have left
+  uint32_t pad1_[15];
+  alignas(16) double ray[kSrvSlots][6]; // host: org, dir (what Traverse reads of a Ray)
+  MgpuIntersection rec[kSrvSlots];  // device
+#ifdef MGPU_SRV_PROFILE
+  uint32_t prof[kSrvSlots][4];      // device, diagnostic builds: ticks of the ray load, of the traversal; nodes, triangles
+#endif
+};
+struct TraceServerCtl { // device memory, zeroed on the server's stream before every launch
+  uint32_t quit, exited;
+  unsigned long long last_work; // wall_clock64() of the last poll that found a request
+};
+hipError_t launch_trace_server(int cap, hipStream_t s, const DScene &sc, TraceMailbox *mb, TraceServerCtl *ctl, uint32_t epoch,
+                               unsigned long long idle_ticks, unsigned long long life_ticks, unsigned long long max_polls,
+                               uint32_t stage_nodes_bytes, uint32_t stage_tris_bytes); // != 0: the scene is copied into LDS
 void launch_count_add(hipStream_t s, int32_t *count, size_t npix, int passes); // single pass: count[px] += 1 only
 // pass accumulation from tile-major planes (k_render_sm with several passes): plane_stride = tiles * 192 floats
 void launch_accumulate_tiled(hipStream_t s, const float *planes, size_t plane_stride, int passes, size_t n_floats, int win_w,

@@ -85,6 +85,10 @@ def load_library():
     L.mgpu_scene_device.restype = i32
     L.mgpu_trace.argtypes = [vp, vp, sz, vp, vp, vp]
     L.mgpu_trace.restype = i32
+    L.mgpu_trace_server_stats.argtypes = [vp, vp, vp, vp, vp]
+    L.mgpu_trace_server_stats.restype = i32
+    L.mgpu_trace_server_retire.argtypes = [vp]
+    L.mgpu_trace_server_retire.restype = i32
     L.mgpu_render.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, u64, u32, vp, vp,
                               vp]
     L.mgpu_render.restype = i32
@@ -432,6 +436,34 @@ class Scene:
         st = Stats()
         _check(load_library().mgpu_trace(self.h, _p(rays), len(rays), _p(out), _p(hit), C.byref(st)), "mgpu_trace")
         return (out, hit, st.as_dict()) if want_stats else (out, hit)
+
+    def trace_calls(self, rays, per_call=1):
+        """The same rays as `per_call`-ray mgpu_trace calls without statistics -- Scene::Trace as the reference calls it
+        (per_call = 1: the resident server; 2..64: the submission queue).  -> (ISECT_DT array, hit uint8 array)"""
+        rays = np.asarray(rays)
+        if rays.dtype != RAY_DT:
+            r6 = _c(rays, "<f8").reshape(-1, 6)
+            rays = np.zeros(len(r6), RAY_DT)
+            rays["org"], rays["dir"] = r6[:, :3], r6[:, 3:]
+        rays = np.ascontiguousarray(rays)
+        out = np.zeros(len(rays), ISECT_DT)
+        hit = np.zeros(len(rays), "u1")
+        L = load_library()
+        base_r, base_o, base_h = rays.ctypes.data, out.ctypes.data, hit.ctypes.data
+        for i in range(0, len(rays), per_call):
+            n = min(per_call, len(rays) - i)
+            _check(L.mgpu_trace(self.h, C.c_void_p(base_r + i * RAY_DT.itemsize), n, C.c_void_p(base_o + i * ISECT_DT.itemsize),
+                                C.c_void_p(base_h + i), None), "mgpu_trace")
+        return out, hit
+
+    def trace_server_stats(self):
+        """-> dict(launches, calls, alive, device_us): the resident server of the one-ray callers (include/mgpu.h)"""
+        a, b, c, d = C.c_uint64(0), C.c_uint64(0), C.c_int32(0), C.c_double(0.0)
+        _check(load_library().mgpu_trace_server_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "mgpu_trace_server_stats")
+        return dict(launches=a.value, calls=b.value, alive=bool(c.value), device_us=d.value)
+
+    def trace_server_retire(self):
+        _check(load_library().mgpu_trace_server_retire(self.h), "mgpu_trace_server_retire")
 
     def trace_device(self, d_rays_ptr, n, d_out_ptr, d_hit_ptr, stream=None, want_stats=False):
         """mgpu_trace_device: rays (88 B each), Intersection records (184 B) and hit bytes at raw device addresses."""

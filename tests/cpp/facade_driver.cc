@@ -26,6 +26,7 @@
 
 // one diagnostic of the C ABI underneath (include/mgpu.h), declared here so that the driver needs the Mallie headers only
 extern "C" int mgpu_trace_queue_stats(MgpuScene *scene, uint64_t *launches, uint64_t *calls);
+extern "C" int mgpu_trace_server_stats(MgpuScene *scene, uint64_t *launches, uint64_t *calls, int *alive, double *device_us);
 
 static bool init(mallie::Scene &scene, const char *kind, const char *file, double scale) {
   std::string obj, eson, vox, mat;
@@ -201,6 +202,11 @@ int main(int argc, char **argv) {
     if (mgpu_trace_queue_stats(scene.DeviceScene(), &launches, &calls) == 0 && launches)
       printf("trace_mt: submission queue: %llu calls in %llu launches (%.2f per launch)\n", (unsigned long long)calls,
              (unsigned long long)launches, (double)calls / (double)launches);
+    int alive = 0;
+    double dev_us = 0.0;
+    if (mgpu_trace_server_stats(scene.DeviceScene(), &launches, &calls, &alive, &dev_us) == 0 && launches)
+      printf("trace_mt: resident server: %llu calls in %llu launches, %.2f us on the device per call, alive at the end: %d\n",
+             (unsigned long long)calls, (unsigned long long)launches, dev_us, alive);
     FILE *fo = fopen(argv[5], "wb");
     for (size_t i = 0; i < n; i++) {
       wr(fo, &hits[i], 4); wr(fo, &rec[i].faceID, 4); wr(fo, &rec[i].t, 8); wr(fo, &rec[i].u, 8); wr(fo, &rec[i].v, 8);

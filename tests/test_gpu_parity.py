@@ -132,6 +132,101 @@ def test_trace_edge_cases(trace_kernel):
     assert out["faceID"][0] == 7 and out["t"][0] == 24.591497079797261
 
 
+ISECT_FIELDS = ("t", "u", "v", "faceID", "materialID", "f0", "f1", "f2", "position", "geometricNormal", "normal", "tangent",
+                "binormal", "texcoord")
+
+
+def _same_records(a, ha, b, hb):
+    assert np.array_equal(ha, hb)
+    for f in ISECT_FIELDS:
+        assert a[f].tobytes() == b[f].tobytes(), f
+
+
+@pytest.mark.parametrize("lds", ["1", "0"])
+def test_one_ray_calls_through_the_resident_server(monkeypatch, lds):
+    """mgpu_trace with ONE ray per call -- Scene::Trace as the reference calls it (scene.cc:253-315, render.cc:403) -- is served
+    by the resident kernel (k_trace_server: mailbox in mapped host memory, per-lane node walk, leaves across the wave; the scene
+    in LDS when it fits, MGPU_TRACE_SERVER_LDS=0: from HBM): every field of every record equals the batched kernel's, which the
+    tests above pin to the reference's goldens -- NaN rays, zero directions and the reference's 1e308 origins included."""
+    import threading
+    import time
+    monkeypatch.setenv("MGPU_TRACE_SERVER_LDS", lds)
+    monkeypatch.setenv("MGPU_TRACE_SERVER_IDLE_US", "300")
+    sc = gpu_scene("cornell_obj")
+    t = O.load_golden("trace_cornell_obj")
+    rays = np.vstack([t["rays"][:700], np.array([
+        [0, 5, 20, 0, 0, -1.0], [0, 5, 20, 0, 0, 1.0], [0, 5, 0, 0, 0, 0], [1e308, 1e308, 1e308, 0.3, -0.5, 0.8],
+        [0, 5, 20, np.nan, 0, -1.0], [np.nan, 5, 20, 0, 0, -1.0], [0, 0.117050, 0, 1, 0, 0], [-5.144927, 0.117050, -4.948757, 1, 0, 0],
+        [0, 5, 20, 0, 0, -np.inf]])])
+    ref, ref_hit = sc.trace(rays)                       # the batched kernel
+    assert sc.trace_server_stats()["launches"] == 0
+    out, hit = sc.trace_calls(rays, per_call=1)         # the server
+    _same_records(out, hit, ref, ref_hit)
+    st = sc.trace_server_stats()
+    assert st["calls"] == len(rays) and st["launches"] >= 1 and st["device_us"] > 0.0
+    q, qh = sc.trace_calls(rays[:300], per_call=3)      # the submission queue (2..64 rays per call)
+    _same_records(q, qh, ref[:300], ref_hit[:300])
+    assert sc.trace_server_stats()["calls"] == len(rays)
+    # a launch leaves after its idle time, the next call starts another one and is served all the same
+    time.sleep(0.05)
+    st = sc.trace_server_stats()
+    assert not st["alive"]
+    out2, hit2 = sc.trace_calls(rays[:50], per_call=1)
+    _same_records(out2, hit2, ref[:50], ref_hit[:50])
+    st2 = sc.trace_server_stats()
+    assert st2["launches"] == st["launches"] + 1 and st2["calls"] == len(rays) + 50
+    # eight threads at once, each its own rays; then the render entry point retires the live launch before it launches
+    res = [None] * 8
+    def work(k):
+        res[k] = sc.trace_calls(rays[k::8], per_call=1)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+    for x in th: x.start()
+    for x in th: x.join()
+    for k in range(8):
+        _same_records(res[k][0], res[k][1], ref[k::8], ref_hit[k::8])
+    W, H = 64, 48
+    frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    sc.trace_calls(rays[:1], per_call=1)
+    img, _, _ = sc.render(frame, W, H, 4, 1, sc.plane(), M.RNG_HASH, seed=3)
+    assert not sc.trace_server_stats()["alive"]
+    oimg, _, _, _ = O.scene_from_golden("cornell_obj").render(frame, W, H, 4, 1, sc.plane(), O.RNG_HASH, seed=3)
+    assert_images_match(img, oimg, "render after one-ray calls")
+    sc.trace_calls(rays[:1], per_call=1)
+    sc.trace_server_retire()
+    assert not sc.trace_server_stats()["alive"]
+    sc.close()                                         # with a launch possibly alive: destroy retires it first
+
+
+def test_one_ray_calls_on_a_deep_tree_and_a_large_scene():
+    """The server's walk with stack entries beyond the LDS part (depth > 32: its own overflow columns) and with a scene that does
+    not fit in LDS (teapot: walked from HBM), against the batched kernel and the oracle."""
+    verts, faces = _deep_scene()
+    nodes, idx, st = M.bvh_build(verts, faces)
+    sc = M.Scene(verts, faces, None, None, None, nodes, idx)
+    rng = np.random.default_rng(19)
+    n = 400
+    tgt = verts[rng.integers(0, len(verts), n)] * (1 + 0.05 * rng.normal(size=(n, 3)))
+    org = np.tile(np.array([-5.0, 0.3, 0.4]), (n, 1)) * (1 + rng.random((n, 1)) * 50)
+    d = tgt - org
+    rays = np.hstack([org, d / np.linalg.norm(d, axis=1, keepdims=True)])
+    ref, ref_hit = sc.trace(rays)
+    out, hit = sc.trace_calls(rays, per_call=1)
+    _same_records(out, hit, ref, ref_hit)
+    oref = O.OracleScene(verts, faces, None, None, None, nodes, idx).trace(rays)
+    h = oref["hit"] == 1
+    assert np.array_equal(hit, oref["hit"].astype("u1")) and h.sum() > 10 and out["t"][h].tobytes() == oref["t"][h].tobytes()
+    sc.close()
+    sc = gpu_scene("teapot_obj")
+    t = O.load_golden("trace_teapot_obj")
+    ref, ref_hit = sc.trace(t["rays"][:600])
+    out, hit = sc.trace_calls(t["rays"][:600], per_call=1)
+    _same_records(out, hit, ref, ref_hit)
+    g = t["hits"][:600]
+    h = g["hit"] == 1
+    assert np.array_equal(hit, g["hit"].astype("u1")) and out["t"][h].tobytes() == g["t"][h].tobytes()
+    sc.close()
+
+
 def test_trace_device_buffers_match_host_call(trace_kernel):
     """mgpu_trace_device (rays and records resident in HBM, asynchronous) writes the same bytes as mgpu_trace; sizes
     chosen to cover a ragged last wave (n % 64 != 0, n % 16 != 0) and a single ray."""
