@@ -295,6 +295,24 @@ def extra_config(key, lib_path, torch, steps=5):
            "nodes_per_ray": round(st["nodes"] / st["real_rays"], 3), "tris_per_ray": round(st["tris"] / st["real_rays"], 3),
            "device_MB": round(sc.device_bytes() / 1e6, 1),
            "roofline": hbm_roofline(key, st, steps, kms, lib_path)}
+    if key in ("c3", "c4"):
+        # the fast mode (fp32) on this configuration too: its time, and how far its frame is from the fp64 frame
+        # of the same passes (buf holds the last timed frame).  Never the headline; north_star's tolerance is 1e-4.
+        try:
+            ref64 = buf.clone()
+            sc.set_precision("fp32")
+            for k in range(2):
+                render(k)
+            torch.cuda.synchronize()
+            ms_f, kms_f, st_f = time_frames(sc, render, steps, torch.cuda.synchronize)
+            l2 = ((buf.double() - ref64.double()) / spp).pow(2).sum(-1).sqrt()
+            out["fast_mode_fp32"] = {"ms_per_frame": round(ms_f, 3), "kernel_avg_ms": round(kms_f, 3), "speedup_vs_fp64": round(ms / ms_f, 3),
+                                     "rms_per_pixel_l2_to_fp64_frame": float("%.3g" % float(l2.pow(2).mean().sqrt().item())),
+                                     "pixels_moved_over_1e-3": float("%.3g" % float((l2 > 1e-3).double().mean().item())),
+                                     "inside_north_star_1e-4": bool(float(l2.pow(2).mean().sqrt().item()) <= 1e-4)}
+            del ref64
+        except Exception as e:  # an extra line must never take the headline down
+            out["fast_mode_fp32"] = {"error": repr(e)}
     sc.close()
     del buf
     torch.cuda.empty_cache()

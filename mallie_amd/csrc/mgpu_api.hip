@@ -1174,6 +1174,9 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
   // treelet of the scene behind them (mgpu_device.hpp, kWTreelet)
   const bool treelet = kern == 1 && s->d.treelet != nullptr;
   if (treelet) block = 1024;
+#ifdef MGPU_EXP_768
+  if (treelet && getenv("MGPU_RENDER_BLOCK") && atoi(getenv("MGPU_RENDER_BLOCK")) == 768) block = 768;
+#endif
   if (kern == 1) shmem = (size_t)(block / 64) * WStack<kWideStackLds>::kWaveBytes + (treelet ? (size_t)s->d.treelet_n * sizeof(WNode) : 0);
   int per_cu = kern == 2 || treelet ? 1 : (kern == 1 ? 4 : 2); // workgroups per CU: 16 waves per CU for the state-machine kernels
   // fast mode (mgpu_scene_set_precision): k_render_f32 on the float copy of the scene -- 32-byte nodes and 48-byte

@@ -116,7 +116,7 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 // when the scene is created).  The three channels of throughput and radiance then perform identical operations on identical
 // values from the first to the last step of a path, so one is carried and the result copied: same bits, four registers less.
 template <int CAP, bool LDS_SCENE, int BLOCK, bool OVF, bool GREY>
-__global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) void k_render_sm(DScene sc, RenderParams P_arg) {
+__global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGPU_SM_MIN_WAVES))) void k_render_sm(DScene sc, RenderParams P_arg) {
   // The launch parameters live in LDS, not in scalar registers: the traversal bodies use none of them, SHADE uses
   // nearly all, and ~60 kernel-argument SGPRs kept alive across the loop were being spilled to VGPR lanes.
   __shared__ RenderParams s_P;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
   }
 
   // ---- BVH in HBM, 1024-thread workgroup: the treelet (mgpu_device.hpp, kWTreelet) behind the far-child stacks ----
-  constexpr bool TL = !LDS_SCENE && BLOCK == 1024;
+  constexpr bool TL = !LDS_SCENE && BLOCK >= 768;
   const unsigned char *lds_treelet = smem + (size_t)kWaves * WS::kWaveBytes;
   if (TL) {
     const uint4 *src = reinterpret_cast<const uint4 *>(sc.treelet);
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_SM_MIN_WAVES)) voi
   const uint32_t total_items = total_tiles * (uint32_t)P.passes;
   uint32_t in_item = 64;
   bool exhausted = false;
-  constexpr uint32_t kWgChunk = LDS_SCENE ? (uint32_t)MGPU_WG_CHUNK_LDS : (uint32_t)MGPU_WG_CHUNK_HBM * (BLOCK == 1024 ? 2u : 1u);
+  constexpr uint32_t kWgChunk = LDS_SCENE ? (uint32_t)MGPU_WG_CHUNK_LDS : (uint32_t)MGPU_WG_CHUNK_HBM * (BLOCK >= 768 ? 2u : 1u);
   const uint32_t shard_items = (total_items + (uint32_t)kShards - 1) / (uint32_t)kShards;
   uint32_t home_shard = 0;
   uint32_t item_tile = 0, item_pass = 0; // wave-uniform: tile and pass of the current item
@@ -1075,6 +1075,9 @@ hipError_t launch_render_sm(int cap, bool lds_scene, int block, dim3 grid, hipSt
   }
   if (!lds_scene && block == 256) return launch_one<1, false, 256, false>(grid, s, shmem, sc, p); // wide form: one variant
   if (!lds_scene && block == 1024 && sc.treelet) return launch_one<1, false, 1024, false>(grid, s, shmem, sc, p); // ... + treelet in LDS
+#ifdef MGPU_EXP_768
+  if (!lds_scene && block == 768 && sc.treelet) return launch_one<1, false, 768, false>(grid, s, shmem, sc, p); // experiment: 3 waves per SIMD, 168 VGPRs
+#endif
   return hipErrorInvalidConfiguration;
 }
 
