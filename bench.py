@@ -268,6 +268,50 @@ def hbm_roofline(key, st, steps, kms, lib_path):
                     "algorithmic bytes of SURVEY 8(d) are mostly L1/L2 hits. Neither HBM nor VALU issue is saturated (DESIGN.md 4.1, 7)."}
 
 
+def one_ray_calls(M, verts, faces, mats, normals, frame, W, H, device, ref_scene, n=6000):
+    """calls/s of one-ray mgpu_trace calls (mgpu_trace_calls_measure: native threads, no binding overhead in the clock) on
+    `n` primary rays spread over the frame; the records of every mode must equal the batched kernel's."""
+    rng = np.random.default_rng(7)
+    px = rng.integers(0, W, n).astype(np.float64) + 0.5
+    py = rng.integers(0, H, n).astype(np.float64) + 0.5
+    f = np.asarray(frame, np.float64).reshape(4, 3)  # origin, corner, du, dv
+    d = f[1][None, :] + px[:, None] * f[2][None, :] + py[:, None] * f[3][None, :] - f[0][None, :]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.hstack([np.tile(f[0], (n, 1)), d])
+    ref, ref_hit = ref_scene.trace(rays)
+    modes = (("resident_server", {}), ("submission_queue", {"MGPU_TRACE_SERVER": "0"}),
+             ("launch_per_call", {"MGPU_TRACE_SERVER": "0", "MGPU_TRACE_QUEUE": "0"}))
+    res = {"unit": "calls/s", "rays": n, "threads": [1, 4, 16]}
+    same = True
+    for name, env in modes:
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            sc = M.Scene(verts, faces, mats, normals, None, device=device)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        rates = []
+        for nt in (1, 4, 16):
+            o, h, rate = sc.trace_calls_measure(rays, threads=nt)
+            rates.append(round(rate))
+            same = same and o.tobytes() == ref.tobytes() and h.tobytes() == ref_hit.tobytes()
+        res[name] = rates
+        if name == "resident_server":
+            st = sc.trace_server_stats()
+            res["server_device_us_per_call"] = round(st["device_us"], 2)
+            res["server_launches"] = int(st["launches"])
+        sc.close()
+    res["records_equal_batched_kernel"] = bool(same)
+    res["note"] = ("primary rays of the workload's camera, one mgpu_trace call per ray; resident_server = k_trace_server polling a mailbox in "
+                   "mapped host memory (no launch per call), submission_queue = concurrent callers share one launch, launch_per_call = "
+                   "a launch, two copies and a synchronisation per ray behind a mutex")
+    return res
+
+
 def extra_config(key, lib_path, torch, steps=5):
     """One single-GPU line for an HBM-resident BASELINE configuration (C3 / C4 / C5): frames rendered into HBM, HIP-event kernel
     time (summed over the launches of a frame), algorithmic bytes, and the counter-based HBM fraction when the committed PMC
@@ -615,6 +659,13 @@ def main():
             out["tile_order_off"] = {"ms_per_frame": round(ms_no, 3), "note": "MGPU_TILE_ORDER=0 (image-order hand-out), same frames"}
             del fr0
             scene0.close()
+            # Scene::Trace as the reference calls it -- ONE ray per call from every OpenMP thread (scene.cc:253-315, render.cc:403):
+            # primary rays of this camera as one-ray mgpu_trace calls from 1 / 4 / 16 native host threads, through the resident
+            # server (default), the submission queue and a launch per call (switches read when a scene is created)
+            try:
+                out["scene_trace_one_ray_calls"] = one_ray_calls(M, verts, faces, mats, normals, frame, W, H, local_rank, scene)
+            except Exception as e:  # an extra line must never take the headline down
+                out["scene_trace_one_ray_calls"] = {"error": repr(e)}
             # the C ABI's exchange step priced on this one GPU (MGPU_FRAME_FORCE_EXCHANGE: the frame's strips are sent to
             # ourselves through RCCL), both exchange modes, 1080p (135 strips) -- device time of the step per frame
             out["exchange_on_one_gpu"] = forced_exchange_timing(M, scene, frame, W, H, mpl, spp, plane, cfg["seed"], local_rank, torch, dev)

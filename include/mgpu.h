@@ -147,6 +147,11 @@ int mgpu_trace_queue_stats(MgpuScene *scene, uint64_t *launches, uint64_t *calls
  * mgpu_trace_server_retire: asks a live launch to leave and returns when it has (a few tens of microseconds). */
 int mgpu_trace_server_stats(MgpuScene *scene, uint64_t *launches, uint64_t *calls, int *alive, double *device_us);
 int mgpu_trace_server_retire(MgpuScene *scene);
+/* Measurement aid (bench.py): rays[0..n) traced as n ONE-ray mgpu_trace calls issued by `threads` host threads of this
+ * library's own (thread t takes rays t, t + threads, ...), i.e. the reference's calling pattern of Scene::Trace without a
+ * binding's per-call overhead in the clock; out / hit receive the records, *calls_per_s the rate (first call outside the clock). */
+int mgpu_trace_calls_measure(MgpuScene *scene, const MgpuRay *rays, size_t n, int threads, MgpuIntersection *out, uint8_t *hit,
+                             double *calls_per_s);
 /* The same with rays, records and hit flags resident in device memory (d_out 16-byte aligned), enqueued on `stream`
  * (a hipStream_t, NULL = default stream) without synchronising; with stats != NULL the call waits for the kernel and
  * returns its counters and time. */

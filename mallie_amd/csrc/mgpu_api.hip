@@ -17,6 +17,8 @@
 #include <new>
 #include <mutex>
 #include <queue>
+#include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -2007,6 +2009,39 @@ int mgpu_trace_server_stats(MgpuScene *s, uint64_t *launches, uint64_t *calls, i
 int mgpu_trace_server_retire(MgpuScene *s) {
   if (!s) return fail(MGPU_ERR_INVALID, "scene is NULL");
   return server_retire(s);
+}
+
+int mgpu_trace_calls_measure(MgpuScene *s, const MgpuRay *rays, size_t n, int threads, MgpuIntersection *out, uint8_t *hit,
+                             double *calls_per_s) {
+  if (!s || !rays || !out || !hit || !calls_per_s) return fail(MGPU_ERR_INVALID, "NULL argument");
+  if (n == 0 || threads < 1 || threads > 1024) return fail(MGPU_ERR_INVALID, "n = %zu, threads = %d", n, threads);
+  {
+    uint8_t h0;
+    MgpuIntersection i0;
+    int rc = mgpu_trace(s, rays, 1, &i0, &h0, nullptr); // outside the clock: staging, the first server launch
+    if (rc) return rc;
+  }
+  std::vector<int> rcs((size_t)threads, MGPU_OK);
+  std::vector<std::string> errs((size_t)threads);
+  std::vector<std::thread> pool;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int t = 0; t < threads; t++)
+    pool.emplace_back([&, t]() {
+      for (size_t i = (size_t)t; i < n; i += (size_t)threads) {
+        const int rc = mgpu_trace(s, rays + i, 1, out + i, hit + i, nullptr);
+        if (rc) {
+          rcs[(size_t)t] = rc;
+          errs[(size_t)t] = g_err; // thread-local text of this worker
+          return;
+        }
+      }
+    });
+  for (std::thread &t : pool) t.join();
+  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (int t = 0; t < threads; t++)
+    if (rcs[(size_t)t]) return fail(rcs[(size_t)t], "%s", errs[(size_t)t].c_str());
+  *calls_per_s = (double)n / sec;
+  return MGPU_OK;
 }
 
 int mgpu_trace_queue_stats(MgpuScene *s, uint64_t *launches, uint64_t *calls) {

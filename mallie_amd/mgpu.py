@@ -87,6 +87,8 @@ def load_library():
     L.mgpu_trace.restype = i32
     L.mgpu_trace_server_stats.argtypes = [vp, vp, vp, vp, vp]
     L.mgpu_trace_server_stats.restype = i32
+    L.mgpu_trace_calls_measure.argtypes = [vp, vp, sz, i32, vp, vp, vp]
+    L.mgpu_trace_calls_measure.restype = i32
     L.mgpu_trace_server_retire.argtypes = [vp]
     L.mgpu_trace_server_retire.restype = i32
     L.mgpu_render.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, u64, u32, vp, vp,
@@ -455,6 +457,22 @@ class Scene:
             _check(L.mgpu_trace(self.h, C.c_void_p(base_r + i * RAY_DT.itemsize), n, C.c_void_p(base_o + i * ISECT_DT.itemsize),
                                 C.c_void_p(base_h + i), None), "mgpu_trace")
         return out, hit
+
+    def trace_calls_measure(self, rays, threads=1):
+        """mgpu_trace_calls_measure: the rays as one-ray mgpu_trace calls from `threads` native threads.
+        -> (ISECT_DT array, hit uint8 array, calls per second)"""
+        rays = np.asarray(rays)
+        if rays.dtype != RAY_DT:
+            r6 = _c(rays, "<f8").reshape(-1, 6)
+            rays = np.zeros(len(r6), RAY_DT)
+            rays["org"], rays["dir"] = r6[:, :3], r6[:, 3:]
+        rays = np.ascontiguousarray(rays)
+        out = np.zeros(len(rays), ISECT_DT)
+        hit = np.zeros(len(rays), "u1")
+        rate = C.c_double(0.0)
+        _check(load_library().mgpu_trace_calls_measure(self.h, _p(rays), len(rays), int(threads), _p(out), _p(hit), C.byref(rate)),
+               "mgpu_trace_calls_measure")
+        return out, hit, rate.value
 
     def trace_server_stats(self):
         """-> dict(launches, calls, alive, device_us): the resident server of the one-ray callers (include/mgpu.h)"""

@@ -1378,6 +1378,11 @@ def test_bench_line_is_well_formed(tmp_path):
     fast = d["fast_mode_fp32"]
     assert "error" not in fast and fast["ms_per_frame"] < d["ms_per_step"] and fast["distance_to_fp64_frame"]["rms_per_pixel_l2"] <= 1e-4
     assert d["frame_with_readback"]["ms_per_frame"] >= d["ms_per_step"] * 0.9
+    tc = d["scene_trace_one_ray_calls"]  # Scene::Trace's calling pattern: the resident server against a launch per call
+    assert "error" not in tc and tc["records_equal_batched_kernel"] is True and tc["server_launches"] >= 1
+    assert tc["resident_server"][0] >= 1.5 * tc["launch_per_call"][0] and tc["resident_server"][1] >= 5 * tc["launch_per_call"][1], tc
+    cf = {k: v.get("fast_mode_fp32") for k, v in d["extra_configs"].items()}
+    assert cf["c5"] is None and all("error" not in cf[k] and cf[k]["speedup_vs_fp64"] > 1.0 for k in ("c3", "c4")), cf
 
 
 def test_bench_batched_frames_through_the_c_abi_exchange():
