@@ -227,6 +227,31 @@ def test_one_ray_calls_on_a_deep_tree_and_a_large_scene():
     sc.close()
 
 
+@pytest.mark.parametrize("name", ["cornell_obj", "teapot_obj"])
+def test_one_ray_calls_random_rays_from_sixteen_native_threads(name):
+    """100 000 random rays (origins in twice the scene box, uniform directions, a sprinkling of axis-parallel ones) as one-ray
+    calls from 16 native threads (mgpu_trace_calls_measure: the server's mailbox under real contention, 16 of its 256 slots in use
+    at any time) against the batched kernel: every field of every record."""
+    sc = gpu_scene(name)
+    bmin, bmax = sc.bbox()
+    rng = np.random.default_rng(123)
+    n = 100000
+    ctr, ext = 0.5 * (bmin + bmax), (bmax - bmin)
+    org = ctr + (rng.random((n, 3)) - 0.5) * 2.0 * ext
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[::97] = np.eye(3)[rng.integers(0, 3, len(d[::97]))] * rng.choice([-1.0, 1.0], (len(d[::97]), 1))  # zero components: inf inverses
+    rays = np.hstack([org, d])
+    ref, ref_hit = sc.trace(rays)
+    out, hit, rate = sc.trace_calls_measure(rays, threads=16)
+    _same_records(out, hit, ref, ref_hit)
+    st = sc.trace_server_stats()
+    assert st["calls"] == n + 1 and ref_hit.sum() > n // 20
+    print("%s: %d one-ray calls from 16 threads: %.0f calls/s, %.2f us on the device per call, %d server launches" % (
+        name, n, rate, st["device_us"], st["launches"]))
+    sc.close()
+
+
 def test_trace_device_buffers_match_host_call(trace_kernel):
     """mgpu_trace_device (rays and records resident in HBM, asynchronous) writes the same bytes as mgpu_trace; sizes
     chosen to cover a ragged last wave (n % 64 != 0, n % 16 != 0) and a single ray."""
