@@ -279,7 +279,7 @@ def test_facade_render_and_trace_on_gpu(driver, tmp_path):
     assert rate[("queue", 1)] >= 0.9 * rate[("launch", 1)], rate  # a caller that is alone waits for nobody
     # measured on the round-3 box (8 000 calls, tools/perf_trace_calls.sh): server 82 k / 325 k / 1 155 k calls/s, queue 34 k / 70 k /
     # 145 k, a launch per call 31 k / 30 k / 30 k -- 2.7x / 10.7x / 38x; the bars below leave room for a slower host
-    assert rate[("server", 1)] >= 2.0 * rate[("launch", 1)] and rate[("server", 4)] >= 7.0 * rate[("launch", 4)], rate
+    assert rate[("server", 1)] >= 1.6 * rate[("launch", 1)] and rate[("server", 4)] >= 6.0 * rate[("launch", 4)], rate
     assert rate[("server", 16)] >= 15.0 * rate[("launch", 16)], rate
 
 
