@@ -1155,14 +1155,16 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
     else if (!strcmp(e, "sm_lds")) kern = 2;
     else return fail(MGPU_ERR_INVALID, "MGPU_RENDER_KERNEL=%s (expected v1|sm|sm_lds)", e);
   }
-  if (kern == 2 && (s->cap > 24 || s->stack_need > s->cap)) kern = 1; // deep trees never fit the LDS budget anyway
+  const int se_bytes = lds_stack_entry_bytes(s->nn); // LDS-resident scene: node indices of 1 or 2 bytes, depth + 1 per lane
+  if (kern == 2 && se_bytes > 2) kern = 1;
   int block = kern == 2 ? 1024 : kBlock;
   if (kern == 2 && getenv("MGPU_RENDER_BLOCK") && atoi(getenv("MGPU_RENDER_BLOCK")) == 512) block = 512; // experiments
   size_t shmem = (size_t)(block / 64) * s->cap * 64 * sizeof(uint32_t);
   if (kern == 2) {
+    shmem = lds_stack_bytes((size_t)(block / 64), (size_t)s->stack_need, (size_t)se_bytes);
     if (shmem + scene_lds > kLdsBudget) {
       block = 512;
-      shmem = (size_t)(block / 64) * s->cap * 64 * sizeof(uint32_t);
+      shmem = lds_stack_bytes((size_t)(block / 64), (size_t)s->stack_need, (size_t)se_bytes);
     }
     if (shmem + scene_lds > kLdsBudget) {
       kern = 1;
@@ -1285,6 +1287,7 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
   P.stats = s->p_stats;
   P.lds_nodes_bytes = (uint32_t)(sizeof(MgpuNode) * s->nn);
   P.lds_tris_bytes = (uint32_t)(sizeof(DTri) * s->nf);
+  P.stack_cap = (uint32_t)s->stack_need;
   if (treelet) P.lds_nodes_bytes = (uint32_t)(sizeof(WNode) * s->d.treelet_n); // what the HBM-resident kernel stages into LDS
   FScene fsc{};
   if (kern == 3) {
@@ -1387,7 +1390,7 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
     } else if (kern == 3) {
       HIP_TRY(launch_render_f32(s->cap, f32_lds, dim3((unsigned)blocks), st, shmem, fsc, P));
     } else {
-      HIP_TRY(launch_render_sm(s->cap, kern == 2, block, dim3((unsigned)blocks), st, shmem, dsc, P));
+      HIP_TRY(launch_render_sm(se_bytes, kern == 2, block, dim3((unsigned)blocks), st, shmem, dsc, P));
     }
     return MGPU_OK;
   };

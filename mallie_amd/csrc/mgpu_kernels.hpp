@@ -54,6 +54,7 @@ struct RenderParams {
   const uint32_t *tile_order;
   uint32_t *tile_cost;
   uint32_t lds_nodes_bytes, lds_tris_bytes; // k_render_sm<LDS_SCENE>: bytes of nodes / triangles staged into LDS
+  uint32_t stack_cap;            // k_render_sm<LDS_SCENE>: stack entries per lane in LDS = tree depth + 1
   unsigned long long *wave_log;  // device or null: 4 words per wave (diagnostic builds only)
   double *probe;                 // device or null: kProbeStride doubles per PathTrace iteration of ONE path
   uint32_t probe_pixel, probe_pass; // full-frame pixel index and pass of the probed path
@@ -71,8 +72,14 @@ void launch_trace_probe(hipStream_t s, const MgpuRay *rays, size_t n, uint32_t *
 void launch_render(int cap, dim3 grid, hipStream_t s, const DScene &sc, const RenderParams &p);
 int pick_stack_cap(int needed_entries);
 // wave-scheduled state-machine renderer (mgpu_render_sm.hip); shmem = stacks (+ scene when lds_scene)
-hipError_t launch_render_sm(int cap, bool lds_scene, int block, dim3 grid, hipStream_t s, size_t shmem, const DScene &sc,
+hipError_t launch_render_sm(int stack_entry_bytes, bool lds_scene, int block, dim3 grid, hipStream_t s, size_t shmem, const DScene &sc,
                             const RenderParams &p);
+// LDS-resident scene: a stack entry is a node index -- 1 byte up to 256 nodes, 2 up to 65 536 (larger trees never fit) --
+// and a lane needs tree depth + 1 of them (bvh_accel.cc:805-834: a pop, then at most two pushes per level)
+inline int lds_stack_entry_bytes(size_t nn) { return nn <= 256 ? 1 : (nn <= 65536 ? 2 : 4); }
+__host__ __device__ inline size_t lds_stack_bytes(size_t waves, size_t cap, size_t entry_bytes) {
+  return (waves * cap * 64 * entry_bytes + 15) & ~(size_t)15;
+}
 // k_render_env (mgpu_render_env.hip): RenderPanoramic
 struct EnvParams {
   double origin[3];        // Camera::origin_ (BuildCameraFrame)

@@ -115,7 +115,16 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 // GREY: every material of the scene has three equal diffuse channels (all the reference can load from .obj / .eson; checked
 // when the scene is created).  The three channels of throughput and radiance then perform identical operations on identical
 // values from the first to the last step of a path, so one is carried and the result copied: same bits, four registers less.
-template <int CAP, bool LDS_SCENE, int BLOCK, bool OVF, bool GREY>
+// SE: entry type of the LDS-resident scene's traversal stack -- a node index: one byte while the tree has at most 256 nodes,
+// two up to 65 536 -- `P.stack_cap` (= tree depth + 1, what the reference's pop / push order can ever hold) of them per lane.
+// (Until round 3: 16 / 24 / 32 four-byte entries, 64 KB of LDS for a 205-node tree of depth 13 that needs 14 KB.)
+template <typename SE> struct LStack {
+  SE *lds; // &s_stack[wave][0][lane]: entry-major, lane-minor
+  __device__ __forceinline__ void put(int i, uint32_t v) const { lds[i * 64] = (SE)v; }
+  __device__ __forceinline__ uint32_t get(int i) const { return (uint32_t)lds[i * 64]; }
+};
+
+template <typename SE, bool LDS_SCENE, int BLOCK, bool GREY>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGPU_SM_MIN_WAVES))) void k_render_sm(DScene sc, RenderParams P_arg) {
   // The launch parameters live in LDS, not in scalar registers: the traversal bodies use none of them, SHADE uses
   // nearly all, and ~60 kernel-argument SGPRs kept alive across the loop were being spilled to VGPR lanes.
@@ -127,14 +136,14 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
   const RenderParams &P = s_P;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int kWaves = BLOCK / 64;
-  uint32_t *s_stack = reinterpret_cast<uint32_t *>(smem); // [kWaves][CAP][64]
+  SE *s_stack = reinterpret_cast<SE *>(smem); // [kWaves][stack_cap][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   // traversal stack: LDS_SCENE walks the reference's 64-byte nodes staged in LDS with a stack of node indices; with the
   // BVH in HBM the wide form is used (mgpu_device.hpp, wide_node_step): far children with their tmin
-  Stack<CAP, OVF> stk;
-  stk.lds = s_stack + ((size_t)wave * CAP) * 64 + lane;
-  stk.overflow = (OVF && sc.stack_overflow) ? sc.stack_overflow + gid * sc.overflow_cap : nullptr;
+  const uint32_t stack_cap = LDS_SCENE ? P.stack_cap : 0u;
+  LStack<SE> stk;
+  stk.lds = s_stack + ((size_t)wave * stack_cap) * 64 + lane;
   using WS = WStack<kWideStackLds>;
   WS wstk;
   if (!LDS_SCENE) {
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
     __syncthreads();
   }
   // ---- optional: stage nodes + triangles into LDS -------------------------------------------------------------
-  const unsigned char *lds_nodes = smem + (size_t)kWaves * CAP * 64 * sizeof(uint32_t);
+  const unsigned char *lds_nodes = smem + lds_stack_bytes(kWaves, stack_cap, sizeof(SE));
   const unsigned char *lds_tris = lds_nodes + (size_t)P.lds_nodes_bytes;
   if (LDS_SCENE) {
     const uint4 *src = reinterpret_cast<const uint4 *>(sc.nodes);
@@ -1035,9 +1044,9 @@ void launch_tonemap(hipStream_t s, const float *image, const int32_t *count, siz
 // =====================================================================================================================
 // launcher
 // =====================================================================================================================
-template <int CAP, bool LDS, int BLOCK, bool OVF, bool GREY>
+template <typename SE, bool LDS, int BLOCK, bool GREY>
 static hipError_t launch_grey(dim3 grid, hipStream_t s, size_t shmem, const DScene &sc, const RenderParams &p) {
-  auto kern = k_render_sm<CAP, LDS, BLOCK, OVF, GREY>;
+  auto kern = k_render_sm<SE, LDS, BLOCK, GREY>;
   // per device: dynamic-LDS size already granted to this instantiation.  Scenes on different devices are driven from
   // different host threads (and the multi-GPU frame drives several from one): the table is guarded.
   static size_t granted[16] = {0};
@@ -1057,26 +1066,25 @@ static hipError_t launch_grey(dim3 grid, hipStream_t s, size_t shmem, const DSce
   return hipGetLastError();
 }
 
-template <int CAP, bool LDS, int BLOCK, bool OVF>
+template <typename SE, bool LDS, int BLOCK>
 static hipError_t launch_one(dim3 grid, hipStream_t s, size_t shmem, const DScene &sc, const RenderParams &p) {
-  return sc.grey ? launch_grey<CAP, LDS, BLOCK, OVF, true>(grid, s, shmem, sc, p) : launch_grey<CAP, LDS, BLOCK, OVF, false>(grid, s, shmem, sc, p);
+  return sc.grey ? launch_grey<SE, LDS, BLOCK, true>(grid, s, shmem, sc, p) : launch_grey<SE, LDS, BLOCK, false>(grid, s, shmem, sc, p);
 }
 
-// Instantiations: LDS-resident scene (small trees only: CAP 16 / 24, never an overflow column) with 1024- or 512-thread
-// workgroups; HBM-resident scene with 256-thread workgroups, CAP 16 / 24 / 32, the overflow column only for CAP 32.
-hipError_t launch_render_sm(int cap, bool lds_scene, int block, dim3 grid, hipStream_t s, size_t shmem, const DScene &sc,
+// Instantiations: LDS-resident scene (stack entries of 1 or 2 bytes, see lds_stack_entry_bytes) with 1024- or 512-thread
+// workgroups; HBM-resident scene (wide form, its own stacks) with 256-thread workgroups or one 1024-thread workgroup + treelet.
+hipError_t launch_render_sm(int stack_entry_bytes, bool lds_scene, int block, dim3 grid, hipStream_t s, size_t shmem, const DScene &sc,
                             const RenderParams &p) {
-  const bool ovf = sc.overflow_cap != 0;
-  if (lds_scene && !ovf) {
-    if (cap == 16 && block == 1024) return launch_one<16, true, 1024, false>(grid, s, shmem, sc, p);
-    if (cap == 16 && block == 512) return launch_one<16, true, 512, false>(grid, s, shmem, sc, p);
-    if (cap == 24 && block == 1024) return launch_one<24, true, 1024, false>(grid, s, shmem, sc, p);
-    if (cap == 24 && block == 512) return launch_one<24, true, 512, false>(grid, s, shmem, sc, p);
+  if (lds_scene) {
+    if (stack_entry_bytes == 1 && block == 1024) return launch_one<uint8_t, true, 1024>(grid, s, shmem, sc, p);
+    if (stack_entry_bytes == 1 && block == 512) return launch_one<uint8_t, true, 512>(grid, s, shmem, sc, p);
+    if (stack_entry_bytes == 2 && block == 1024) return launch_one<uint16_t, true, 1024>(grid, s, shmem, sc, p);
+    if (stack_entry_bytes == 2 && block == 512) return launch_one<uint16_t, true, 512>(grid, s, shmem, sc, p);
   }
-  if (!lds_scene && block == 256) return launch_one<1, false, 256, false>(grid, s, shmem, sc, p); // wide form: one variant
-  if (!lds_scene && block == 1024 && sc.treelet) return launch_one<1, false, 1024, false>(grid, s, shmem, sc, p); // ... + treelet in LDS
+  if (!lds_scene && block == 256) return launch_one<uint32_t, false, 256>(grid, s, shmem, sc, p); // wide form: one variant
+  if (!lds_scene && block == 1024 && sc.treelet) return launch_one<uint32_t, false, 1024>(grid, s, shmem, sc, p); // ... + treelet in LDS
 #ifdef MGPU_EXP_768
-  if (!lds_scene && block == 768 && sc.treelet) return launch_one<1, false, 768, false>(grid, s, shmem, sc, p); // experiment: 3 waves per SIMD, 168 VGPRs
+  if (!lds_scene && block == 768 && sc.treelet) return launch_one<uint32_t, false, 768>(grid, s, shmem, sc, p); // experiment: 3 waves per SIMD, 168 VGPRs
 #endif
   return hipErrorInvalidConfiguration;
 }

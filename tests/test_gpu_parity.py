@@ -136,6 +136,20 @@ ISECT_FIELDS = ("t", "u", "v", "faceID", "materialID", "f0", "f1", "f2", "positi
                 "binormal", "texcoord")
 
 
+GOLDEN_FIELDS = ("t", "u", "v", "faceID", "materialID", "f0", "f1", "f2", "position", "geometricNormal", "normal", "texcoord")
+
+
+def _equals_reference_records(out, hit, ref, what, fields=GOLDEN_FIELDS):
+    """Records of the HIP path against records of the REFERENCE (tests/golden/trace_*.npz, written by the reference binary) or
+    of the oracle: the hit flags, and every field of every hit (a miss leaves only t = DBL_MAX, faceID = -1 defined,
+    bvh_accel.cc:782-786,838)."""
+    assert np.array_equal(hit, ref["hit"].astype("u1")), what
+    h = ref["hit"] == 1
+    for f in fields:
+        assert out[f][h].tobytes() == ref[f][h].tobytes(), (what, f)
+    assert np.all(out["t"][~h & ~np.isnan(out["t"])] == np.finfo(np.float64).max), what
+
+
 def _same_records(a, ha, b, hb):
     assert np.array_equal(ha, hb)
     for f in ISECT_FIELDS:
@@ -162,6 +176,8 @@ def test_one_ray_calls_through_the_resident_server(monkeypatch, lds):
     assert sc.trace_server_stats()["launches"] == 0
     out, hit = sc.trace_calls(rays, per_call=1)         # the server
     _same_records(out, hit, ref, ref_hit)
+    # ... and the first 700 are the reference's own golden rays: against the reference's records, not only our batched kernel's
+    _equals_reference_records(out[:700], hit[:700], t["hits"][:700], "server vs reference goldens")
     st = sc.trace_server_stats()
     assert st["calls"] == len(rays) and st["launches"] >= 1 and st["device_us"] > 0.0
     q, qh = sc.trace_calls(rays[:300], per_call=3)      # the submission queue (2..64 rays per call)
@@ -245,6 +261,11 @@ def test_one_ray_calls_random_rays_from_sixteen_native_threads(name):
     ref, ref_hit = sc.trace(rays)
     out, hit, rate = sc.trace_calls_measure(rays, threads=16)
     _same_records(out, hit, ref, ref_hit)
+    # a 5 000-ray subsample against the oracle (CPU restatement pinned to the reference): the server's records, not the batched
+    # kernel's, are what is compared
+    sub = rng.choice(n, 5000, replace=False)
+    oref = O.scene_from_golden(name).trace(rays[sub])
+    _equals_reference_records(out[sub], hit[sub], oref, "server vs oracle, " + name, fields=("t", "u", "v", "faceID", "materialID", "position", "geometricNormal", "normal"))
     st = sc.trace_server_stats()
     assert st["calls"] == n + 1 and ref_hit.sum() > n // 20
     print("%s: %d one-ray calls from 16 threads: %.0f calls/s, %.2f us on the device per call, %d server launches" % (
