@@ -7,8 +7,11 @@ semantics accumulated on the device in one persistent-kernel launch per GPU (+ o
 rank 0 when N > 1; there three frames are kept in flight on three streams so that the gather and the drain of one
 launch overlap the next frames, see --frames-in-flight and DESIGN.md 6).  Step k renders passes [16k, 16k+16) -- a
 progressive renderer's next frame, not the same frame again.  The scene (mesh arrays from tests/golden, BVH built by this
-library's host builder) is resident in HBM before the timed region; the frame stays in HBM (`value`); the same frame
-including its read-back to pinned host memory is timed separately (`frame_with_readback`).
+library's host builder) is resident in HBM before the timed region.  At N = 1 a frame is SURVEY.md 8(d)'s frame: the passes
+AND one read-back -- every frame is copied to pinned host memory on a copy stream behind its kernel (mgpu_frame_set_readback),
+which with two frames in flight runs under the next frame's kernel, and the caller takes frame k - 1 while frame k renders;
+`value` / `ms_per_step` time that.  The same frames staying in HBM (the headline of rounds 1-3) and with a synchronous
+read-back are timed beside it (`frame_resident_in_hbm`, `frame_with_synchronous_readback`).
 
 "rays" = BVH traversals actually performed ("real" rays: primary + bounce rays up to and including a path's first
 miss); the reference's post-miss continuation rays are finished analytically and are NOT counted.
@@ -448,6 +451,15 @@ def main():
     if world == 1 and os.environ.get("MGPU_FRAME_FORCE_EXCHANGE"):  # debugging aid: the C ABI's exchange path on one GPU
         cframe = M.Frame.create_rank(scene, local_rank, 0, 1, None, W, H, strip_h=8, frames_in_flight=fif)
         exchange = "mgpu_frame_* forced on one GPU (RCCL send/recv to self)"
+    # N = 1, the headline: SURVEY 8(d)'s frame = the passes + ONE read-back.  The frame object (C ABI) copies every frame into a
+    # pinned host buffer of its slot on a copy stream, behind the frame; with two slots the copy of frame k runs under the
+    # kernel of frame k + 1, and the caller takes frame k - 1 (mgpu_frame_wait_host) while frame k renders.
+    readback = world == 1 and cframe is None and not force_gather and not os.environ.get("MALLIE_BENCH_NO_READBACK")
+    if readback:
+        fif = max(fif, 2)
+        cframe = M.Frame.create_rank(scene, local_rank, 0, 1, None, W, H, strip_h=8, frames_in_flight=fif)
+        cframe.set_readback(True)
+        exchange = "none (one GPU); every frame read back to pinned host memory under the next frame's kernel"
     if single:
         cframe = M.Frame(scenes, devices, W, H, strip_h=8, frames_in_flight=fif)
         exchange = "mgpu_frame_* (C ABI), one process driving %d devices (ncclCommInitAll)" % world
@@ -472,10 +484,15 @@ def main():
                 cframe = None
 
     pending = []
+    taken = {"frames": 0, "last": None}  # read-back mode: host frames the caller has taken, and the latest (aliases pinned memory)
 
     def render_frame(k):
         if cframe is not None:
-            pending.append(cframe.render(frame, mpl, spp, plane, seed=cfg["seed"], pass_base=k * spp))
+            slot = cframe.render(frame, mpl, spp, plane, seed=cfg["seed"], pass_base=k * spp)
+            if readback and pending:  # frame k is enqueued: take frame k - 1 from its pinned buffer while k renders
+                taken["last"] = cframe.wait_host(pending.pop())
+                taken["frames"] += 1
+            pending.append(slot)
         else:
             fr.render(pass_base=k * spp)
 
@@ -489,7 +506,11 @@ def main():
     def finish_frames():
         if cframe is not None:
             for slot in sorted(set(pending[-fif:])):
-                cframe.wait(slot)
+                if readback:
+                    taken["last"] = cframe.wait_host(slot)
+                    taken["frames"] += 1
+                else:
+                    cframe.wait(slot)
             del pending[:]
 
     def sync_all():
@@ -510,6 +531,7 @@ def main():
         sc.timing_enable(True)
     if cframe is not None:
         cframe.stats(reset=True)
+    taken["frames"] = 0
     sync_all()
     t0 = time.perf_counter()
     for k0 in range(0, args.steps, fpl if batched else 1):  # frame k = passes [k*spp, (k+1)*spp): the next 16 samples per pixel
@@ -517,6 +539,8 @@ def main():
     finish_frames()
     sync_all()
     elapsed = time.perf_counter() - t0
+    host_frames_taken = taken["frames"]
+    last_host_frame = None if taken["last"] is None else taken["last"].copy()  # the last timed frame as the caller received it
     per_rank_kernel, launch_counts, sts = [], [], []
     for sc in scenes:
         kernel_ms, launches = sc.timing_read()
@@ -605,6 +629,9 @@ def main():
                 "parallelism": "replicated scene, interleaved 8-row strips x%d, 1 RCCL exchange/frame: %s" % (world, exchange)
                                if world > 1 else "single GPU, persistent-threads kernel",
                 "frames_in_flight": fif, "frames_per_launch": fpl if batched else 1,
+                "readback": ("every frame copied to pinned host memory (24.9 MB at 1080p) behind its kernel, on a copy stream, and "
+                             "taken by the caller while the next frame renders: %d of %d timed frames taken inside the timed region"
+                             % (host_frames_taken, args.steps)) if readback else "none: frames stay in HBM",
                 "rays_per_frame": int(rays / args.steps), "trace_calls_per_frame": int(trace_calls / args.steps),
                 "nodes_per_ray": round(nodes / rays, 3), "tris_per_ray": round(tris / rays, 3),
                 "mtrace_calls_per_s": round(trace_calls / elapsed / 1e6, 2),
@@ -645,9 +672,13 @@ def main():
                 torch.cuda.synchronize(dev)  # the caller owns the frame before the next one starts (mallie::Render semantics)
             render_rb(0)
             ms_rb, _, _ = time_frames(scene, render_rb, args.steps, lambda: torch.cuda.synchronize(dev))
-            out["frame_with_readback"] = {"ms_per_frame": round(ms_rb, 3), "value": round(rays / args.steps / ms_rb / 1e3, 2),
-                                          "unit": "Mrays/s", "note": "same frames, each followed by its 24.9 MB device-to-host copy "
-                                          "(pinned memory) and a synchronisation; SURVEY 8(d) frame definition"}
+            out["frame_with_synchronous_readback"] = {"ms_per_frame": round(ms_rb, 3), "value": round(rays / args.steps / ms_rb / 1e3, 2),
+                                          "unit": "Mrays/s", "note": "same frames, one in flight, each followed by its 24.9 MB device-to-host copy "
+                                          "(pinned memory) and a synchronisation before the next frame starts (rounds 1-3: frame_with_readback)"}
+            ms_res, kms_res, _ = time_frames(scene, lambda k: fr1.render(pass_base=k * spp), args.steps, lambda: torch.cuda.synchronize(dev))
+            out["frame_resident_in_hbm"] = {"ms_per_frame": round(ms_res, 3), "kernel_avg_ms": round(kms_res, 3),
+                                            "value": round(rays / args.steps / ms_res / 1e3, 2), "unit": "Mrays/s",
+                                            "note": "same frames, one in flight, no read-back: the frame stays in HBM (the headline of rounds 1-3)"}
             # the cost-ordered tile hand-out predicts a frame from an earlier one: the same frames without it (the switch is
             # read when a scene is created)
             os.environ["MGPU_TILE_ORDER"] = "0"
@@ -700,6 +731,8 @@ def main():
             fr.render(pass_base=last_pass_base)
             torch.cuda.synchronize(dev)
             gpu_frame = fr.frame_buffer.detach().cpu().numpy()
+            if last_host_frame is not None:  # what the caller took from pinned memory inside the timed region, against a fresh render
+                conf["host_frame_equals_rerendered_frame"] = bool(last_host_frame.tobytes() == gpu_frame.tobytes())
         if world == 1 and not args.no_extras:
             fr = None
             torch.cuda.empty_cache()

@@ -287,6 +287,16 @@ int mgpu_frame_render_batch(MgpuFrame *frame, const double cam[12], int maxPathL
 /* Waits for the frame of `slot`.  On the process that holds rank 0: *device_image (nullable) receives the device pointer
  * of the H x W x 3 float frame (valid until the slot is used again), host_image (nullable) a copy of it. */
 int mgpu_frame_wait(MgpuFrame *frame, int slot, float *host_image, float **device_image);
+/* SURVEY 8(d)'s frame ends with one read-back (render.cc:673-679 writes the caller's host image).  With the read-back switched
+ * on, every slot of rank 0's process owns a pinned host buffer and mgpu_frame_wait_host(slot) -- once the slot's frame is
+ * complete -- copies the frame into it on a copy stream of its own, waits for the copy and hands the buffer out (H x W x 3 floats,
+ * valid until the slot's next render call).  The intended use is a pipeline: enqueue frame k + 1 (mgpu_frame_render), THEN take
+ * frame k -- its 24.9 MB (1080p) then cross PCIe under frame k + 1's kernel and cost nothing (needs frames_in_flight >= 2; a
+ * slot is not rendered into again before its copy has left it).  On one GPU the frames of a frame object with the read-back on
+ * go down ONE stream, in order (two whole-GPU launches enqueued on two streams share the CUs and finish together, which leaves
+ * nothing to hide the first copy under). */
+int mgpu_frame_set_readback(MgpuFrame *frame, int on);
+int mgpu_frame_wait_host(MgpuFrame *frame, int slot, const float **host_image);
 /* What the frame object knows about itself and its exchange step: `rccl_ranks` is read back from the communicator
  * (ncclCommCount; 0 when no communicator exists, i.e. one GPU without MGPU_FRAME_FORCE_EXCHANGE); `exchange_ms` is the device
  * time of the exchange steps (grouped sends / receives + the placement copies) of `exchange_frames` frames, from HIP events

@@ -167,7 +167,10 @@ int dev_alloc(MgpuScene *s, void **p, size_t bytes) {
   *p = nullptr;
   if (!bytes) return MGPU_OK;
   hipError_t e = hipMalloc(p, bytes);
-  if (e != hipSuccess) return fail(MGPU_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  if (e != hipSuccess) {
+    (void)hipGetLastError(); // not sticky: the caller may retry with less
+    return fail(MGPU_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  }
   s->device_bytes += bytes;
   return MGPU_OK;
 }
@@ -526,6 +529,24 @@ inline void cpu_relax() {
 
 std::mutex g_srv_mutex;
 std::vector<MgpuScene *> g_srv_scenes; // scenes whose server has been set up (any device)
+// Render entry points in progress per device.  A render call retires the live servers of its device (its persistent kernel wants
+// every CU and most of the LDS) -- and a one-ray caller spinning in trace_served would start the next server at once, in front of
+// the render kernel.  While a render call holds its device, server_launch starts nothing and new one-ray calls go
+// through the submission queue.
+constexpr int kMaxDevices = 64;
+std::atomic<int> g_render_hold[kMaxDevices];
+struct RenderHold {
+  int dev;
+  explicit RenderHold(int device) : dev(device >= 0 && device < kMaxDevices ? device : -1) {
+    if (dev >= 0) g_render_hold[dev].fetch_add(1, std::memory_order_acq_rel);
+  }
+  ~RenderHold() {
+    if (dev >= 0) g_render_hold[dev].fetch_sub(1, std::memory_order_acq_rel);
+  }
+  RenderHold(const RenderHold &) = delete;
+  RenderHold &operator=(const RenderHold &) = delete;
+};
+bool render_held(int device) { return device >= 0 && device < kMaxDevices && g_render_hold[device].load(std::memory_order_acquire) > 0; }
 
 int server_init_locked(MgpuScene *s) {
   if (s->srv_ready.load()) return MGPU_OK;
@@ -574,6 +595,7 @@ inline bool server_alive(const MgpuScene *s) {
 int server_launch(MgpuScene *s, uint32_t seen_epoch) {
   std::lock_guard<std::mutex> lk(s->srv_mutex);
   if (s->srv_epoch.load() != seen_epoch) return MGPU_OK;
+  if (render_held(s->device)) return MGPU_OK; // a render call is in progress on this device: the caller keeps waiting
   int rc = set_device(s);
   if (rc) return rc;
   DScene d = s->d; // the scene as the batched trace sees it, with the server's own overflow columns
@@ -584,10 +606,17 @@ int server_launch(MgpuScene *s, uint32_t seen_epoch) {
   const unsigned long long ticks_per_us = 100; // wall_clock64(): the constant 100 MHz counter
   // a scene whose nodes and triangles fit beside the stacks is walked from LDS (MGPU_TRACE_SERVER_LDS=0: never)
   const size_t nodes_bytes = sizeof(MgpuNode) * s->nn, tris_bytes = sizeof(DTri) * s->nf;
-  const bool stage = s->srv_stage && nodes_bytes + tris_bytes + (size_t)s->cap * 256 + 1024 <= 160 * 1024;
-  HIP_TRY(launch_trace_server(s->cap, s->srv_stream, d, s->srv_mb_dev, s->srv_ctl, seen_epoch + 1, s->srv_idle_us * ticks_per_us,
-                              s->srv_life_us * ticks_per_us, s->srv_life_us * 20ull + 1000ull, stage ? (uint32_t)nodes_bytes : 0u,
-                              stage ? (uint32_t)tris_bytes : 0u));
+  bool stage = s->srv_stage && nodes_bytes + tris_bytes + (size_t)s->cap * 256 + 1024 <= kLdsBudget;
+  hipError_t le = launch_trace_server(s->cap, s->srv_stream, d, s->srv_mb_dev, s->srv_ctl, seen_epoch + 1, s->srv_idle_us * ticks_per_us,
+                                      s->srv_life_us * ticks_per_us, s->srv_life_us * 20ull + 1000ull, stage ? (uint32_t)nodes_bytes : 0u,
+                                      stage ? (uint32_t)tris_bytes : 0u);
+  if (le != hipSuccess && stage) { // a device that grants less LDS than this build assumes: walk the scene from HBM instead
+    (void)hipGetLastError();
+    s->srv_stage = false;
+    le = launch_trace_server(s->cap, s->srv_stream, d, s->srv_mb_dev, s->srv_ctl, seen_epoch + 1, s->srv_idle_us * ticks_per_us,
+                             s->srv_life_us * ticks_per_us, s->srv_life_us * 20ull + 1000ull, 0u, 0u);
+  }
+  HIP_TRY(le);
   s->srv_launches.fetch_add(1);
   s->srv_epoch.store(seen_epoch + 1, std::memory_order_release);
   return MGPU_OK;
@@ -640,7 +669,15 @@ void server_destroy(MgpuScene *s) {
   s->srv_mb = nullptr;
 }
 
+int trace_coalesced(MgpuScene *s, TraceTicket &t);
+
 int trace_served(MgpuScene *s, const MgpuRay *ray, MgpuIntersection *out, uint8_t *hit) {
+  if (render_held(s->device)) { // a render call is in progress on this device: no server until it has enqueued its work
+    TraceTicket t;
+    t.rays = ray; t.n = 1; t.out = out; t.hit = hit;
+    t.err[0] = 0;
+    return trace_coalesced(s, t);
+  }
   if (!s->srv_ready.load(std::memory_order_acquire)) {
     int rc = server_init(s);
     if (rc) return rc;
@@ -1138,6 +1175,7 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
   }
   const double t0 = now_ms();
   int rc = set_device(s);
+  RenderHold hold(s->device); // no server is (re)launched on this device until this call has enqueued its work
   if (!rc) rc = servers_retire_device(s->device); // a resident trace server leaves first: this launch wants every CU
   if (rc) return rc;
   if (stats) memset(stats, 0, sizeof(*stats));
@@ -1236,6 +1274,7 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
   P.pix_step = pstep;
   P.inv_len[0] = 0.0;
   for (int L = 1; L <= 16; ++L) P.inv_len[L] = 1.0 / (double)L;
+  fill_tail_unit(P);
   if (pstep != 1 && kern == 0) return fail(MGPU_ERR_UNSUPPORTED, "MGPU_RENDER_KERNEL=v1 has no pixel step");
   P.rng_mode = rng_mode;
   P.rng_states = d_rng_states;
@@ -1268,8 +1307,12 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
       if (const char *e = getenv("MGPU_FRAMES_PER_LAUNCH")) fpl = std::max(1, std::min(fpl, atoi(e)));
       while (fpl > 1 && tiles * (uint64_t)fpl * (uint64_t)passes >= ((uint64_t)1 << 28)) --fpl;
     }
-    const size_t need = plane_floats * (size_t)group * (size_t)fpl;
-    if (need > R.planes_floats) {
+    // The planes are grow-only scratch, one set per stream in use.  When the device cannot give what the budget allows (smaller
+    // GPUs, several scenes or ranks on one device), fewer frames share a launch, then fewer passes a group, before the call
+    // fails: same images, more launches.
+    for (;;) {
+      const size_t need = plane_floats * (size_t)group * (size_t)fpl;
+      if (need <= R.planes_floats) break;
       if (R.p_planes) {
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipFree(R.p_planes));
@@ -1277,9 +1320,18 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
         R.p_planes = nullptr;
         R.planes_floats = 0;
       }
-      rc = dev_alloc(s, (void **)&R.p_planes, need * sizeof(float));
-      if (rc) return rc;
-      R.planes_floats = need;
+      size_t free_b = 0, total_b = 0;
+      const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+      if (!known) (void)hipGetLastError();
+      // leave a quarter of what is free to the caller's own buffers
+      rc = (known && need * sizeof(float) > free_b - free_b / 4) ? MGPU_ERR_OOM : dev_alloc(s, (void **)&R.p_planes, need * sizeof(float));
+      if (!rc) {
+        R.planes_floats = need;
+        break;
+      }
+      if (rc != MGPU_ERR_OOM || (fpl == 1 && group == 1)) return rc == MGPU_ERR_OOM ? fail(MGPU_ERR_OOM, "no device memory for one pass plane (%zu bytes)", plane_floats * sizeof(float)) : rc;
+      if (fpl > 1) fpl = (fpl + 1) / 2;
+      else group = (group + 1) / 2;
     }
     P.out = R.p_planes;
     P.pass_stride = plane_floats;
@@ -1600,6 +1652,7 @@ int mgpu_render_stream(MgpuScene *s, const double origin[3], const double corner
   std::lock_guard<std::mutex> host_lock(s->host_mutex);
   uint32_t next_state[4];
   int rc = set_device(s);
+  RenderHold hold(s->device); // no server is (re)launched on this device until this call has enqueued its work
   if (!rc) rc = servers_retire_device(s->device); // a resident trace server leaves first: this launch wants every CU
   if (rc) return rc;
   {
@@ -1784,6 +1837,7 @@ int mgpu_render_aov(MgpuScene *s, const double origin[3], const double corner[3]
   std::lock_guard<std::mutex> host_lock(s->host_mutex);
   const double t0 = now_ms();
   int rc = set_device(s);
+  RenderHold hold(s->device); // no server is (re)launched on this device until this call has enqueued its work
   if (!rc) rc = servers_retire_device(s->device); // a resident trace server leaves first: this launch wants every CU
   if (rc) return rc;
   if (stats) memset(stats, 0, sizeof(*stats));
@@ -1872,6 +1926,7 @@ int mgpu_render_panoramic_device(MgpuScene *s, const double origin[3], int W, in
   if (rng_mode == MGPU_RNG_TABLE && !d_rng_states) return fail(MGPU_ERR_INVALID, "MGPU_RNG_TABLE needs rng_states");
   const double t0 = now_ms();
   int rc = set_device(s);
+  RenderHold hold(s->device); // no server is (re)launched on this device until this call has enqueued its work
   if (!rc) rc = servers_retire_device(s->device); // a resident trace server leaves first: this launch wants every CU
   if (rc) return rc;
   if (stats) memset(stats, 0, sizeof(*stats));

@@ -707,9 +707,13 @@ __device__ __forceinline__ bool plane_hit(const float pl[4], const double unit_n
 }
 
 // ---- GenerateBasis + SampleDiffuseIS (render.cc:271-339) ------------------------------------------------------------------
-// `azimuth`: null = the device library's sincospi; a table in LDS = sincos_turn (mgpu_sincos.hpp), the same two numbers to
-// 2e-16 for a quarter of the instructions (k_render_sm).
-__device__ __forceinline__ V3 sample_diffuse(V3 n, Rng &rng, const SincosTable *azimuth = nullptr) {
+// TURN = false: the azimuth through the device library's sincospi; TURN = true: through sincos_turn and its table in LDS
+// (mgpu_sincos.hpp), the same two numbers to 2e-16 for a quarter of the instructions (k_render_sm, k_render_env).
+// A compile-time switch, not a null test of `azimuth`: the address of an LDS object may legitimately be 0, so the compiler kept
+// both evaluations alive -- and hoisted the library polynomial's constants into six register pairs it then spilled (until
+// round 4: 12 of the LDS variant's 13 spilled VGPRs served a branch that never ran).
+template <bool TURN>
+__device__ __forceinline__ V3 sample_diffuse_t(V3 n, Rng &rng, const SincosTable *azimuth) {
   // Minor axis by |n[i]| compared after rounding to float (fabsf); the loop of render.cc:279-285 keeps the FIRST
   // strict minimum below 1e6, and an index that stays -1 (NaN / huge normal) takes the final else branch.
   // Written as boolean selects, not as an int index + if/else-if chain: hipcc (ROCm 7.2, clang 22) lowers that
@@ -750,7 +754,7 @@ __device__ __forceinline__ V3 sample_diffuse(V3 n, Rng &rng, const SincosTable *
   const double s2 = fma(-x, x, 1.0); // >= 2^-53 or exactly 0 (u1 == 0)
   if (__builtin_expect(__ballot(!(s2 > 0x1p-100)) != 0ull, 0)) sin_theta = sqrt(s2);
   else sin_theta = sqrt_core(s2);
-  if (azimuth) sincos_turn(k2, *azimuth, sin_phi, cos_phi);
+  if constexpr (TURN) sincos_turn(k2, *azimuth, sin_phi, cos_phi);
   else sincospi(2.0 * u2, &sin_phi, &cos_phi);
 #endif
   const V3 T = scale(scale(t, cos_phi), sin_theta);
@@ -758,6 +762,9 @@ __device__ __forceinline__ V3 sample_diffuse(V3 n, Rng &rng, const SincosTable *
   const V3 N = scale(n, cos_theta);
   return (T + B) + N;
 }
+
+__device__ __forceinline__ V3 sample_diffuse(V3 n, Rng &rng) { return sample_diffuse_t<false>(n, rng, nullptr); }
+__device__ __forceinline__ V3 sample_diffuse(V3 n, Rng &rng, const SincosTable *azimuth) { return sample_diffuse_t<true>(n, rng, azimuth); }
 
 // Camera::GenerateRay direction (camera.cc:222-240)
 __device__ __forceinline__ V3 camera_dir(const double *frame, double u, double v) {

@@ -110,6 +110,12 @@ struct Slot {
   hipEvent_t rendered = nullptr, exchanged = nullptr;
   hipEvent_t x0 = nullptr, x1 = nullptr; // rank 0: the exchange step of this slot's frame on the communicator stream (timed)
   bool x_pending = false;                // x0 / x1 were recorded and not read yet
+  // rank 0 with the read-back on (mgpu_frame_set_readback): the frame's landing buffer in pinned host memory and the event
+  // behind its device-to-host copy on the member's read-back stream
+  float *host = nullptr;
+  hipEvent_t copied = nullptr;
+  bool copy_wanted = false;  // a frame was enqueued with the read-back on and its copy has not been issued yet
+  bool copy_pending = false; // the copy was issued: `copied` is behind it
 };
 
 struct Member { // one GPU of this process
@@ -118,6 +124,7 @@ struct Member { // one GPU of this process
   int n_rows = 0;
   ncclComm_t comm = nullptr;
   hipStream_t comm_stream = nullptr; // every RCCL call of this communicator, in frame order
+  hipStream_t rb_stream = nullptr;   // rank 0 with the read-back on: the device-to-host copies, frame after frame
   Slot slot[kMaxInFlight];
 };
 
@@ -141,6 +148,10 @@ struct MgpuFrame {
   // exchange timing (rank 0's communicator stream): summed when a slot is waited for or reused
   double x_ms_sum = 0.0;
   unsigned long long x_frames = 0, x_ops = 0; // frames measured; receives rank 0 posts per frame
+  // SURVEY 8(d)'s frame ends with ONE read-back.  With `readback` on, every frame's copy to pinned host memory is enqueued
+  // behind its exchange on a stream of its own, so it runs under the NEXT frame's kernel (frames_in_flight >= 2); the slot is
+  // not rendered into again before the copy has left it.  mgpu_frame_wait_host hands the pinned buffer out.
+  bool readback = false;
   bool broken = false; // a render call failed half-way: streams and slots are out of step, only destroy is allowed
 };
 
@@ -240,6 +251,15 @@ int place_strips(float *frame, const float *local, int rows, int owner, int worl
   return MGPU_OK;
 }
 
+// The stream a member's launches go to.  Slots have streams of their own so that consecutive frames' launches overlap where one
+// ends and the next begins -- and, enqueued back to back, two whole-GPU persistent launches then share the CUs and
+// finish TOGETHER, which is fine for throughput and useless for a read-back that wants to run under the NEXT frame's kernel
+// (measured, tools/perf_copy_overlap*.py: frames complete in pairs and one copy per pair is exposed).  With the read-back on and
+// one GPU, frames therefore go down ONE stream, in order.
+hipStream_t render_stream(const MgpuFrame *f, const Member &m, int first_slot) {
+  return (f->readback && f->world == 1) ? m.slot[0].stream : m.slot[first_slot].stream;
+}
+
 // reads a finished slot's exchange timing into the frame's sums (rank 0's member only)
 void collect_timing(MgpuFrame *f, Slot &s, bool wait) {
   if (!s.x_pending) return;
@@ -320,7 +340,10 @@ int mgpu_frame_destroy(MgpuFrame *f) {
       if (s.x0) (void)hipEventDestroy(s.x0);
       if (s.x1) (void)hipEventDestroy(s.x1);
       if (s.stream) (void)hipStreamDestroy(s.stream);
+      if (s.copied) (void)hipEventDestroy(s.copied);
+      if (s.host) (void)hipHostFree(s.host);
     }
+    if (m.rb_stream) (void)hipStreamDestroy(m.rb_stream);
     if (m.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m.comm);
     if (m.comm_stream) (void)hipStreamDestroy(m.comm_stream);
   }
@@ -465,10 +488,11 @@ static int render_frames_enqueue(MgpuFrame *f, const double cam[12], int maxPath
   const bool block = f->exchange_mode == MGPU_EXCHANGE_BLOCK;
   for (Member &m : f->members) {
     FHIP(hipSetDevice(m.device));
-    hipStream_t rs = m.slot[ks[0]].stream; // the launch and the copies of the whole batch
+    hipStream_t rs = render_stream(f, m, ks[0]); // the launch and the copies of the whole batch
     // the slots' previous frames must have left their buffers: their exchange is the last thing that touched them
     for (int i = 0; i < n; ++i) {
       FHIP(hipStreamWaitEvent(rs, m.slot[ks[i]].exchanged, 0));
+      if (m.slot[ks[i]].copy_pending) FHIP(hipStreamWaitEvent(rs, m.slot[ks[i]].copied, 0)); // ... and its read-back
       if (m.rank == 0) collect_timing(f, m.slot[ks[i]], false);
     }
     if (m.n_rows) {
@@ -602,10 +626,12 @@ static int render_frames_enqueue(MgpuFrame *f, const double cam[12], int maxPath
         FHIP(hipEventRecord(m.slot[k].x1, m.comm_stream));
         m.slot[k].x_pending = true;
       }
-      FHIP(hipEventRecord(m.slot[k].exchanged, exchange ? m.comm_stream : m.slot[ks[0]].stream));
+      FHIP(hipEventRecord(m.slot[k].exchanged, exchange ? m.comm_stream : render_stream(f, m, ks[0])));
     }
     if (slots_out) slots_out[i] = k;
   }
+  if (f->readback && root)
+    for (int i = 0; i < n; ++i) root->slot[ks[i]].copy_wanted = true; // issued by mgpu_frame_wait_host, see there
   f->next += (unsigned long long)n;
   return MGPU_OK;
 }
@@ -651,6 +677,62 @@ int mgpu_frame_wait(MgpuFrame *f, int slot, float *host_image, float **device_im
     FHIP(hipMemcpy(host_image, dev, sizeof(float) * 3 * (size_t)f->W * f->H, hipMemcpyDeviceToHost));
   }
   return MGPU_OK;
+}
+
+int mgpu_frame_set_readback(MgpuFrame *f, int on) {
+  if (!f) return ffail(MGPU_ERR_INVALID, "NULL argument");
+  if (f->broken) return ffail(MGPU_ERR_INVALID, "this frame object failed in an earlier render call and can only be destroyed");
+  for (Member &m : f->members) {
+    if (m.rank != 0) continue;
+    FHIP(hipSetDevice(m.device));
+    if (on && !m.rb_stream) FHIP(hipStreamCreateWithFlags(&m.rb_stream, hipStreamNonBlocking));
+    for (int k = 0; k < f->in_flight; ++k) {
+      Slot &s = m.slot[k];
+      if (s.copy_pending) { // a switch between frames: nothing of the old mode stays in flight
+        FHIP(hipEventSynchronize(s.copied));
+        s.copy_pending = false;
+      }
+      s.copy_wanted = false;
+      if (s.exchanged) FHIP(hipEventSynchronize(s.exchanged)); // the render stream changes with the mode (render_stream)
+      if (on && !s.host) {
+        FHIP(hipHostMalloc((void **)&s.host, sizeof(float) * 3 * (size_t)f->W * f->H, hipHostMallocDefault));
+        FHIP(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+      }
+    }
+  }
+  f->readback = on != 0;
+  return MGPU_OK;
+}
+
+int mgpu_frame_wait_host(MgpuFrame *f, int slot, const float **host_image) {
+  if (!f || slot < 0 || slot >= f->in_flight || !host_image) return ffail(MGPU_ERR_INVALID, "bad frame / slot / NULL argument");
+  *host_image = nullptr;
+  for (Member &m : f->members) {
+    FHIP(hipSetDevice(m.device));
+    if (m.rank != 0) {
+      FHIP(hipEventSynchronize(m.slot[slot].exchanged));
+      continue;
+    }
+    Slot &s = m.slot[slot];
+    if (!(s.copy_wanted || s.copy_pending) || !s.host)
+      return ffail(MGPU_ERR_INVALID, "slot %d has no read-back in flight (mgpu_frame_set_readback before the render call)", slot);
+    if (s.copy_wanted) {
+      // The copy is enqueued by the HOST once it has seen the frame complete, not by a stream-side wait: a copy that waits on
+      // the GPU for the frame's event costs 0.12 ms of a 5.5 ms frame more (the runtime then orders it through the compute
+      // queue), one enqueued after the fact goes straight to the copy engine and disappears under the next frame's kernel
+      // (5.54 ms per C2 frame with and without it; tools/perf_copy_overlap3.py).
+      FHIP(hipEventSynchronize(s.exchanged));
+      FHIP(hipMemcpyAsync(s.host, s.frame, sizeof(float) * 3 * (size_t)f->W * f->H, hipMemcpyDeviceToHost, m.rb_stream));
+      FHIP(hipEventRecord(s.copied, m.rb_stream));
+      s.copy_wanted = false;
+      s.copy_pending = true;
+    }
+    FHIP(hipEventSynchronize(s.copied));
+    collect_timing(f, s, true);
+    *host_image = s.host;
+    return MGPU_OK;
+  }
+  return ffail(MGPU_ERR_INVALID, "this process does not hold rank 0: the frame lives elsewhere");
 }
 
 int mgpu_frame_stats(MgpuFrame *f, MgpuFrameStats *out, int reset) {

@@ -39,6 +39,10 @@ struct RenderParams {
   // which is the correctly rounded quotient when y is the correctly rounded reciprocal (Markstein); tests/test_host_cpu.py
   // checks the sequence against exact rational arithmetic.  Longer paths divide.
   double inv_len[17];
+  // tail_unit[m][L0], 1 <= L0 <= maxPathLength <= 16: the post-miss tail's sum for throughput 1 starting at length L0 with the
+  // material multiplier 0.5 applied (m = 1) or not (m = 0: the plane) -- the kernel's own loop run on the host
+  // (fill_tail_unit): for a power-of-two throughput the sum is throughput x this, bit for bit.
+  double tail_unit[2][17];
   int rng_mode;
   const uint32_t *rng_states; // device, MGPU_RNG_TABLE layout, or null
   unsigned long long seed;
@@ -59,6 +63,22 @@ struct RenderParams {
   double *probe;                 // device or null: kProbeStride doubles per PathTrace iteration of ONE path
   uint32_t probe_pixel, probe_pass; // full-frame pixel index and pass of the probed path
 };
+// the GREY tail loop of k_render_sm (render.cc:409-418 after the first miss) for throughput 1, diffuse 0.5
+inline void fill_tail_unit(RenderParams &P) {
+  for (int m = 0; m < 2; ++m)
+    for (int L0 = 0; L0 <= 16; ++L0) {
+      double rad = 0.0, thr = 1.0;
+      if (L0 >= 1 && L0 <= P.maxPathLength && P.maxPathLength <= 16)
+        for (int L = L0;; ++L) {
+          const double x = thr * 0.5, y = P.inv_len[L], dl = (double)(unsigned)L;
+          const double q = x * y;
+          rad += __builtin_fma(__builtin_fma(-q, dl, x), y, q);
+          if (L >= P.maxPathLength) break;
+          if (m) thr *= 0.5;
+        }
+      P.tail_unit[m][L0] = rad;
+    }
+}
 constexpr int kProbeStride = 16; // org[3] dir[3] t hit slot normal[3] materialID pathLength throughput.x radiance.x
 
 // stack capacities (LDS entries per lane) the kernels are instantiated for

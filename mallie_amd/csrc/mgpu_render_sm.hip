@@ -97,11 +97,17 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 #ifndef MGPU_SINCOS_TURN
 #define MGPU_SINCOS_TURN 1
 #endif
+#ifndef MGPU_TAIL_TABLE
+#define MGPU_TAIL_TABLE 1
+#endif
 #ifndef MGPU_TAIL_RECIP
 #define MGPU_TAIL_RECIP 1
 #endif
 #ifndef MGPU_OCC
 #define MGPU_OCC 0 // 1: active-lane accounting (kOcc* words); built into libmallie_mgpu_occ.so only, see mallie_amd/build.py
+#endif
+#ifndef MGPU_ROOT_AT_ARM
+#define MGPU_ROOT_AT_ARM 0 // experiment (profiles/experiments/README.md, round 4: measured, not kept); LDS-resident scene: the root box test where the ray is armed (see there)
 #endif
 #ifndef MGPU_SHARED_LEAVES
 #define MGPU_SHARED_LEAVES 1
@@ -266,6 +272,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
 #ifdef MGPU_UTIL
   uint32_t u_node = 0, u_tri = 0, u_shade = 0, u_shade_lanes = 0;
   unsigned long long u_hist = 0;
+  uint32_t u_tail_steps = 0, u_bounce_steps = 0, u_start_steps = 0; // SHADE steps in which the sub-body ran (booked by its first lane)
   uint32_t u_node_it = 0, u_tri_it = 0; // loop iterations inside NODE / TRI steps (one lane of the wave books each)
   unsigned long long cyc_node = 0, cyc_tri = 0, cyc_shade = 0, cyc_t0 = 0, cyc_s = 0;
   unsigned long long cyc_sub[6] = {0, 0, 0, 0, 0, 0};
@@ -530,6 +537,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
               // throughput*0.5/length and re-applies the stale material.  Their RNG draws cannot reach
               // this pixel's value, so the tail is evaluated in closed loop: same adds, same multiplies, same order.
               trace_calls += (uint32_t)P.maxPathLength;
+#ifdef MGPU_UTIL
+              const unsigned long long cyc_tail0 = clock64();
+              const bool tail_first = lane == __ffsll((long long)__ballot(1)) - 1;
+#endif
               double d0 = 0.5, d1 = 0.5, d2 = 0.5; // Material().diffuse default (material.h:12-15)
               const bool mul = last_mat != kNoMaterial;
               if (mul && (size_t)(int)last_mat < (size_t)sc.nm) {
@@ -537,11 +548,24 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
                 d1 = sc.mat_diffuse[3 * (size_t)last_mat + 1];
                 d2 = sc.mat_diffuse[3 * (size_t)last_mat + 2];
               }
+#ifdef MGPU_ABL_NOTAIL // timing ablation only (wrong image): what the closed-loop tail costs
+              if (thr0 == 12345.0)
+#endif
               if (GREY || (thr0 == thr1 && thr1 == thr2 && d0 == d1 && d1 == d2)) {
                 // grey path (every material the reference can load from .obj/.eson is grey): the three channels
                 // perform identical operations on identical values, so evaluate one and copy -- same bits, 1/3 of the
                 // fp64 divisions
-                if (MGPU_TAIL_RECIP && P.maxPathLength <= 16) { // x / L through the rounded reciprocal (mgpu_kernels.hpp, inv_len)
+                // Throughput a power of two and a 0.5-grey (or no) multiplier -- every scene the reference loads without an .mtl:
+                // Material() is 0.5 grey (material.h:12-15) -- make every operand of the loop below a power-of-two multiple of
+                // what it is for throughput 1, and scaling by a power of two commutes with every rounding in it (no underflow
+                // above 2^-900): the sum is throughput x (the loop's result for throughput 1), which the host tabulates per
+                // (multiplier on / off, first length) with the loop's own operations (RenderParams::tail_unit).
+                const unsigned long long thr_bits = (unsigned long long)__double_as_longlong(thr0);
+                const bool unit_ok = MGPU_TAIL_TABLE && P.maxPathLength <= 16 && d0 == 0.5 && (thr_bits & 0x000FFFFFFFFFFFFFull) == 0ull &&
+                                     thr0 >= 0x1p-900 && thr0 <= 1.0;
+                if (MGPU_TAIL_TABLE && __ballot(!unit_ok) == 0ull) {
+                  rad0 = thr0 * P.tail_unit[mul ? 1 : 0][pathLength];
+                } else if (MGPU_TAIL_RECIP && P.maxPathLength <= 16) { // x / L through the rounded reciprocal (mgpu_kernels.hpp, inv_len)
                   for (int L = pathLength;; ++L) {
                     const double x = thr0 * 0.5, y = P.inv_len[L], dl = (double)(unsigned)L;
                     const double q = x * y;
@@ -578,16 +602,23 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
                   if (mul) { thr0 *= d0; thr1 *= d1; thr2 *= d2; }
                 }
               }
+#ifdef MGPU_UTIL
+              if (tail_first) { cyc_sub[1] += clock64() - cyc_tail0; u_tail_steps++; }
+#endif
             }
           } else if (pathLength >= P.maxPathLength) {
             path_done = true;
             trace_calls += (uint32_t)P.maxPathLength;
           } else {
+#ifdef MGPU_UTIL
+            const unsigned long long cyc_b0 = clock64();
+            const bool bounce_first = lane == __ffsll((long long)__ballot(1)) - 1;
+#endif
             const V3 hitP = org + scale(dir, t);
             (void)rng_next(rng); // `double r = randomreal();` drawn and never used (render.cc:430)
             const double ndoti = dot(n, neg(dir));
             if (ndoti < 0.0) n = neg(n);
-            const V3 sd = sample_diffuse(n, rng, MGPU_SINCOS_TURN ? &s_azimuth : nullptr);
+            const V3 sd = sample_diffuse_t<MGPU_SINCOS_TURN != 0>(n, rng, &s_azimuth);
             if (last_mat != kNoMaterial) { // Scene::GetMaterial, scene.h:58-65
               if ((size_t)(int)last_mat < (size_t)sc.nm) {
                 thr0 *= sc.mat_diffuse[3 * (size_t)last_mat + 0];
@@ -603,6 +634,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
             org = hitP + scale(sd, 1.0e-3);
             dir = sd;
             ++pathLength;
+#ifdef MGPU_UTIL
+            if (bounce_first) { cyc_sub[3] += clock64() - cyc_b0; u_bounce_steps++; }
+#endif
           }
           if (path_done) {
             // image[...] = radiance (double -> float, render.cc:673-675); passes are summed later, in order
@@ -612,9 +646,14 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
             float *dst = P.pass_stride ? P.out + (size_t)pass * P.pass_stride + ((size_t)(ly >> 3) * tiles_x + (lx >> 3)) * 192u +
                                              (size_t)(((ly & 7u) << 3) + (lx & 7u)) * 3u
                                        : P.out + 3 * ((size_t)ly * (size_t)win_w + lx);
-            dst[0] = (float)rad0;
-            dst[1] = (float)rad1;
-            dst[2] = (float)rad2;
+#ifdef MGPU_ABL_NOSTORE // timing ablation only (wrong image): what the result stores cost
+            if (rad0 == 12345.0)
+#endif
+            {
+              dst[0] = (float)rad0;
+              dst[1] = (float)rad1;
+              dst[2] = (float)rad2;
+            }
             if (P.tile_cost && pass == 0) // what this path cost, for the next launch's hand-out order
               atomicAdd(P.tile_cost + ((ly >> 3) * tiles_x + (lx >> 3)), n_nodes + n_tris + 16u * n_rays - cost_base);
           }
@@ -720,6 +759,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
       if (shade_lane) {
         if (path_done && have_path) {
           have_path = false;
+#ifdef MGPU_UTIL
+          if (lane == __ffsll((long long)__ballot(1)) - 1) u_start_steps++;
+#endif
           // start a new eye path (PathTrace prologue, render.cc:387-400)
           const uint32_t j = ly;
           // pix_step > 1: Render(step): the window is in units of step x step blocks and a block's path is that of its
@@ -732,7 +774,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
             const uint4 q = reinterpret_cast<const uint4 *>(P.rng_states)[(size_t)pass * P.W * P.H + gpix];
             s4[0] = q.x; s4[1] = q.y; s4[2] = q.z; s4[3] = q.w;
           } else {
+#ifdef MGPU_ABL_CHEAPSTART // timing ablation only (another image): what the splitmix64 seeding costs
+            s4[0] = gpix * 2654435761u ^ (uint32_t)pass; s4[1] = gpix + 0x9E3779B9u; s4[2] = (uint32_t)pass * 40503u + 1u; s4[3] = gpix ^ 0x85EBCA6Bu;
+#else
             hash_state(P.seed, P.pass_base + (uint32_t)pass, gpix, s4);
+#endif
           }
           rng = Rng{s4[0], s4[1], s4[2], s4[3]};
           probe_on = P.probe && gpix == P.probe_pixel && (uint32_t)pass == P.probe_pass;
@@ -759,15 +805,46 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
           ray_plain = sc.boxes_ordered && inv_ok && origin_is_finite(org);
           bt = kDblMax; bu = 0.0; bv = 0.0; bslot = kNoHit;
           sp = 0;
+          have_ray = true;
+          ++n_rays;
+          st = ST_NODE;
           if constexpr (LDS_SCENE) {
+#if MGPU_ROOT_AT_ARM
+            // The reference's first pop -- the root, tested against the fresh ray (bvh_accel.cc:805-812) -- happens here, where
+            // the ray is made: three rays in five of the Cornell frame (sky and plane pixels, bounces that leave the box) end at
+            // this test, and no longer pass through a NODE step to find that out.  Same test, same count, same pushes.
+            {
+              const double2 rb0 = *reinterpret_cast<const double2 *>(lds_nodes), rb1 = *reinterpret_cast<const double2 *>(lds_nodes + 16),
+                            rb2 = *reinterpret_cast<const double2 *>(lds_nodes + 32);
+              const int4 rmeta = *reinterpret_cast<const int4 *>(lds_nodes + 48);
+              const bool sx = (sgn & 1u) != 0u, sy = (sgn & 2u) != 0u, sz = (sgn & 4u) != 0u;
+              ++n_nodes;
+              sp = -1;
+              st = ST_SHADE; // a miss: the ray is finished
+              const bool rhit = (__ballot(!ray_plain) == 0ull) ? slab_hit<true>(rb0, rb1, rb2, org, ix, iy, iz, sx, sy, sz, bt)
+                                                              : slab_hit<false>(rb0, rb1, rb2, org, ix, iy, iz, sx, sy, sz, bt);
+              if (rhit) {
+                if (rmeta.x == 0) {
+                  const bool nearIsSecond = ((sgn >> (uint32_t)rmeta.y) & 1u) != 0u;
+                  const uint32_t c0 = (uint32_t)rmeta.z, c1 = (uint32_t)rmeta.w;
+                  stk.put(0, nearIsSecond ? c0 : c1); // far
+                  stk.put(1, nearIsSecond ? c1 : c0); // near: popped first
+                  sp = 1;
+                  st = ST_NODE;
+                } else if (rmeta.z != 0) {
+                  tri_cur = (uint32_t)rmeta.w;
+                  tri_end = (uint32_t)rmeta.w + (uint32_t)rmeta.z;
+                  st = ST_TRI;
+                }
+              }
+            }
+#else
             stk.put(0, 0u);
+#endif
           } else {
             cur = TL ? kWTreelet : sc.wroot; // the super root (record 0 of the treelet): its child 0 is the tree's root (the reference's first pop)
             n_nodes -= 1u;  // ... and its child 1 a dummy the reference never pops
           }
-          have_ray = true;
-          ++n_rays;
-          st = ST_NODE;
         }
       }
 #ifdef MGPU_UTIL
@@ -811,6 +888,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
   {
     unsigned long long a = u_node, b = u_tri, cc = u_shade, d = u_shade_lanes;
     unsigned long long e_rays = n_rays - dry_rays, e_act = dry_active, e_plen = dry_plen, it_n = u_node_it, it_t = u_tri_it;
+    unsigned long long s_tail = u_tail_steps, s_bounce = u_bounce_steps, s_start = u_start_steps, c_tail = cyc_sub[1], c_bounce = cyc_sub[3];
     for (int off = 32; off; off >>= 1) {
       a += __shfl_down(a, off);
       b += __shfl_down(b, off);
@@ -821,6 +899,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
       e_plen += __shfl_down(e_plen, off);
       it_n += __shfl_down(it_n, off);
       it_t += __shfl_down(it_t, off);
+      s_tail += __shfl_down(s_tail, off);
+      s_bounce += __shfl_down(s_bounce, off);
+      s_start += __shfl_down(s_start, off);
+      c_tail += __shfl_down(c_tail, off);
+      c_bounce += __shfl_down(c_bounce, off);
     }
     if (lane == 0) {
       atomicAdd(&P.stats[kUtilNodeSteps], a);
@@ -832,7 +915,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
       atomicAdd(&P.stats[16], cyc_node);
       atomicAdd(&P.stats[17], cyc_tri);
       atomicAdd(&P.stats[18], cyc_shade);
+      cyc_sub[1] = c_tail;   // wave totals (booked by the sub-body's first lane), not lane-0 samples
+      cyc_sub[3] = c_bounce;
       for (int k = 0; k < 6; ++k) atomicAdd(&P.stats[19 + k], cyc_sub[k]);
+      atomicAdd(&P.stats[kUtilTraceLanes], s_tail);
+      atomicAdd(&P.stats[kUtilGenLanes], s_bounce);
+      atomicAdd(&P.stats[5], s_start);
       const unsigned long long loop_cyc = clock64() - cyc_loop0;
       atomicAdd(&P.stats[25], loop_cyc);
       atomicMax(&P.stats[26], loop_cyc);

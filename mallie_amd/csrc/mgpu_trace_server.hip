@@ -207,7 +207,8 @@ __global__ __launch_bounds__(64) void k_trace_server(DScene sc, TraceMailbox *mb
     } else if (lane == 0) {
       unsigned long long last = __hip_atomic_load(&ctl->last_work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (last < t_start) last = t_start;
-      if (stop || now - last > idle_ticks) __hip_atomic_store(&ctl->quit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (`last` may be another wave's later clock reading -- fetch_max above -- in which case the unsigned difference would wrap)
+      if (stop || (last < now && now - last > idle_ticks)) __hip_atomic_store(&ctl->quit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (lane == 0 && now - t_start > life_ticks) __hip_atomic_store(&ctl->quit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }

@@ -125,6 +125,10 @@ def load_library():
     L.mgpu_frame_render_batch.restype = i32
     L.mgpu_frame_wait.argtypes = [vp, i32, vp, C.POINTER(vp)]
     L.mgpu_frame_wait.restype = i32
+    L.mgpu_frame_set_readback.argtypes = [vp, i32]
+    L.mgpu_frame_set_readback.restype = i32
+    L.mgpu_frame_wait_host.argtypes = [vp, i32, C.POINTER(vp)]
+    L.mgpu_frame_wait_host.restype = i32
     L.mgpu_frame_done_event_wait.argtypes = [vp, i32, vp]
     L.mgpu_frame_done_event_wait.restype = i32
     L.mgpu_frame_stats.argtypes = [vp, C.POINTER(FrameStats), i32]
@@ -357,6 +361,23 @@ class Frame:
         if rc:
             raise MgpuError(rc, "mgpu_frame_wait", L.mgpu_frame_last_error().decode())
         return host if to_host else (dev.value or 0)
+
+    def set_readback(self, on=True):
+        """mgpu_frame_set_readback: every frame enqueued from now on is copied to a pinned host buffer of its slot behind its
+        exchange, on a copy stream (under the next frame's kernel when frames_in_flight >= 2)."""
+        rc = load_library().mgpu_frame_set_readback(self.h, 1 if on else 0)
+        if rc:
+            raise MgpuError(rc, "mgpu_frame_set_readback", load_library().mgpu_frame_last_error().decode())
+
+    def wait_host(self, slot, copy=False):
+        """mgpu_frame_wait_host: blocks until the slot's read-back is complete; returns the pinned host frame as an H x W x 3
+        float32 array that ALIASES the slot's buffer (valid until the slot renders again), or a copy of it."""
+        ptr = C.c_void_p()
+        rc = load_library().mgpu_frame_wait_host(self.h, slot, C.byref(ptr))
+        if rc:
+            raise MgpuError(rc, "mgpu_frame_wait_host", load_library().mgpu_frame_last_error().decode())
+        a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(self.H, self.W, 3))
+        return a.copy() if copy else a
 
     def stats(self, reset=False):
         """mgpu_frame_stats: world, members of this process, rccl_ranks (read back from the communicator), exchange mode

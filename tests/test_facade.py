@@ -260,7 +260,7 @@ def test_facade_render_and_trace_on_gpu(driver, tmp_path):
     rp2 = str(tmp_path / "rays2.bin")
     rays2.tofile(rp2)
     modes = {"server": {}, "queue": {"MGPU_TRACE_SERVER": "0"}, "launch": {"MGPU_TRACE_SERVER": "0", "MGPU_TRACE_QUEUE": "0"}}
-    rate, ref_bytes = {}, None
+    rate, per_launch, ref_bytes = {}, {}, None
     for mode, env in modes.items():
         for nt in (1, 4, 16):
             opq = str(tmp_path / ("hits_%s_%d.bin" % (mode, nt)))
@@ -270,17 +270,21 @@ def test_facade_render_and_trace_on_gpu(driver, tmp_path):
             rate[(mode, nt)] = float(re.search(r"([0-9.]+) calls/s", r.stdout).group(1))
             print("%s: %s" % (mode, " | ".join(l for l in r.stdout.splitlines() if l.startswith("trace_mt"))))
             assert ("resident server" in r.stdout) == (mode == "server"), r.stdout
+            m = re.search(r"(?:submission queue|resident server): (\d+) calls in (\d+) launches", r.stdout)
+            if m:
+                per_launch[(mode, nt)] = int(m.group(1)) / max(1, int(m.group(2)))
             b = open(opq, "rb").read()
             ref_bytes = ref_bytes or b
             assert b == ref_bytes, (mode, nt)
+    # calls/s are logged, not asserted (wall-clock ratios of 2 000-call runs on a shared box do not belong in a
+    # correctness suite; tools/perf_trace_calls.sh and bench.py's scene_trace_one_ray_calls are where they are measured).  What IS
+    # asserted is the mechanism: the server serves (nearly) all calls of a run from a handful of launches, and the queue combines
+    # concurrent callers into shared launches
     print("Scene::Trace calls/s at 1 / 4 / 16 threads: " + " | ".join(
         "%s %.0f / %.0f / %.0f" % (m, rate[(m, 1)], rate[(m, 4)], rate[(m, 16)]) for m in modes))
-    assert rate[("queue", 4)] >= 2.0 * rate[("launch", 4)] and rate[("queue", 16)] >= 3.0 * rate[("launch", 16)], rate
-    assert rate[("queue", 1)] >= 0.9 * rate[("launch", 1)], rate  # a caller that is alone waits for nobody
-    # measured on the round-3 box (8 000 calls, tools/perf_trace_calls.sh): server 82 k / 325 k / 1 155 k calls/s, queue 34 k / 70 k /
-    # 145 k, a launch per call 31 k / 30 k / 30 k -- 2.7x / 10.7x / 38x; the bars below leave room for a slower host
-    assert rate[("server", 1)] >= 1.6 * rate[("launch", 1)] and rate[("server", 4)] >= 6.0 * rate[("launch", 4)], rate
-    assert rate[("server", 16)] >= 15.0 * rate[("launch", 16)], rate
+    for nt in (1, 4, 16):
+        assert per_launch[("server", nt)] >= 100, per_launch   # 2 000 calls: at most 20 server launches (idle exits on a slow host)
+    assert per_launch[("queue", 16)] > 1.5 and per_launch[("queue", 1)] == 1.0, per_launch
 
 
 @pytest.mark.gpu

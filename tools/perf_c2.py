@@ -38,6 +38,9 @@ if os.environ.get("UTIL"):
         tot = cn + ct + cs + cb
         print("  cycle share: node %.1f%% (%.0f cyc/step)  tri %.1f%% (%.0f cyc/step)  shade %.1f%% (%.0f cyc/step)  [wave wall-clock cycles incl. interleaving]" % (
             100 * cn / tot, cn / max(1, ns), 100 * ct / tot, ct / max(1, ts_), 100 * cs / tot, cs / max(1, outer)))
+    if trl or genl:
+        print("  SHADE sub-bodies (wave level): miss tail ran in %d steps (%.0f cyc each), bounce in %d steps (%.0f cyc each), path start in %d steps; of %d SHADE steps" % (
+            trl, int(w[20]) / max(1, trl), genl, int(w[22]) / max(1, genl), int(w[5]), outer))
     sub = [int(x) for x in w[19:25]]
     if sum(sub):
         names = ["1a normals+plane", "(unused)", "1b miss/bounce/accum", "2 hand-out", "3a new path", "3b arm"]
