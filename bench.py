@@ -700,6 +700,13 @@ def main():
             # the C ABI's exchange step priced on this one GPU (MGPU_FRAME_FORCE_EXCHANGE: the frame's strips are sent to
             # ourselves through RCCL), both exchange modes, 1080p (135 strips) -- device time of the step per frame
             out["exchange_on_one_gpu"] = forced_exchange_timing(M, scene, frame, W, H, mpl, spp, plane, cfg["seed"], local_rank, torch, dev)
+            # the reference's OWN random stream (render.cc:116-168: one xorshift128 state walked through the frame in scanline order)
+            # resolved on the device: one 1080p pass, 16 segments (the reference's compiled-in kMaxPathLength) -- the only mode whose
+            # image IS the reference's image.  Chip-wide resolution (mgpu_stream.hip) against the round-3 one-workgroup walk.
+            try:
+                out["reference_stream_1080p"] = reference_stream_timing(scene, frame, W, H, plane)
+            except Exception as e:  # an extra line must never take the headline down
+                out["reference_stream_1080p"] = {"error": repr(e)}
             # the fast mode (MGPU_PRECISION_FP32, SURVEY 7 step 6 "report both"): the same frames in float.  Never `value`:
             # its frames are close to the reference's, not equal to them -- the distance is measured here, on the last frame.
             try:
@@ -762,6 +769,36 @@ def main():
     flush_c_stdio()
     if out is not None:
         print(json.dumps(out), flush=True)
+
+
+def reference_stream_timing(scene, frame, W, H, plane, mpl=16):
+    """mgpu_render_stream, one pass: wall ms of the stream resolution (first call = classification + whatever attempts its
+    verification asked for; later calls continue the stream with the camera's classes cached) and of the round-3 serial kernel."""
+    import hashlib
+    state, res, first = None, [], None
+    for k in range(5):
+        img, _, st, state, _ = scene.render_stream(frame, W, H, mpl, 1, plane, stream_state=state)
+        ss = scene.stream_stats()
+        if k == 0:
+            first, digest = ss, hashlib.sha256(img.tobytes()).hexdigest()
+        else:
+            res.append(ss["resolve_ms"])
+    os.environ["MGPU_STREAM_SERIAL"] = "1"
+    try:
+        t0 = time.perf_counter()
+        img_s, _, st_s, _, _ = scene.render_stream(frame, W, H, mpl, 1, plane)
+        serial_ms = 1e3 * (time.perf_counter() - t0)
+    finally:
+        del os.environ["MGPU_STREAM_SERIAL"]
+    return {"resolve_ms_per_pass": round(float(np.median(res)), 3), "resolve_ms_first_call": round(first["resolve_ms"], 3),
+            "resolve_ms_later_calls": [round(x, 3) for x in res], "uncertain_pixels_per_pass": ss["uncertain_pixels"],
+            "resolutions_repeated_in_5_calls": int(ss["retries"]), "serial_kernel_call_ms": round(serial_ms, 1),
+            "first_frame_equals_serial_kernels": bool(hashlib.sha256(img_s.tobytes()).hexdigest() == digest),
+            "frame_kernel_ms": round(st["kernel_ms"], 3), "maxPathLength": mpl,
+            "note": "start state of every pixel of a %dx%d pass in the reference's serial xorshift128 stream, from its seed alone: "
+                    "classification (cached per camera), the chain over the uncertain pixels in rounds of 128 with every possible hit "
+                    "count traced at once, and a verification trace of every pixel; wall ms from the first kernel to the verdict. "
+                    "serial_kernel_call_ms = the whole call with MGPU_STREAM_SERIAL=1 (one workgroup walks the chain)" % (W, H)}
 
 
 def forced_exchange_timing(M, scene, frame, W, H, mpl, spp, plane, seed, device, torch, dev, frames=6):

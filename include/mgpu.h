@@ -193,6 +193,12 @@ int mgpu_render_stream(MgpuScene *scene, const double origin[3], const double co
                        const double dv[3], int W, int H, int maxPathLength, int passes, const float plane[4],
                        uint32_t stream_state[4], float *image_out, int32_t *count_out, uint32_t *states_out, MgpuStats *stats);
 
+/* What the last mgpu_render_stream call's resolution of the reference's random stream took (wall ms, all passes of the call, from
+ * the first kernel to the verdict of its verification), whether it had to classify the camera's pixels first (a camera's classes
+ * are cached with the scene), how many resolutions of this scene had to be repeated because a pixel classified "certain" was
+ * not, and how many pixels of a pass are uncertain (silhouette pixels of mesh + plane against the sky). */
+int mgpu_debug_stream_classes(MgpuScene *scene, unsigned char *out, size_t npix); /* diagnostic: the cached classes, 0 / 1 / 2 per pixel */
+int mgpu_stream_stats(MgpuScene *scene, double *resolve_ms, int *classified, unsigned long long *retries, uint32_t *uncertain_pixels);
 /* Render() with its `step` argument (render.cc:657-696): step == 1 is mgpu_render with passes = 1 on the whole frame.
  * step > 1 traces one path per step x step block -- the path of the block's top-left pixel (its jitter, its RNG start
  * state: TABLE index / HASH pixel id are those of that pixel in the W x H frame) -- and fills the block with its radiance;

@@ -94,6 +94,7 @@ struct MgpuScene {
   int tree_depth = 0;  // deepest node level (root = 0)
   bool boxes_ordered = false; // bmin <= bmax in every reachable node (lets the kernels take the min/max slab test)
   int precision = MGPU_PRECISION_FP64; // mgpu_scene_set_precision: which render kernel family the render entry points use
+  StreamScratch stream; // MGPU_RNG_STREAM: scratch of the chip-wide resolution, and the cached classification of a camera's pixels
   int stack_need = 1;  // entries a traversal can ever hold = tree_depth + 1
   int cap = 16;        // LDS stack entries per lane of the instantiated kernels
   double bmin[3], bmax[3];
@@ -105,6 +106,9 @@ struct MgpuScene {
        *p_woverflow = nullptr, *p_treelet = nullptr;
   size_t overflow_lanes = 0, woverflow_lanes = 0;
   uint32_t *p_counters = nullptr;         // kCounterRing work counters
+  double stream_last_ms = 0.0;           // wall time of the last chip-wide resolution (all passes of the call)
+  bool stream_last_fresh = false;        // ... and whether it had to classify the camera's pixels first
+  unsigned long long stream_retries = 0; // MGPU_RNG_STREAM: attempts the chip-wide resolution had to repeat (a certain pixel that was not)
   unsigned long long *p_stats = nullptr;  // kStatWords
   unsigned launch_seq = 0;
   size_t device_bytes = 0;
@@ -923,6 +927,12 @@ int mgpu_scene_destroy(MgpuScene *s) {
     if (p) (void)hipFree(p);
   if (s->p_trace_pinned) (void)hipHostFree(s->p_trace_pinned);
   if (s->p_trace_zc) (void)hipHostFree(s->p_trace_zc);
+  {
+    StreamScratch &X = s->stream;
+    void *sp[] = {X.cls, X.C, X.J, X.U, X.base, X.block_sum, X.F, X.uflag, X.Sarr, X.USx, X.totals, X.bad};
+    for (void *p : sp)
+      if (p) (void)hipFree(p);
+  }
   for (RenderSlot &r : s->slot) {
     void *rp[] = {r.p_planes, r.p_tile_cost, r.p_tile_order, r.p_overflow, r.p_woverflow};
     for (void *p : rp)
@@ -1622,6 +1632,59 @@ int mgpu_render(MgpuScene *s, const double origin[3], const double corner[3], co
 #undef TRY_R
 }
 
+// Scratch of the chip-wide stream resolution for a W x H frame (grow-only), and whether the classification cached in it belongs
+// to another camera (then the caller's first kernel classifies again).
+static void stream_scratch_free(MgpuScene *s) {
+  StreamScratch &X = s->stream;
+  void *ptrs[] = {X.cls, X.C, X.J, X.U, X.base, X.block_sum, X.F, X.uflag, X.Sarr, X.USx, X.totals, X.bad};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  X = StreamScratch();
+}
+static int stream_scratch_for(MgpuScene *s, const StreamParams &P, bool *fresh) {
+  StreamScratch &X = s->stream;
+  const size_t npix = (size_t)P.W * (size_t)P.H;
+  if (npix > X.npix_cap) {
+    stream_scratch_free(s);
+    const size_t sarr = stream_scratch_sarr_cap(npix);
+#define SALLOC(field, bytes)                                                                     \
+  do {                                                                                           \
+    hipError_t e_ = hipMalloc((void **)&X.field, (bytes));                                       \
+    if (e_ != hipSuccess) {                                                                      \
+      (void)hipGetLastError();                                                                   \
+      stream_scratch_free(s);                                                                    \
+      return fail(MGPU_ERR_OOM, "hipMalloc(%zu) for the stream resolution failed", (size_t)(bytes)); \
+    }                                                                                            \
+  } while (0)
+    SALLOC(cls, npix);
+    SALLOC(C, 4 * npix);
+    SALLOC(J, 4 * npix);
+    SALLOC(U, 4 * npix);
+    SALLOC(base, 16 * npix);
+    SALLOC(block_sum, 8 * (npix / 1024 + 2));
+    SALLOC(F, stream_scratch_f_bytes());
+    SALLOC(uflag, npix);
+    SALLOC(Sarr, 4 * sarr);
+    SALLOC(USx, 4 * (npix + 1));
+    SALLOC(totals, 8);
+    SALLOC(bad, 8);
+#undef SALLOC
+    X.npix_cap = npix;
+    X.sarr_cap = sarr;
+  }
+  const bool same = X.key_has_plane == P.has_plane && X.key_W == P.W && X.key_H == P.H && memcmp(X.key_frame, P.frame, sizeof(P.frame)) == 0 &&
+                    memcmp(X.key_plane, P.plane, sizeof(P.plane)) == 0;
+  *fresh = !same;
+  if (!same) {
+    memcpy(X.key_frame, P.frame, sizeof(P.frame));
+    memcpy(X.key_plane, P.plane, sizeof(P.plane));
+    X.key_has_plane = P.has_plane;
+    X.key_W = P.W;
+    X.key_H = P.H;
+  }
+  return MGPU_OK;
+}
+
 int mgpu_render_stream(MgpuScene *s, const double origin[3], const double corner[3], const double du[3], const double dv[3],
                        int W, int H, int maxPathLength, int passes, const float plane[4], uint32_t stream_state[4],
                        float *image_out, int32_t *count_out, uint32_t *states_out, MgpuStats *stats) {
@@ -1696,8 +1759,30 @@ int mgpu_render_stream(MgpuScene *s, const double origin[3], const double corner
     P.jump = d_jump;
     P.state = d_state;
     P.table = d_table;
-    TRY_S(launch_stream_states(s->cap, 0, s->d, P));
-    TRY_S(hipMemcpy(next_state, d_state, 16, hipMemcpyDeviceToHost)); // waits for the kernel
+    const char *serial = getenv("MGPU_STREAM_SERIAL");
+    if (serial && atoi(serial) != 0) { // round-3 kernel: one workgroup walks the chain (kept for A/B and as the tests' second opinion)
+      TRY_S(launch_stream_states(s->cap, 0, s->d, P));
+    } else {
+      bool fresh = false;
+      rc = stream_scratch_for(s, P, &fresh);
+      if (!rc) rc = ensure_overflow(s, (size_t)s->num_cu * 4 * 256);
+      if (rc) {
+        cleanup();
+        return rc;
+      }
+      uint32_t retries = 0;
+      const double tr0 = now_ms();
+      hipError_t e = stream_states_resolve(s->cap, 0, s->d, P, s->stream, s->num_cu, fresh, &retries);
+      s->stream_last_ms = now_ms() - tr0; // the resolution ends with a synchronisation (it reads the verification's verdict)
+      s->stream_last_fresh = fresh;
+      if (e != hipSuccess) {
+        s->stream.key_has_plane = -1; // whatever is cached may be half-updated
+        cleanup();
+        return fail(MGPU_ERR_HIP, "stream_states_resolve failed: %s", hipGetErrorString(e));
+      }
+      s->stream_retries += retries;
+    }
+    TRY_S(hipMemcpy(next_state, d_state, 16, hipMemcpyDeviceToHost)); // waits for the kernels
   }
   // the frame itself: the ordinary renderer from that table, which stays on the device
   {
@@ -1740,6 +1825,31 @@ int mgpu_render_stream(MgpuScene *s, const double origin[3], const double corner
   if (stats) stats->total_ms = now_ms() - t0;
   return MGPU_OK;
 #undef TRY_S
+}
+
+int mgpu_debug_stream_classes(MgpuScene *s, unsigned char *out, size_t npix) { // diagnostic: the cached classification (0 / 1 / 2)
+  if (!s || !out) return fail(MGPU_ERR_INVALID, "NULL argument");
+  if (!s->stream.cls || npix > s->stream.npix_cap) return fail(MGPU_ERR_INVALID, "no classification of that size is cached");
+  int rc = set_device(s);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(out, s->stream.cls, npix, hipMemcpyDeviceToHost));
+  return MGPU_OK;
+}
+
+int mgpu_stream_stats(MgpuScene *s, double *resolve_ms, int *classified, unsigned long long *retries, uint32_t *uncertain_pixels) {
+  if (!s) return fail(MGPU_ERR_INVALID, "scene is NULL");
+  if (resolve_ms) *resolve_ms = s->stream_last_ms;
+  if (classified) *classified = s->stream_last_fresh ? 1 : 0;
+  if (retries) *retries = s->stream_retries;
+  if (uncertain_pixels) {
+    *uncertain_pixels = 0;
+    if (s->stream.totals) {
+      int rc = set_device(s);
+      if (rc) return rc;
+      HIP_TRY(hipMemcpy(uncertain_pixels, s->stream.totals, 4, hipMemcpyDeviceToHost));
+    }
+  }
+  return MGPU_OK;
 }
 
 int mgpu_render_step(MgpuScene *s, const double origin[3], const double corner[3], const double du[3], const double dv[3],

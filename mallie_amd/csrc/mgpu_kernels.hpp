@@ -136,7 +136,8 @@ struct AovParams {
 void launch_render_aov(int cap, dim3 grid, hipStream_t s, const DScene &sc, const AovParams &p);
 // k_stream_states (mgpu_stream.hip): MGPU_RNG_STREAM -- the start state of every (pass, pixel) in the reference's own
 // serial stream, written to an MGPU_RNG_TABLE table; `state` (device, 4 words) is the stream state, in and out
-constexpr int kStreamJumpBits = 18;      // window offsets < 2^18: maxPathLength <= kStreamMaxPathLength
+constexpr int kStreamJumpBits = 44;      // T^(2^j), j < 44: a pass of 2^32 pixels at maxPathLength 341 draws < 2^43 numbers
+constexpr int kStreamSerialJumpBits = 18; // the one-workgroup kernel: window offsets < 2^18 <=> maxPathLength <= kStreamMaxPathLength
 constexpr int kStreamMaxPathLength = 341; // 256 * (2 + 3 * 340) < 2^18
 struct StreamParams {
   double frame[12];
@@ -149,6 +150,26 @@ struct StreamParams {
   uint32_t *table;   // device: passes * W * H * 4 words
 };
 hipError_t launch_stream_states(int cap, hipStream_t s, const DScene &sc, const StreamParams &p);
+// the chip-wide resolution of the same table (mgpu_stream.hip): scratch kept with the scene, the classification of a camera's
+// pixels cached in it from call to call
+struct StreamScratch {
+  unsigned char *cls = nullptr;        // [npix] 0 / 1 / 2
+  uint32_t *C = nullptr, *J = nullptr; // [npix] certain hits / uncertain pixels before a pixel
+  uint32_t *U = nullptr;               // [npix] the uncertain pixels, in order
+  uint4 *base = nullptr;               // [npix]
+  unsigned long long *block_sum = nullptr; // [npix / 1024 + 1]
+  unsigned char *F = nullptr, *uflag = nullptr;
+  uint32_t *Sarr = nullptr, *USx = nullptr, *totals = nullptr, *bad = nullptr;
+  size_t npix_cap = 0, sarr_cap = 0;
+  // what the cached classification belongs to
+  double key_frame[12];
+  float key_plane[4];
+  int key_has_plane = -1, key_W = 0, key_H = 0;
+};
+size_t stream_scratch_sarr_cap(size_t npix);
+size_t stream_scratch_f_bytes();
+hipError_t stream_states_resolve(int cap, hipStream_t st, const DScene &sc, const StreamParams &p, StreamScratch &scratch, int num_cu, bool fresh_camera,
+                                 uint32_t *retries_out);
 void stream_jump_matrices(uint32_t *out /* kStreamJumpBits * 128 * 4 words */);
 // k_trace_sm (mgpu_trace_sm.hip): persistent, wave-scheduled batched trace; `counter` = one zeroed device word
 hipError_t launch_trace_sm(dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, uint32_t n,

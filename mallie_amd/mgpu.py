@@ -109,6 +109,8 @@ def load_library():
     L.mgpu_render_step.restype = i32
     L.mgpu_render_stream.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     L.mgpu_render_stream.restype = i32
+    L.mgpu_stream_stats.argtypes = [vp, vp, vp, vp, vp]
+    L.mgpu_stream_stats.restype = i32
     L.mgpu_render_aov.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, u64, u32, vp, vp, vp]
     L.mgpu_render_aov.restype = i32
     L.mgpu_frame_create.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.POINTER(vp)]
@@ -543,6 +545,19 @@ class Scene:
                                                  maxPathLength, passes, _p(_c(plane, "<f4")), _p(state), _p(image), _p(count),
                                                  _p(states), C.byref(st)), "mgpu_render_stream")
         return image, count, st.as_dict(), state, states
+
+    def stream_classes(self, W, H):
+        out = np.zeros((H, W), "u1")
+        L = load_library()
+        L.mgpu_debug_stream_classes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        _check(L.mgpu_debug_stream_classes(self.h, _p(out), W * H), "mgpu_debug_stream_classes")
+        return out
+
+    def stream_stats(self):
+        """mgpu_stream_stats: the last render_stream call's resolution of the reference's random stream."""
+        ms, cl, rt, un = C.c_double(), C.c_int(), C.c_uint64(), C.c_uint32()
+        _check(load_library().mgpu_stream_stats(self.h, C.byref(ms), C.byref(cl), C.byref(rt), C.byref(un)), "mgpu_stream_stats")
+        return {"resolve_ms": ms.value, "classified": bool(cl.value), "retries": rt.value, "uncertain_pixels": un.value}
 
     def render_aov(self, frame, W, H, kind, rng_mode=RNG_HASH, rng_states=None, seed=1, pass_base=0):
         """mgpu_render_aov: ShowNormal (kind 0) / ShowUV (kind 1) of the whole frame -> (image, stats)."""

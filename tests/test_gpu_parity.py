@@ -536,6 +536,36 @@ def test_render_in_the_reference_stream_without_a_table(name):
         assert a.tobytes() == r["images"][0].tobytes() and b.tobytes() == r["images"][1].tobytes() and np.array_equal(s2, state)
 
 
+@pytest.mark.parametrize("mesh,eye,lookat,W,H,mpl,passes", [
+    ("cornell_obj", (0, 0, 20), (0, 0, 0), 640, 360, 5, 3),
+    ("teapot_obj", (0, 40, 250), (0, 40, 0), 480, 270, 9, 2),
+    ("cornell_obj", (3, 4, 14), (0, 2, 0), 333, 217, 1, 2),   # maxPathLength 1: no draws beyond the jitter, the chain is trivial
+    ("cornell_obj", (0, 0, 20), (0, 0, 0), 131, 97, 200, 1)])  # long paths: 599 draws per hit
+def test_stream_chain_resolved_across_the_chip_equals_the_serial_walk(mesh, eye, lookat, W, H, mpl, passes, monkeypatch):
+    """MGPU_RNG_STREAM's table of start states from the chip-wide resolution (classification, rounds of 128 uncertain pixels with every
+    possible hit count traced at once, verification of every pixel: mgpu_stream.hip) against the round-3 kernel that walks the chain
+    with one workgroup (MGPU_STREAM_SERIAL=1, itself pinned to the reference's goldens above): states of every (pass, pixel), the
+    stream state left behind and the images, word for word -- on frames large enough for thousands of silhouette pixels, for a
+    second call that continues the stream from the cached classification, and for another camera on the same scene."""
+    sc = gpu_scene(mesh)
+    frame = M.camera_frame(eye, lookat, width=W, height=H)
+    plane = sc.plane() if mesh != "teapot_obj" else None
+    monkeypatch.setenv("MGPU_STREAM_SERIAL", "1")
+    img0, _, st0, state0, states0 = sc.render_stream(frame, W, H, mpl, passes, plane, want_states=True)
+    img0b, _, _, state0b, states0b = sc.render_stream(frame, W, H, mpl, 1, plane, stream_state=state0, want_states=True)
+    monkeypatch.delenv("MGPU_STREAM_SERIAL")
+    img1, _, st1, state1, states1 = sc.render_stream(frame, W, H, mpl, passes, plane, want_states=True)
+    assert np.array_equal(states1, states0) and np.array_equal(state1, state0) and img1.tobytes() == img0.tobytes()
+    assert (st1["real_rays"], st1["trace_calls"]) == (st0["real_rays"], st0["trace_calls"])
+    img1b, _, _, state1b, states1b = sc.render_stream(frame, W, H, mpl, 1, plane, stream_state=state1, want_states=True)  # cached classes
+    assert np.array_equal(states1b, states0b) and np.array_equal(state1b, state0b) and img1b.tobytes() == img0b.tobytes()
+    frame2 = M.camera_frame((eye[0] + 1.5, eye[1] + 0.7, eye[2]), lookat, width=W, height=H)                              # another camera
+    a = sc.render_stream(frame2, W, H, mpl, 1, plane, want_states=True)
+    monkeypatch.setenv("MGPU_STREAM_SERIAL", "1")
+    b = sc.render_stream(frame2, W, H, mpl, 1, plane, want_states=True)
+    assert np.array_equal(a[4], b[4]) and np.array_equal(a[3], b[3]) and a[0].tobytes() == b[0].tobytes()
+
+
 def test_reference_default_config_from_its_seed_alone():
     """The reference's default configuration (config.json: cornellbox_suzanne, 512x512, one pass, plane on, 16 segments) in
     its own stream on the GPU: the digest of the reference's frame (tests/golden/render_cornell_obj_512_plane_digest.npz)."""
