@@ -1206,20 +1206,18 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
   const int se_bytes = lds_stack_entry_bytes(s->nn); // LDS-resident scene: node indices of 1 or 2 bytes, depth + 1 per lane
   if (kern == 2 && se_bytes > 2) kern = 1;
   int block = kern == 2 ? 1024 : kBlock;
-  if (kern == 2 && getenv("MGPU_RENDER_BLOCK") && atoi(getenv("MGPU_RENDER_BLOCK")) == 512) block = 512; // experiments
   size_t shmem = (size_t)(block / 64) * s->cap * 64 * sizeof(uint32_t);
+  bool prim = false; // LDS-resident scene: the items' primary rays staged in LDS when 40 KB more fit (k_render_sm, PRIM)
   if (kern == 2) {
     shmem = lds_stack_bytes((size_t)(block / 64), (size_t)s->stack_need, (size_t)se_bytes);
-    if (shmem + scene_lds > kLdsBudget) {
-      block = 512;
-      shmem = lds_stack_bytes((size_t)(block / 64), (size_t)s->stack_need, (size_t)se_bytes);
-    }
     if (shmem + scene_lds > kLdsBudget) {
       kern = 1;
       block = kBlock;
       shmem = (size_t)(block / 64) * s->cap * 64 * sizeof(uint32_t);
     } else {
       shmem += scene_lds;
+      prim = render_sm_prim_bytes() != 0 && shmem + render_sm_prim_bytes() <= kLdsBudget && !getenv("MGPU_NO_PRIM");
+      if (prim) shmem += render_sm_prim_bytes();
     }
   }
   // BVH in HBM: the wide traversal's far-child stacks, and -- one 1024-thread workgroup per CU instead of four of 256 -- the
@@ -1452,7 +1450,7 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
     } else if (kern == 3) {
       HIP_TRY(launch_render_f32(s->cap, f32_lds, dim3((unsigned)blocks), st, shmem, fsc, P));
     } else {
-      HIP_TRY(launch_render_sm(se_bytes, kern == 2, block, dim3((unsigned)blocks), st, shmem, dsc, P));
+      HIP_TRY(launch_render_sm(se_bytes, kern == 2, prim, block, dim3((unsigned)blocks), st, shmem, dsc, P));
     }
     return MGPU_OK;
   };

@@ -92,8 +92,9 @@ void launch_trace_probe(hipStream_t s, const MgpuRay *rays, size_t n, uint32_t *
 void launch_render(int cap, dim3 grid, hipStream_t s, const DScene &sc, const RenderParams &p);
 int pick_stack_cap(int needed_entries);
 // wave-scheduled state-machine renderer (mgpu_render_sm.hip); shmem = stacks (+ scene when lds_scene)
-hipError_t launch_render_sm(int stack_entry_bytes, bool lds_scene, int block, dim3 grid, hipStream_t s, size_t shmem, const DScene &sc,
+hipError_t launch_render_sm(int stack_entry_bytes, bool lds_scene, bool prim, int block, dim3 grid, hipStream_t s, size_t shmem, const DScene &sc,
                             const RenderParams &p);
+size_t render_sm_prim_bytes(); // LDS the LDS-resident variant wants behind the scene for its primary-ray staging (0: compiled out)
 // LDS-resident scene: a stack entry is a node index -- 1 byte up to 256 nodes, 2 up to 65 536 (larger trees never fit) --
 // and a lane needs tree depth + 1 of them (bvh_accel.cc:805-834: a pop, then at most two pushes per level)
 inline int lds_stack_entry_bytes(size_t nn) { return nn <= 256 ? 1 : (nn <= 65536 ? 2 : 4); }

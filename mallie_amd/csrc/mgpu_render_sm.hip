@@ -55,6 +55,10 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 #define MGPU_START_MIN_LDS 12
 #define MGPU_START_FORCE_LDS 16
 #endif
+#ifndef MGPU_START_MIN_PRIM // with the primary rays staged in LDS a path start is a copy: 8 / 12 (5.38 ms) against 12 / 16 (5.44), 4 / 8 (5.42), 1 / 4 (5.38 .. 5.45)
+#define MGPU_START_MIN_PRIM 8
+#define MGPU_START_FORCE_PRIM 12
+#endif
 #ifndef MGPU_START_MIN_HBM
 #define MGPU_START_MIN_HBM 8
 #define MGPU_START_FORCE_HBM 12
@@ -109,6 +113,9 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 #ifndef MGPU_ROOT_AT_ARM
 #define MGPU_ROOT_AT_ARM 0 // experiment (profiles/experiments/README.md, round 4: measured, not kept); LDS-resident scene: the root box test where the ray is armed (see there)
 #endif
+#ifndef MGPU_PRIM_LDS
+#define MGPU_PRIM_LDS 1 // LDS-resident scene: the 64 primary rays of a work item generated by the whole wave when the item is taken (40 KB)
+#endif
 #ifndef MGPU_SHARED_LEAVES
 #define MGPU_SHARED_LEAVES 1
 #endif
@@ -130,7 +137,8 @@ template <typename SE> struct LStack {
   __device__ __forceinline__ uint32_t get(int i) const { return (uint32_t)lds[i * 64]; }
 };
 
-template <typename SE, bool LDS_SCENE, int BLOCK, bool GREY>
+// PRIM (LDS-resident scene with 40 KB of LDS to spare): see s_prim below.
+template <typename SE, bool LDS_SCENE, int BLOCK, bool GREY, bool PRIM = false>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGPU_SM_MIN_WAVES))) void k_render_sm(DScene sc, RenderParams P_arg) {
   // The launch parameters live in LDS, not in scalar registers: the traversal bodies use none of them, SHADE uses
   // nearly all, and ~60 kernel-argument SGPRs kept alive across the loop were being spilled to VGPR lanes.
@@ -182,6 +190,16 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
     __syncthreads();
   }
 
+  // PRIM: a (tile, pass) item's 64 primary rays -- start state, jitter, camera direction -- are made by ALL lanes of the wave at the
+  // moment the item is taken and parked in LDS (40 bytes each); a lane that is handed a path copies its ray from there.  The
+  // path-start body (~170 instructions: two splitmix64, two draws, a normalisation) then runs once per 64 paths with 64 lanes
+  // instead of in two SHADE steps out of three with whoever asks.
+  static_assert(!PRIM || LDS_SCENE, "primary-ray staging exists for the LDS-resident scene only");
+  struct PrimRay {
+    double d[3];
+    uint32_t s[4];
+  };
+  PrimRay *s_prim = reinterpret_cast<PrimRay *>(const_cast<unsigned char *>(lds_tris) + (((size_t)P.lds_tris_bytes + 15) & ~(size_t)15)) + (size_t)wave * 64;
   const int win_w = P.x1 - P.x0;
   const uint32_t tiles_x = (uint32_t)(win_w + 7) >> 3;
   const uint32_t tiles_y = (uint32_t)(P.n_rows + 7) >> 3;
@@ -304,7 +322,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
     // MGPU_SHADE_MIN lanes have a ray to finish, or MGPU_START_FORCE lanes are parked between paths, or nothing else is
     // runnable; otherwise NODE runs unless TRI has several times more lanes waiting (MGPU_NODE_WEIGHT_*).
     const int cReal = __popcll(__ballot(st == ST_SHADE && have_ray)); // lanes with a ray to finish (not parked between paths)
-    const bool run_shade = (cReal >= MGPU_SHADE_MIN) || (cN == 0 && cT == 0) || (cS - cReal >= (LDS_SCENE ? MGPU_START_FORCE_LDS : MGPU_START_FORCE_HBM));
+    const bool run_shade = (cReal >= MGPU_SHADE_MIN) || (cN == 0 && cT == 0) || (cS - cReal >= (PRIM ? MGPU_START_FORCE_PRIM : (LDS_SCENE ? MGPU_START_FORCE_LDS : MGPU_START_FORCE_HBM)));
     if (!run_shade && cN * (LDS_SCENE ? MGPU_NODE_WEIGHT_LDS : MGPU_NODE_WEIGHT_HBM) >= cT * (LDS_SCENE ? MGPU_TRI_WEIGHT_LDS : MGPU_TRI_WEIGHT_HBM)) {
       // ================================ NODE step ================================
       MGPU_TICK();
@@ -668,7 +686,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
       // ---- (2) path hand-out, executed by the whole wave (cursor variables are wave-uniform) ----
       // deferred start: with few lanes asking for a new path while others still traverse, the lanes stay parked (state
       // SHADE, no ray) and the path-start body runs later for more of them at once
-      const bool defer = !exhausted && (cN + cT) > 0 && __popcll(__ballot(want_pixel)) < (LDS_SCENE ? MGPU_START_MIN_LDS : MGPU_START_MIN_HBM);
+      const bool defer = !exhausted && (cN + cT) > 0 && __popcll(__ballot(want_pixel)) < (PRIM ? MGPU_START_MIN_PRIM : (LDS_SCENE ? MGPU_START_MIN_LDS : MGPU_START_MIN_HBM));
       for (;;) {
         const unsigned long long want = __ballot(want_pixel);
         if (!want || exhausted || defer) break;
@@ -736,6 +754,32 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
           const uint32_t ti = item / (uint32_t)P.passes;
           item_pass = item - ti * (uint32_t)P.passes;
           item_tile = P.tile_order ? (uint32_t)__builtin_amdgcn_readfirstlane((int)P.tile_order[ti]) : ti;
+          if constexpr (PRIM) { // the new item's primary rays, one per lane (every slot of the previous item has been copied out)
+            const uint32_t tx = item_tile % tiles_x, ty = item_tile / tiles_x;
+            const uint32_t x = tx * 8 + ((uint32_t)lane & 7u), y = ty * 8 + ((uint32_t)lane >> 3);
+            if (x < (uint32_t)win_w && y < (uint32_t)P.n_rows) {
+              const int gy = (P.y_first + (int)(y / (uint32_t)P.strip_h) * P.y_period + (int)(y % (uint32_t)P.strip_h)) * P.pix_step;
+              const int gx = (P.x0 + (int)x) * P.pix_step;
+              const uint32_t gpix = (uint32_t)gy * (uint32_t)P.W + (uint32_t)gx;
+              uint32_t s4[4];
+              if (P.rng_mode == MGPU_RNG_TABLE) {
+                const uint4 q = reinterpret_cast<const uint4 *>(P.rng_states)[(size_t)item_pass * P.W * P.H + gpix];
+                s4[0] = q.x; s4[1] = q.y; s4[2] = q.z; s4[3] = q.w;
+              } else {
+                hash_state(P.seed, P.pass_base + item_pass, gpix, s4);
+              }
+              Rng r{s4[0], s4[1], s4[2], s4[3]};
+              const float ju = (float)(rng_next(r) - 0.5);
+              const float jv = (float)(rng_next(r) - 0.5);
+              const V3 d = camera_dir(P.frame, (double)((float)gx + ju), (double)((float)gy + jv));
+              PrimRay &pr = s_prim[lane];
+              pr.d[0] = d.x; pr.d[1] = d.y; pr.d[2] = d.z;
+              pr.s[0] = r.x; pr.s[1] = r.y; pr.s[2] = r.z; pr.s[3] = r.w;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          }
         }
         if (want_pixel) {
           const uint32_t rank = __popcll(want & ((1ull << lane) - 1ull));
@@ -748,6 +792,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
               pass = (int)item_pass;
               have_path = true;
               want_pixel = false;
+              if constexpr (PRIM) { // this lane's path has ended: its ray registers are free
+                const PrimRay &pr = s_prim[slot];
+                dir = v3(pr.d[0], pr.d[1], pr.d[2]);
+                rng = Rng{pr.s[0], pr.s[1], pr.s[2], pr.s[3]};
+              }
             }
           }
         }
@@ -763,6 +812,14 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
           if (lane == __ffsll((long long)__ballot(1)) - 1) u_start_steps++;
 #endif
           // start a new eye path (PathTrace prologue, render.cc:387-400)
+          if constexpr (PRIM) {
+            if (P.probe) {
+              const int gy = (P.y_first + (int)(ly / (uint32_t)P.strip_h) * P.y_period + (int)(ly % (uint32_t)P.strip_h)) * P.pix_step;
+              const uint32_t gpix = (uint32_t)gy * (uint32_t)P.W + (uint32_t)((P.x0 + (int)lx) * P.pix_step);
+              probe_on = gpix == P.probe_pixel && (uint32_t)pass == P.probe_pass;
+            }
+            org = v3(P.frame[0], P.frame[1], P.frame[2]);
+          } else {
           const uint32_t j = ly;
           // pix_step > 1: Render(step): the window is in units of step x step blocks and a block's path is that of its
           // top-left pixel (render.cc:657-681)
@@ -786,6 +843,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
           const float jv = (float)(rng_next(rng) - 0.5);
           org = v3(P.frame[0], P.frame[1], P.frame[2]);
           dir = camera_dir(P.frame, (double)((float)gx + ju), (double)((float)gy + jv));
+          }
           thr0 = 1.0;
           if (!GREY) thr1 = thr2 = 1.0;
           pathLength = 1;
@@ -1132,9 +1190,9 @@ void launch_tonemap(hipStream_t s, const float *image, const int32_t *count, siz
 // =====================================================================================================================
 // launcher
 // =====================================================================================================================
-template <typename SE, bool LDS, int BLOCK, bool GREY>
+template <typename SE, bool LDS, int BLOCK, bool GREY, bool PRIM>
 static hipError_t launch_grey(dim3 grid, hipStream_t s, size_t shmem, const DScene &sc, const RenderParams &p) {
-  auto kern = k_render_sm<SE, LDS, BLOCK, GREY>;
+  auto kern = k_render_sm<SE, LDS, BLOCK, GREY, PRIM>;
   // per device: dynamic-LDS size already granted to this instantiation.  Scenes on different devices are driven from
   // different host threads (and the multi-GPU frame drives several from one): the table is guarded.
   static size_t granted[16] = {0};
@@ -1154,20 +1212,22 @@ static hipError_t launch_grey(dim3 grid, hipStream_t s, size_t shmem, const DSce
   return hipGetLastError();
 }
 
-template <typename SE, bool LDS, int BLOCK>
+template <typename SE, bool LDS, int BLOCK, bool PRIM = false>
 static hipError_t launch_one(dim3 grid, hipStream_t s, size_t shmem, const DScene &sc, const RenderParams &p) {
-  return sc.grey ? launch_grey<SE, LDS, BLOCK, true>(grid, s, shmem, sc, p) : launch_grey<SE, LDS, BLOCK, false>(grid, s, shmem, sc, p);
+  return sc.grey ? launch_grey<SE, LDS, BLOCK, true, PRIM>(grid, s, shmem, sc, p) : launch_grey<SE, LDS, BLOCK, false, PRIM>(grid, s, shmem, sc, p);
 }
 
-// Instantiations: LDS-resident scene (stack entries of 1 or 2 bytes, see lds_stack_entry_bytes) with 1024- or 512-thread
-// workgroups; HBM-resident scene (wide form, its own stacks) with 256-thread workgroups or one 1024-thread workgroup + treelet.
-hipError_t launch_render_sm(int stack_entry_bytes, bool lds_scene, int block, dim3 grid, hipStream_t s, size_t shmem, const DScene &sc,
+// LDS the LDS-resident variant wants behind the scene for a wave's 64 staged primary rays (40 bytes each), 16 waves
+size_t render_sm_prim_bytes() { return MGPU_PRIM_LDS ? (size_t)16 * 64 * 40 : 0; }
+
+// Instantiations: LDS-resident scene (one 1024-thread workgroup per CU; stack entries of 1 or 2 bytes, see lds_stack_entry_bytes;
+// with or without the primary-ray staging); HBM-resident scene (wide form, its own stacks) with 256-thread workgroups or one
+// 1024-thread workgroup + treelet.
+hipError_t launch_render_sm(int stack_entry_bytes, bool lds_scene, bool prim, int block, dim3 grid, hipStream_t s, size_t shmem, const DScene &sc,
                             const RenderParams &p) {
-  if (lds_scene) {
-    if (stack_entry_bytes == 1 && block == 1024) return launch_one<uint8_t, true, 1024>(grid, s, shmem, sc, p);
-    if (stack_entry_bytes == 1 && block == 512) return launch_one<uint8_t, true, 512>(grid, s, shmem, sc, p);
-    if (stack_entry_bytes == 2 && block == 1024) return launch_one<uint16_t, true, 1024>(grid, s, shmem, sc, p);
-    if (stack_entry_bytes == 2 && block == 512) return launch_one<uint16_t, true, 512>(grid, s, shmem, sc, p);
+  if (lds_scene && block == 1024) {
+    if (stack_entry_bytes == 1) return prim ? launch_one<uint8_t, true, 1024, true>(grid, s, shmem, sc, p) : launch_one<uint8_t, true, 1024>(grid, s, shmem, sc, p);
+    if (stack_entry_bytes == 2) return prim ? launch_one<uint16_t, true, 1024, true>(grid, s, shmem, sc, p) : launch_one<uint16_t, true, 1024>(grid, s, shmem, sc, p);
   }
   if (!lds_scene && block == 256) return launch_one<uint32_t, false, 256>(grid, s, shmem, sc, p); // wide form: one variant
   if (!lds_scene && block == 1024 && sc.treelet) return launch_one<uint32_t, false, 1024>(grid, s, shmem, sc, p); // ... + treelet in LDS
