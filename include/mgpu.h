@@ -314,6 +314,8 @@ typedef struct {
   uint64_t exchange_frames;        /* frames whose exchange step was timed                    */
   uint64_t exchange_ops_per_frame; /* receives rank 0 posts per frame                         */
   double exchange_ms;              /* summed over exchange_frames                             */
+  uint64_t enqueue_calls;          /* render calls (mgpu_frame_render / _render_batch) since the last reset               */
+  double enqueue_ms;               /* host time those calls spent enqueueing (launches, events, the exchange) for ALL members */
 } MgpuFrameStats;
 int mgpu_frame_stats(MgpuFrame *frame, MgpuFrameStats *out, int reset);
 /* Makes `stream` (a hipStream_t on rank 0's device) wait for the slot's frame without blocking the host. */

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -148,6 +149,9 @@ struct MgpuFrame {
   // exchange timing (rank 0's communicator stream): summed when a slot is waited for or reused
   double x_ms_sum = 0.0;
   unsigned long long x_frames = 0, x_ops = 0; // frames measured; receives rank 0 posts per frame
+  // host time of the render calls: ONE thread enqueues launches, events and the exchange for every member of this process
+  double enq_ms_sum = 0.0;
+  unsigned long long enq_calls = 0;
   // SURVEY 8(d)'s frame ends with ONE read-back.  With `readback` on, every frame's copy to pinned host memory is enqueued
   // behind its exchange on a stream of its own, so it runs under the NEXT frame's kernel (frames_in_flight >= 2); the slot is
   // not rendered into again before the copy has left it.  mgpu_frame_wait_host hands the pinned buffer out.
@@ -486,6 +490,18 @@ static int render_frames_enqueue(MgpuFrame *f, const double cam[12], int maxPath
   const int W = f->W, H = f->H, sh = f->strip_h, world = f->world;
   const bool exchange = world > 1 || f->force_exchange;
   const bool block = f->exchange_mode == MGPU_EXCHANGE_BLOCK;
+  static const bool prof = getenv("MGPU_FRAME_PROFILE") != nullptr;
+  static double ph[4] = {0, 0, 0, 0};
+  static unsigned long long ph_n = 0;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tp = prof ? now() : 0.0;
+  auto lap = [&](int k) {
+    if (prof) {
+      const double t = now();
+      ph[k] += t - tp;
+      tp = t;
+    }
+  };
   for (Member &m : f->members) {
     FHIP(hipSetDevice(m.device));
     hipStream_t rs = render_stream(f, m, ks[0]); // the launch and the copies of the whole batch
@@ -495,6 +511,7 @@ static int render_frames_enqueue(MgpuFrame *f, const double cam[12], int maxPath
       if (m.slot[ks[i]].copy_pending) FHIP(hipStreamWaitEvent(rs, m.slot[ks[i]].copied, 0)); // ... and its read-back
       if (m.rank == 0) collect_timing(f, m.slot[ks[i]], false);
     }
+    lap(0);
     if (m.n_rows) {
       float *images[kMaxInFlight];
       for (int i = 0; i < n; ++i) images[i] = m.slot[ks[i]].local;
@@ -502,6 +519,7 @@ static int render_frames_enqueue(MgpuFrame *f, const double cam[12], int maxPath
                                          rng_mode, nullptr, seed, pass_base, n, images, nullptr, rs, nullptr);
       if (rc) return ffail(rc, "rank %d: %s", m.rank, mgpu_last_error());
     }
+    lap(1);
     for (int i = 0; i < n; ++i) {
       Slot &s = m.slot[ks[i]];
       if (m.rank == 0 && m.n_rows && !f->force_exchange) { // own strips to their final rows
@@ -511,6 +529,7 @@ static int render_frames_enqueue(MgpuFrame *f, const double cam[12], int maxPath
       FHIP(hipEventRecord(s.rendered, rs));
     }
     if (exchange) FHIP(hipStreamWaitEvent(m.comm_stream, m.slot[ks[n - 1]].rendered, 0));
+    lap(2);
   }
   Member *root = nullptr; // the member that holds rank 0 (copy transport: the one that moves everybody's bytes)
   for (Member &m : f->members)
@@ -630,6 +649,10 @@ static int render_frames_enqueue(MgpuFrame *f, const double cam[12], int maxPath
     }
     if (slots_out) slots_out[i] = k;
   }
+  lap(3);
+  if (prof && (++ph_n % 4) == 0)
+    fprintf(stderr, "mgpu_frame profile after %llu render calls: waits+setup %.3f, mgpu_render_frames_device %.3f, place+events %.3f, exchange %.3f ms per call\n", ph_n,
+            ph[0] / ph_n, ph[1] / ph_n, ph[2] / ph_n, ph[3] / ph_n);
   if (f->readback && root)
     for (int i = 0; i < n; ++i) root->slot[ks[i]].copy_wanted = true; // issued by mgpu_frame_wait_host, see there
   f->next += (unsigned long long)n;
@@ -645,7 +668,10 @@ static int render_frames(MgpuFrame *f, const double cam[12], int maxPathLength, 
   if (maxPathLength < 1 || passes < 1) return ffail(MGPU_ERR_INVALID, "maxPathLength and passes must be >= 1");
   if (rng_mode != MGPU_RNG_HASH)
     return ffail(MGPU_ERR_UNSUPPORTED, "multi-GPU frames are seeded per (pixel, pass) (MGPU_RNG_HASH): the image must not depend on the GPU count");
+  const auto t0 = std::chrono::steady_clock::now();
   const int rc = render_frames_enqueue(f, cam, maxPathLength, passes, plane, rng_mode, seed, pass_base, n, slots_out);
+  f->enq_ms_sum += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  f->enq_calls += 1;
   if (rc) f->broken = true;
   return rc;
 }
@@ -760,9 +786,13 @@ int mgpu_frame_stats(MgpuFrame *f, MgpuFrameStats *out, int reset) {
   out->exchange_frames = f->x_frames;
   out->exchange_ms = f->x_ms_sum;
   out->exchange_ops_per_frame = f->x_ops;
+  out->enqueue_calls = f->enq_calls;
+  out->enqueue_ms = f->enq_ms_sum;
   if (reset) {
     f->x_frames = 0;
     f->x_ms_sum = 0.0;
+    f->enq_calls = 0;
+    f->enq_ms_sum = 0.0;
   }
   return MGPU_OK;
 }

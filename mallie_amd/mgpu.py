@@ -38,7 +38,7 @@ class Stats(C.Structure):
 class FrameStats(C.Structure):
     _fields_ = [("world", C.c_int), ("members", C.c_int), ("rccl_ranks", C.c_int), ("exchange_mode", C.c_int),
                 ("frames", C.c_uint64), ("exchange_frames", C.c_uint64), ("exchange_ops_per_frame", C.c_uint64),
-                ("exchange_ms", C.c_double)]
+                ("exchange_ms", C.c_double), ("enqueue_calls", C.c_uint64), ("enqueue_ms", C.c_double)]
 
 
 _lib = None

@@ -1184,6 +1184,38 @@ def test_c_abi_frame_on_one_gpu(force, monkeypatch):
         M.Frame([sc], [1], W, H, strip_h=8, frames_in_flight=1)
 
 
+@pytest.mark.skipif(M.device_count() < 2, reason="needs two GPUs: RCCL between distinct devices")
+def test_rccl_frame_between_distinct_devices():
+    """The default N > 1 transport where there is hardware for it: every visible GPU renders its interleaved strips, ONE grouped
+    ncclSend / ncclRecv step per frame over xGMI brings them to rank 0 (both exchange modes), three frames in flight, a batch of
+    frames per launch, the read-back behind the exchange.  Frames must equal the oracle's byte for byte."""
+    n = min(M.device_count(), 8)
+    osc = O.scene_from_golden("cornell_obj")
+    g = O.load_golden("cornell_obj")
+    scenes = [M.Scene(g["verts"], g["faces"], g["matIDs"], g["normals"], None, device=d) for d in range(n)]
+    W, H, mpl, passes = 320, 203, 5, 2
+    cam = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    plane = scenes[0].plane()
+    refs = [osc.render(cam, W, H, mpl, passes, plane, O.RNG_HASH, seed=5, pass_base=k * passes)[0] for k in range(5)]
+    for mode in ("block", "strips"):
+        os.environ["MGPU_FRAME_EXCHANGE"] = mode
+        try:
+            fr = M.Frame(scenes, list(range(n)), W, H, strip_h=8, frames_in_flight=3)
+        finally:
+            del os.environ["MGPU_FRAME_EXCHANGE"]
+        slots = [fr.render(cam, mpl, passes, plane, seed=5, pass_base=k * passes) for k in range(2)]
+        frames = [fr.wait(s, to_host=True) for s in slots]
+        frames += [fr.wait(s, to_host=True) for s in fr.render_batch(cam, mpl, passes, 3, plane, seed=5, pass_base=2 * passes)]
+        fr.set_readback(True)
+        s0 = fr.render(cam, mpl, passes, plane, seed=5, pass_base=0)
+        frames.append(fr.wait_host(s0, copy=True))
+        fs = fr.stats()
+        assert fs["rccl_ranks"] == n and fs["transport"] == "rccl" and fs["exchange_mode"] == mode and fs["exchange_ms"] > 0
+        for k, img in enumerate(frames):
+            assert_images_match(img, refs[k % 5], "%d GPUs, %s exchange, frame %d" % (n, mode, k))
+        fr.close()
+
+
 @pytest.mark.parametrize("world,in_flight", [(1, 2), (1, 3), (3, 2)])
 def test_c_abi_frame_readback_runs_under_the_next_frame(world, in_flight, monkeypatch):
     """SURVEY 8(d)'s frame ends with one read-back (render.cc:673-679 fills the caller's host image).  mgpu_frame_set_readback:
