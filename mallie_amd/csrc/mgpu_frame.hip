@@ -490,18 +490,6 @@ static int render_frames_enqueue(MgpuFrame *f, const double cam[12], int maxPath
   const int W = f->W, H = f->H, sh = f->strip_h, world = f->world;
   const bool exchange = world > 1 || f->force_exchange;
   const bool block = f->exchange_mode == MGPU_EXCHANGE_BLOCK;
-  static const bool prof = getenv("MGPU_FRAME_PROFILE") != nullptr;
-  static double ph[4] = {0, 0, 0, 0};
-  static unsigned long long ph_n = 0;
-  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  double tp = prof ? now() : 0.0;
-  auto lap = [&](int k) {
-    if (prof) {
-      const double t = now();
-      ph[k] += t - tp;
-      tp = t;
-    }
-  };
   for (Member &m : f->members) {
     FHIP(hipSetDevice(m.device));
     hipStream_t rs = render_stream(f, m, ks[0]); // the launch and the copies of the whole batch
@@ -511,7 +499,6 @@ static int render_frames_enqueue(MgpuFrame *f, const double cam[12], int maxPath
       if (m.slot[ks[i]].copy_pending) FHIP(hipStreamWaitEvent(rs, m.slot[ks[i]].copied, 0)); // ... and its read-back
       if (m.rank == 0) collect_timing(f, m.slot[ks[i]], false);
     }
-    lap(0);
     if (m.n_rows) {
       float *images[kMaxInFlight];
       for (int i = 0; i < n; ++i) images[i] = m.slot[ks[i]].local;
@@ -519,7 +506,6 @@ static int render_frames_enqueue(MgpuFrame *f, const double cam[12], int maxPath
                                          rng_mode, nullptr, seed, pass_base, n, images, nullptr, rs, nullptr);
       if (rc) return ffail(rc, "rank %d: %s", m.rank, mgpu_last_error());
     }
-    lap(1);
     for (int i = 0; i < n; ++i) {
       Slot &s = m.slot[ks[i]];
       if (m.rank == 0 && m.n_rows && !f->force_exchange) { // own strips to their final rows
@@ -529,7 +515,6 @@ static int render_frames_enqueue(MgpuFrame *f, const double cam[12], int maxPath
       FHIP(hipEventRecord(s.rendered, rs));
     }
     if (exchange) FHIP(hipStreamWaitEvent(m.comm_stream, m.slot[ks[n - 1]].rendered, 0));
-    lap(2);
   }
   Member *root = nullptr; // the member that holds rank 0 (copy transport: the one that moves everybody's bytes)
   for (Member &m : f->members)
@@ -649,10 +634,6 @@ static int render_frames_enqueue(MgpuFrame *f, const double cam[12], int maxPath
     }
     if (slots_out) slots_out[i] = k;
   }
-  lap(3);
-  if (prof && (++ph_n % 4) == 0)
-    fprintf(stderr, "mgpu_frame profile after %llu render calls: waits+setup %.3f, mgpu_render_frames_device %.3f, place+events %.3f, exchange %.3f ms per call\n", ph_n,
-            ph[0] / ph_n, ph[1] / ph_n, ph[2] / ph_n, ph[3] / ph_n);
   if (f->readback && root)
     for (int i = 0; i < n; ++i) root->slot[ks[i]].copy_wanted = true; // issued by mgpu_frame_wait_host, see there
   f->next += (unsigned long long)n;
