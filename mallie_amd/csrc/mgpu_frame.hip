@@ -499,16 +499,19 @@ static int render_frames_enqueue(MgpuFrame *f, const double cam[12], int maxPath
       if (m.slot[ks[i]].copy_pending) FHIP(hipStreamWaitEvent(rs, m.slot[ks[i]].copied, 0)); // ... and its read-back
       if (m.rank == 0) collect_timing(f, m.slot[ks[i]], false);
     }
+    // one rank and no forced exchange: its "strips" are the whole frame in frame order -- rendered straight into the frame
+    // buffer (the strided device copy that deals strips to their rows cost 0.07 ms of a 5.5 ms frame for moving nothing)
+    const bool direct = world == 1 && !f->force_exchange && m.rank == 0;
     if (m.n_rows) {
       float *images[kMaxInFlight];
-      for (int i = 0; i < n; ++i) images[i] = m.slot[ks[i]].local;
+      for (int i = 0; i < n; ++i) images[i] = direct ? m.slot[ks[i]].frame : m.slot[ks[i]].local;
       int rc = mgpu_render_frames_device(m.scene, cam, W, H, 0, W, m.rank * sh, sh, sh * world, m.n_rows, maxPathLength, passes, plane,
                                          rng_mode, nullptr, seed, pass_base, n, images, nullptr, rs, nullptr);
       if (rc) return ffail(rc, "rank %d: %s", m.rank, mgpu_last_error());
     }
     for (int i = 0; i < n; ++i) {
       Slot &s = m.slot[ks[i]];
-      if (m.rank == 0 && m.n_rows && !f->force_exchange) { // own strips to their final rows
+      if (m.rank == 0 && m.n_rows && !f->force_exchange && !direct) { // own strips to their final rows
         int rc = place_strips(s.frame, s.local, m.n_rows, 0, world, sh, W, rs);
         if (rc) return rc;
       }

@@ -515,7 +515,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
           bool hit = bt < kDblMax; // bvh_accel.cc:838
           double t = bt;
           V3 n = v3(0, 0, 0);
-          if (bslot != kNoHit) last_mat = sc.tris[bslot].mat; // written by TestLeafNode on every accepted triangle
+          if (bslot != kNoHit) // written by TestLeafNode on every accepted triangle
+            last_mat = LDS_SCENE ? *reinterpret_cast<const uint32_t *>(lds_tris + (size_t)bslot * 80 + 76) : sc.tris[bslot].mat;
           if (hit) {
             if (sc.has_fv_normals) { // barycentric lerp, not renormalised (bvh_accel.cc:745-748)
               const double *nn = sc.slot_normal + 9 * (size_t)bslot;
@@ -566,9 +567,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
                 d1 = sc.mat_diffuse[3 * (size_t)last_mat + 1];
                 d2 = sc.mat_diffuse[3 * (size_t)last_mat + 2];
               }
-#ifdef MGPU_ABL_NOTAIL // timing ablation only (wrong image): what the closed-loop tail costs
-              if (thr0 == 12345.0)
-#endif
               if (GREY || (thr0 == thr1 && thr1 == thr2 && d0 == d1 && d1 == d2)) {
                 // grey path (every material the reference can load from .obj/.eson is grey): the three channels
                 // perform identical operations on identical values, so evaluate one and copy -- same bits, 1/3 of the
@@ -664,14 +662,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
             float *dst = P.pass_stride ? P.out + (size_t)pass * P.pass_stride + ((size_t)(ly >> 3) * tiles_x + (lx >> 3)) * 192u +
                                              (size_t)(((ly & 7u) << 3) + (lx & 7u)) * 3u
                                        : P.out + 3 * ((size_t)ly * (size_t)win_w + lx);
-#ifdef MGPU_ABL_NOSTORE // timing ablation only (wrong image): what the result stores cost
-            if (rad0 == 12345.0)
-#endif
-            {
-              dst[0] = (float)rad0;
-              dst[1] = (float)rad1;
-              dst[2] = (float)rad2;
-            }
+            dst[0] = (float)rad0;
+            dst[1] = (float)rad1;
+            dst[2] = (float)rad2;
             if (P.tile_cost && pass == 0) // what this path cost, for the next launch's hand-out order
               atomicAdd(P.tile_cost + ((ly >> 3) * tiles_x + (lx >> 3)), n_nodes + n_tris + 16u * n_rays - cost_base);
           }
@@ -831,11 +824,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
             const uint4 q = reinterpret_cast<const uint4 *>(P.rng_states)[(size_t)pass * P.W * P.H + gpix];
             s4[0] = q.x; s4[1] = q.y; s4[2] = q.z; s4[3] = q.w;
           } else {
-#ifdef MGPU_ABL_CHEAPSTART // timing ablation only (another image): what the splitmix64 seeding costs
-            s4[0] = gpix * 2654435761u ^ (uint32_t)pass; s4[1] = gpix + 0x9E3779B9u; s4[2] = (uint32_t)pass * 40503u + 1u; s4[3] = gpix ^ 0x85EBCA6Bu;
-#else
             hash_state(P.seed, P.pass_base + (uint32_t)pass, gpix, s4);
-#endif
           }
           rng = Rng{s4[0], s4[1], s4[2], s4[3]};
           probe_on = P.probe && gpix == P.probe_pixel && (uint32_t)pass == P.probe_pass;

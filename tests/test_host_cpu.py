@@ -215,3 +215,43 @@ def test_tail_division_through_the_rounded_reciprocal_is_exact():
             r = A - Fraction(q) * L  # what fma(-q, L, a) returns: it is exactly representable
             assert Fraction(rn(r)) == r
             assert rn(Fraction(q) + r * Fraction(y)) == a / L, (a, L)
+
+
+def test_tail_table_scales_with_a_power_of_two_throughput():
+    """k_render_sm reads the post-miss tail of a path whose throughput is a power of two and whose multiplier is 0.5 (or absent) from
+    RenderParams::tail_unit: throughput x (the tail loop's result for throughput 1).  The claim behind it -- scaling every operand of
+    the loop by a power of two scales every rounded intermediate by it -- checked here by running the loop itself (Python floats are
+    IEEE doubles; math.fma where the interpreter has it, exact rational arithmetic otherwise) for every (first length, maxPathLength,
+    multiplier on / off) and throughputs 2^0 .. 2^-40 and 2^-900."""
+    import math
+    from fractions import Fraction
+
+    if hasattr(math, "fma"):
+        fma = math.fma
+    else:
+        def fma(a, b, c):  # correctly rounded a * b + c through exact rationals (float(Fraction) rounds to nearest even)
+            return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+    def tail(thr, L0, mpl, mul):
+        rad = 0.0
+        L = L0
+        while True:
+            x, y, dl = thr * 0.5, 1.0 / L, float(L)
+            q = x * y
+            rad += fma(fma(-q, dl, x), y, q)
+            if L >= mpl:
+                break
+            if mul:
+                thr *= 0.5
+            L += 1
+        return rad
+
+    for mpl in (2, 5, 9, 16):
+        for L0 in range(1, mpl + 1):
+            for mul in (False, True):
+                unit = tail(1.0, L0, mpl, mul)
+                for k in list(range(0, 41)) + [900]:
+                    thr = math.ldexp(1.0, -k)
+                    assert tail(thr, L0, mpl, mul) == thr * unit, (mpl, L0, mul, k)
+    # and a throughput that is NOT a power of two does not scale like that in general (the kernel then runs the loop)
+    assert any(tail(0.3 * math.ldexp(1.0, -k), 2, 16, True) != 0.3 * math.ldexp(1.0, -k) * tail(1.0, 2, 16, True) for k in range(8))
