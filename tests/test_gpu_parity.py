@@ -44,12 +44,17 @@ def assert_images_match(img, ref, what):
     conftest.PARITY["notes"].append(msg)
 
 
-def assert_same_work(st, ost):
+def assert_same_work(st, ost, primary_only=False):
     """Rays actually traversed must agree exactly (same hit/miss decisions). Node / triangle visits of BOUNCE rays may
     differ in a handful of box tests because bounce directions carry the <=1 ulp difference between the device's and
-    glibc's acos/sin/cos; batched traces of identical rays are compared exactly in test_trace_*."""
+    glibc's acos/sin/cos; batched traces of identical rays are compared exactly in test_trace_*.  primary_only: the workload
+    traces camera rays only (maxPathLength 1, the AOV integrators) -- every operation on their way is IEEE arithmetic, so the
+    counters must be EQUAL."""
     assert st["real_rays"] == ost["real_rays"]
-    assert abs(st["nodes"] - ost["nodes"]) <= 2e-3 * ost["nodes"] and abs(st["tris"] - ost["tris"]) <= 2e-3 * ost["tris"]
+    if primary_only:
+        assert (st["nodes"], st["tris"]) == (ost["nodes"], ost["tris"])
+    else:
+        assert abs(st["nodes"] - ost["nodes"]) <= 2e-3 * ost["nodes"] and abs(st["tris"] - ost["tris"]) <= 2e-3 * ost["tris"]
 
 
 def test_loaded_native_library_and_device():
@@ -628,7 +633,7 @@ def test_render_hash_mode_vs_oracle(mpl, passes):
     assert_images_match(img, oimg, "hash mpl=%d" % mpl)
     assert np.array_equal(count, ocount)
     assert (st["trace_calls"], st["paths"]) == (ost["trace_calls"], ost["paths"])
-    assert_same_work(st, ost)
+    assert_same_work(st, ost, primary_only=(mpl == 1))
     assert ost["garbage_hits"] == 0
 
 
