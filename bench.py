@@ -454,11 +454,11 @@ def main():
     # N = 1, the headline: SURVEY 8(d)'s frame = the passes + ONE read-back.  The frame object (C ABI) copies every frame into a
     # pinned host buffer of its slot on a copy stream, behind the frame; with two slots the copy of frame k runs under the
     # kernel of frame k + 1, and the caller takes frame k - 1 (mgpu_frame_wait_host) while frame k renders.
-    readback = world == 1 and cframe is None and not force_gather and not os.environ.get("MALLIE_BENCH_NO_READBACK")
-    if readback:
+    want_readback = not force_gather and not os.environ.get("MALLIE_BENCH_NO_READBACK")
+    readback = False
+    if world == 1 and cframe is None and want_readback:
         fif = max(fif, 2)
         cframe = M.Frame.create_rank(scene, local_rank, 0, 1, None, W, H, strip_h=8, frames_in_flight=fif)
-        cframe.set_readback(True)
         exchange = "none (one GPU); every frame read back to pinned host memory under the next frame's kernel"
     if single:
         cframe = M.Frame(scenes, devices, W, H, strip_h=8, frames_in_flight=fif)
@@ -483,21 +483,38 @@ def main():
                 cframe.close()
                 cframe = None
 
+    # a frame ends with ONE read-back (behind the RCCL exchange when N > 1).  With the frame object every frame is copied
+    # from rank 0's HBM to pinned host memory on a copy stream while later frames render; the caller takes the frames enqueued BEFORE
+    # the latest render call once that call is out (mgpu_frame_wait_host; other ranks only wait for their strips to have left).
+    if cframe is not None and want_readback:
+        cframe.set_readback(True)
+        readback = True
     pending = []
     taken = {"frames": 0, "last": None}  # read-back mode: host frames the caller has taken, and the latest (aliases pinned memory)
 
+    def take(slots):
+        for sl in slots:
+            got = cframe.wait_host(sl)
+            if got is not None:
+                taken["last"] = got
+            taken["frames"] += 1
+
+    def make_room(n):
+        """Read-back mode: the frame object has `fif` slots; before n more frames are enqueued the OLDEST frames in flight are taken
+        (they have had the longest to finish, and the frames behind them keep the GPUs busy meanwhile) until the n fit."""
+        while readback and pending and len(pending) + n > fif:
+            take([pending.pop(0)])
+
     def render_frame(k):
         if cframe is not None:
-            slot = cframe.render(frame, mpl, spp, plane, seed=cfg["seed"], pass_base=k * spp)
-            if readback and pending:  # frame k is enqueued: take frame k - 1 from its pinned buffer while k renders
-                taken["last"] = cframe.wait_host(pending.pop())
-                taken["frames"] += 1
-            pending.append(slot)
+            make_room(1)
+            pending.append(cframe.render(frame, mpl, spp, plane, seed=cfg["seed"], pass_base=k * spp))
         else:
             fr.render(pass_base=k * spp)
 
     def render_frames(k0, n):
         if cframe is not None and n > 1:
+            make_room(n)
             pending.extend(cframe.render_batch(frame, mpl, spp, n, plane, seed=cfg["seed"], pass_base=k0 * spp))
         else:
             for k in range(k0, k0 + n):
@@ -505,11 +522,10 @@ def main():
 
     def finish_frames():
         if cframe is not None:
-            for slot in sorted(set(pending[-fif:])):
-                if readback:
-                    taken["last"] = cframe.wait_host(slot)
-                    taken["frames"] += 1
-                else:
+            if readback:
+                take(list(pending))
+            else:
+                for slot in sorted(set(pending[-fif:])):
                     cframe.wait(slot)
             del pending[:]
 
@@ -636,9 +652,9 @@ def main():
                 "parallelism": "replicated scene, interleaved 8-row strips x%d, 1 RCCL exchange/frame: %s" % (world, exchange)
                                if world > 1 else "single GPU, persistent-threads kernel",
                 "frames_in_flight": fif, "frames_per_launch": fpl if batched else 1,
-                "readback": ("every frame copied to pinned host memory (24.9 MB at 1080p) behind its kernel, on a copy stream, and "
-                             "taken by the caller while the next frame renders: %d of %d timed frames taken inside the timed region"
-                             % (host_frames_taken, args.steps)) if readback else "none: frames stay in HBM",
+                "readback": ("every frame copied to pinned host memory (%.1f MB) behind its kernel%s, on a copy stream, and "
+                             "taken by the caller while later frames render: %d of %d timed frames taken inside the timed region"
+                             % (12e-6 * W * H, " and exchange" if world > 1 else "", host_frames_taken, args.steps)) if readback else "none: frames stay in HBM",
                 "rays_per_frame": int(rays / args.steps), "trace_calls_per_frame": int(trace_calls / args.steps),
                 "nodes_per_ray": round(nodes / rays, 3), "tris_per_ray": round(tris / rays, 3),
                 "mtrace_calls_per_s": round(trace_calls / elapsed / 1e6, 2),

@@ -378,6 +378,8 @@ class Frame:
         rc = load_library().mgpu_frame_wait_host(self.h, slot, C.byref(ptr))
         if rc:
             raise MgpuError(rc, "mgpu_frame_wait_host", load_library().mgpu_frame_last_error().decode())
+        if not ptr.value:
+            return None  # this process does not hold rank 0
         a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(self.H, self.W, 3))
         return a.copy() if copy else a
 
