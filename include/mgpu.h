@@ -197,6 +197,13 @@ int mgpu_render_stream(MgpuScene *scene, const double origin[3], const double co
  * the first kernel to the verdict of its verification), whether it had to classify the camera's pixels first (a camera's classes
  * are cached with the scene), how many resolutions of this scene had to be repeated because a pixel classified "certain" was
  * not, and how many pixels of a pass are uncertain (silhouette pixels of mesh + plane against the sky). */
+/* Render-ahead for progressive callers of mgpu_render (off by default; mallie::Render switches it on): a call that renders whole
+ * rows with MGPU_RNG_HASH and stats == NULL enqueues, before it copies its own frame to the caller, the frame the NEXT call will
+ * ask for if it repeats the arguments with pass_base moved on by `passes` -- what render.cc's drivers do pass after pass -- so
+ * that kernel runs under this call's PCIe copy.  A next call that asks for exactly that finds it done; any other call drops it.
+ * Images do not depend on it.  mgpu_render_ahead_stats: calls served from a frame rendered ahead / calls that were not. */
+int mgpu_scene_set_render_ahead(MgpuScene *scene, int on);
+int mgpu_render_ahead_stats(MgpuScene *scene, unsigned long long *hits, unsigned long long *misses);
 int mgpu_debug_stream_classes(MgpuScene *scene, unsigned char *out, size_t npix); /* diagnostic: the cached classes, 0 / 1 / 2 per pixel */
 int mgpu_stream_stats(MgpuScene *scene, double *resolve_ms, int *classified, unsigned long long *retries, uint32_t *uncertain_pixels);
 /* Render() with its `step` argument (render.cc:657-696): step == 1 is mgpu_render with passes = 1 on the whole frame.

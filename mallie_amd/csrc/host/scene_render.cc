@@ -3,6 +3,7 @@
 //   Scene::Init / InitFromArrays   scene.cc:66-251   (mesh load, scale / fit-to-[-1,1]^3, BVH build)
 //   Scene::Trace / BoundingBox     scene.cc:253-333
 //   Render                         render.cc:593-708 (camera frame, first-call plane setup, one pass, count++)
+#include <chrono>
 #include <algorithm>
 #include <cfloat>
 #include <cstdio>
@@ -363,10 +364,20 @@ static bool render_impl(Scene &scene, const RenderConfig &config, std::vector<fl
     fflush(stdout);
     return true;
   }
+  // A progressive driver calls Render() pass after pass with the same camera (main_sdl.cc:689, main_console.cc): the call
+  // enqueues the NEXT pass on the device before it copies this one out (include/mgpu.h, mgpu_scene_set_render_ahead;
+  // MALLIE_RENDER_AHEAD=0: never), which is why it asks for no statistics (they would tie the call to its own launch)
+  static const bool render_ahead = !(getenv("MALLIE_RENDER_AHEAD") && atoi(getenv("MALLIE_RENDER_AHEAD")) == 0);
+  const bool ahead = render_ahead && step == 1 && !table;
+  if (mgpu_scene_set_render_ahead(dev, ahead ? 1 : 0) != MGPU_OK) {
+    printf("Mallie:err\tmsg:Render: %s\n", mgpu_last_error());
+    return false;
+  }
+  const auto t_call = std::chrono::steady_clock::now();
   const int rc = step == 1
                      ? mgpu_render(dev, origin, corner, du, dv, width, height, 0, 0, width, height, gMaxPathLength, passes,
                                    gPlane ? pl : NULL, table ? MGPU_RNG_TABLE : MGPU_RNG_HASH, gRngTable, gSeed, gPassCounter,
-                                   &image[0], &count[0], &st)
+                                   &image[0], &count[0], ahead ? NULL : &st)
                      : mgpu_render_step(dev, origin, corner, du, dv, width, height, step, gMaxPathLength, gPlane ? pl : NULL,
                                         table ? MGPU_RNG_TABLE : MGPU_RNG_HASH, gRngTable, gSeed, gPassCounter, &image[0],
                                         &count[0], &st);
@@ -376,7 +387,7 @@ static bool render_impl(Scene &scene, const RenderConfig &config, std::vector<fl
     return false;
   }
   gPassCounter += (unsigned int)passes;
-  const double sec = st.total_ms / 1000.0;
+  const double sec = ahead ? std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call).count() : st.total_ms / 1000.0;
   printf("\r[Mallie] Render time: %f sec(s) | %f fps", sec, sec > 0 ? 1.0 / sec : 0.0);
   fflush(stdout);
   return true;

@@ -109,6 +109,10 @@ def load_library():
     L.mgpu_render_step.restype = i32
     L.mgpu_render_stream.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     L.mgpu_render_stream.restype = i32
+    L.mgpu_scene_set_render_ahead.argtypes = [vp, i32]
+    L.mgpu_scene_set_render_ahead.restype = i32
+    L.mgpu_render_ahead_stats.argtypes = [vp, vp, vp]
+    L.mgpu_render_ahead_stats.restype = i32
     L.mgpu_stream_stats.argtypes = [vp, vp, vp, vp, vp]
     L.mgpu_stream_stats.restype = i32
     L.mgpu_render_aov.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, u64, u32, vp, vp, vp]
@@ -516,9 +520,18 @@ class Scene:
                                                 C.byref(st) if want_stats else None), "mgpu_trace_device")
         return st.as_dict() if want_stats else None
 
+    def set_render_ahead(self, on=True):
+        _check(load_library().mgpu_scene_set_render_ahead(self.h, 1 if on else 0), "mgpu_scene_set_render_ahead")
+
+    def render_ahead_stats(self):
+        h, m = C.c_uint64(), C.c_uint64()
+        _check(load_library().mgpu_render_ahead_stats(self.h, C.byref(h), C.byref(m)), "mgpu_render_ahead_stats")
+        return {"hits": h.value, "misses": m.value}
+
     def render(self, frame, W, H, maxPathLength=16, passes=1, plane=None, rng_mode=RNG_HASH, rng_states=None, seed=1,
-               pass_base=0, window=None, image=None, count=None):
-        """mgpu_render into host buffers. -> (image HxWx3 float32, count HxW int32, stats dict)"""
+               pass_base=0, window=None, image=None, count=None, want_stats=True):
+        """mgpu_render into host buffers. -> (image HxWx3 float32, count HxW int32, stats dict; None with want_stats=False: the
+        call then may be served by the render-ahead, set_render_ahead)"""
         frame = _c(frame, "<f8")
         x0, y0, x1, y1 = window if window is not None else (0, 0, W, H)
         if image is None:
@@ -530,8 +543,8 @@ class Scene:
         st = Stats()
         _check(load_library().mgpu_render(self.h, _p(frame[0:3]), _p(frame[3:6]), _p(frame[6:9]), _p(frame[9:12]), W, H,
                                           x0, y0, x1, y1, maxPathLength, passes, _p(plane), rng_mode, _p(rng_states),
-                                          seed, pass_base, _p(image), _p(count), C.byref(st)), "mgpu_render")
-        return image, count, st.as_dict()
+                                          seed, pass_base, _p(image), _p(count), C.byref(st) if want_stats else None), "mgpu_render")
+        return image, count, (st.as_dict() if want_stats else None)
 
     def render_stream(self, frame, W, H, maxPathLength=16, passes=1, plane=None, stream_state=None, count=None, want_states=False):
         """mgpu_render_stream: Render() in the reference's own serial random stream -> (image, count, stats, stream_state after,

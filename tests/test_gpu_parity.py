@@ -1189,6 +1189,48 @@ def test_c_abi_frame_on_one_gpu(force, monkeypatch):
         M.Frame([sc], [1], W, H, strip_h=8, frames_in_flight=1)
 
 
+def test_render_ahead_serves_the_next_pass_and_never_changes_a_frame():
+    """mgpu_scene_set_render_ahead: a mgpu_render call enqueues the frame the next call will ask for if it repeats the arguments
+    with pass_base moved on by `passes` (what mallie::Render's callers do), under its own PCIe copy.  Every frame of a progressive
+    sequence -- with a change of camera, of the pass count and of the window in the middle, a call that asks for statistics, a
+    ray batch traced in between and the switch turned off again -- must be the frame of the same call without the render-ahead
+    (itself pinned to the oracle elsewhere), and the calls that continue the sequence must have been served from the frame
+    rendered ahead."""
+    sc, ref = gpu_scene("cornell_obj"), gpu_scene("cornell_obj")
+    osc = O.scene_from_golden("cornell_obj")
+    W, H, mpl = 200, 120, 5
+    cam_a = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    cam_b = M.camera_frame((2, 3, 18), (0, 1, 0), width=W, height=H)
+    plane = sc.plane()
+    t = O.load_golden("trace_cornell_obj")
+    sc.set_render_ahead(True)
+    # (camera, passes, pass_base, window, want_stats, continues the sequence?)
+    calls = [(cam_a, 1, 0, None, False, False), (cam_a, 1, 1, None, False, True), (cam_a, 1, 2, None, False, True),
+             (cam_b, 1, 3, None, False, False), (cam_b, 1, 4, None, False, True), (cam_b, 2, 5, None, False, False),
+             (cam_b, 2, 7, None, False, True), (cam_b, 2, 9, (0, 16, W, 80), False, False), (cam_b, 2, 11, (0, 16, W, 80), False, True),
+             (cam_b, 2, 13, (0, 16, W, 80), True, False), (cam_b, 2, 15, (0, 16, W, 80), False, False), (cam_a, 1, 40, None, False, False)]
+    hits = 0
+    for k, (cam, passes, pb, win, want, cont) in enumerate(calls):
+        before = sc.render_ahead_stats()["hits"]
+        img, cnt, _ = sc.render(cam, W, H, mpl, passes, plane, M.RNG_HASH, seed=9, pass_base=pb, window=win, want_stats=want)
+        rimg, rcnt, _ = ref.render(cam, W, H, mpl, passes, plane, M.RNG_HASH, seed=9, pass_base=pb, window=win)
+        assert img.tobytes() == rimg.tobytes() and np.array_equal(cnt, rcnt), k
+        served = sc.render_ahead_stats()["hits"] - before
+        assert served == (1 if cont else 0), (k, served)
+        hits += served
+        if k == 5:  # a ray batch in between: the frame rendered ahead is on the GPU while it runs
+            out, hit = sc.trace(t["rays"][:300])
+            assert np.array_equal(hit, t["hits"]["hit"][:300].astype("u1"))
+    assert hits == 5
+    oimg, _, _, _ = osc.render(cam_a, W, H, mpl, 1, plane, O.RNG_HASH, seed=9, pass_base=2)
+    img, _, _ = sc.render(cam_a, W, H, mpl, 1, plane, M.RNG_HASH, seed=9, pass_base=2, want_stats=False)
+    assert_images_match(img, oimg, "a frame through the render-ahead path vs the oracle")
+    sc.set_render_ahead(False)
+    before = sc.render_ahead_stats()
+    img2, _, _ = sc.render(cam_a, W, H, mpl, 1, plane, M.RNG_HASH, seed=9, pass_base=3, want_stats=False)
+    assert sc.render_ahead_stats() == before and img2.tobytes() == ref.render(cam_a, W, H, mpl, 1, plane, M.RNG_HASH, seed=9, pass_base=3)[0].tobytes()
+
+
 @pytest.mark.skipif(M.device_count() < 2, reason="needs two GPUs: RCCL between distinct devices")
 def test_rccl_frame_between_distinct_devices():
     """The default N > 1 transport where there is hardware for it: every visible GPU renders its interleaved strips, ONE grouped
