@@ -99,6 +99,8 @@ struct MgpuScene {
   int cap = 16;        // LDS stack entries per lane of the instantiated kernels
   double bmin[3], bmax[3];
   DScene d{};
+  DScene d_created{}; // `d` as mgpu_scene_create left it (overflow columns null): what never changes afterwards.  The trace server
+                      // launches from a caller's thread without host_mutex and must not read fields ensure_overflow rewrites
   // owned device allocations
   void *p_nodes = nullptr, *p_tris = nullptr, *p_slotn = nullptr, *p_mat = nullptr, *p_verts = nullptr,
        *p_fnodes = nullptr, *p_ftris = nullptr, *p_fnormals = nullptr, *p_fdiffuse = nullptr, // fast mode (float copies)
@@ -623,7 +625,7 @@ int server_launch(MgpuScene *s, uint32_t seen_epoch) {
   if (render_held(s->device)) return MGPU_OK; // a render call is in progress on this device: the caller keeps waiting
   int rc = set_device(s);
   if (rc) return rc;
-  DScene d = s->d; // the scene as the batched trace sees it, with the server's own overflow columns
+  DScene d = s->d_created; // the scene as it was created, with the server's own overflow columns
   const int extra = s->stack_need - s->cap;
   d.stack_overflow = extra > 0 ? (uint32_t *)s->srv_overflow : nullptr;
   d.overflow_cap = extra > 0 ? (uint32_t)extra : 0u;
@@ -924,6 +926,7 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
     if (atoi(e) == 0) s->d.grey = 0;
   if (const char *e = getenv("MGPU_PLAIN_SLABS")) // 0: literal slab test only (A/B measurements, tests)
     if (atoi(e) == 0) s->d.boxes_ordered = 0;
+  s->d_created = s->d;
   if (const char *e = getenv("MGPU_TRACE_QUEUE")) s->trace_queue_on = atoi(e) != 0;
   if (const char *e = getenv("MGPU_TRACE_SERVER")) s->srv_on = atoi(e) != 0;
   if (const char *e = getenv("MGPU_TRACE_SERVER_LDS")) s->srv_stage = atoi(e) != 0;

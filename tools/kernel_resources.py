@@ -18,7 +18,10 @@ for line in err.splitlines():
     elif cur is not None and ":" in t:
         k, v = t.split(":", 1)
         cur[k.strip()] = v.strip()
-names = subprocess.run(["c++filt"] + [r["name"] for r in rows], capture_output=True, text=True).stdout.splitlines()
+if not rows:
+    sys.stderr.write(err[-3000:])
+    raise SystemExit("no kernels reported (compile error?)")
+names = subprocess.run(["c++filt"] + [r["name"] for r in rows], capture_output=True, text=True, stdin=subprocess.DEVNULL).stdout.splitlines()
 print("%-70s %5s %5s %7s %6s %6s %4s %7s" % ("kernel", "VGPR", "SGPR", "scratch", "vspill", "sspill", "occ", "LDS"))
 for r, n in zip(rows, names):
     n = re.sub(r"\(.*", "", n)
