@@ -123,6 +123,26 @@ if os.path.exists(bf) and os.path.getsize(bf):
         t.append("C2 lane occupancy (instrumented pass of the bench run): NODE %.2f, TRI %.2f, SHADE %.2f, weighted %.2f; useful share of the issue peak %s." % (
             occ.get("node_frac") or 0, occ.get("tri_frac") or 0, occ.get("shade_frac") or 0, occ.get("weighted") or 0,
             "%.2f" % roof["useful_frac"] if roof.get("useful_frac") else "-"))
+    # what a "frame" is in that line, and the CPU figures of the same run (so that DESIGN.md never quotes a stale one by hand)
+    t.append("")
+    fr_parts = ["`value` / `ms_per_step` = the frame of SURVEY 8(d), passes + one read-back taken by the caller under the next frame: %.3f ms (%.0f Mrays/s)" % (b["ms_per_step"], b["value"])]
+    for key2, label in (("frame_resident_in_hbm", "the same frames left in HBM, one in flight (the headline of rounds 1-3)"),
+                        ("frame_with_synchronous_readback", "with a synchronous read-back before the next frame starts"), ("tile_order_off", "without the cost-ordered hand-out")):
+        if key2 in b and "ms_per_frame" in b[key2]:
+            fr_parts.append("%s: %.3f ms" % (label, b[key2]["ms_per_frame"]))
+    t.append("Frames of that run: " + "; ".join(fr_parts) + ".")
+    cb, cr = b.get("cpu_baseline") or {}, b.get("cpu_reference") or {}
+    if cb.get("value"):
+        t.append("")
+        t.append("CPU on the same host (%s): the oracle (`kind: port`) %.1f Mrays/s on %s threads (first frame byte-equal to the GPU's: %s)%s." % (
+            ("%s, %s physical cores" % (cb.get("cpu_model", "host"), cb.get("physical_cores"))), cb["value"], cb.get("cores"), cb.get("gpu_frame_byte_equal"),
+            "; Mallie's own OpenMP `Render()` (`kind: reference`, kMaxPathLength 16) %.2f Mrays/s on %s threads" % (cr["value"], cr.get("cores")) if cr.get("value") else ""))
+    rs = b.get("reference_stream_1080p") or {}
+    if rs.get("resolve_ms_per_pass"):
+        t.append("")
+        t.append("The reference's own random stream, one 1080p pass (`reference_stream_1080p`): resolved across the chip in %.1f ms per pass (first call, with the camera's "
+                 "classification: %.1f ms; %d uncertain pixels per pass) against %.0f ms for the whole call with the one-workgroup kernel of round 3." % (
+                     rs["resolve_ms_per_pass"], rs["resolve_ms_first_call"], rs["uncertain_pixels_per_pass"], rs["serial_kernel_call_ms"]))
     txt = "\n".join(t) + "\n"
     open(os.path.join(ROOT, "profiles", tag + "_tables.md"), "w").write(txt)
     dp = os.path.join(ROOT, "DESIGN.md")
