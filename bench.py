@@ -662,6 +662,9 @@ def main():
                 # exchange step's device time per frame (HIP events on rank 0's communicator stream) and mean kernel time per
                 # launch on every rank (a launch carries frames_per_launch frames)
                 "rccl_ranks": fstats["rccl_ranks"] if fstats else (env_world if multi_proc else 0),
+                # which HIP device every rank of THIS process drives; ranks share a device only under MGPU_FRAME_TRANSPORT=copy (a test
+                # aid: no RCCL, no scaling -- the line then is about the machinery, not about N GPUs)
+                "devices": devices, "ranks_share_a_device": len(set(devices)) < len(devices),
                 "kernel_ms_per_launch_by_rank": [round(x, 3) for x in per_rank_kernel]}
         if same_as_one_gpu is not None:
             conf["frame_equals_single_gpu_frame"] = same_as_one_gpu

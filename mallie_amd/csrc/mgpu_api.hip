@@ -1088,6 +1088,7 @@ int mgpu_trace(MgpuScene *s, const MgpuRay *rays, size_t n, MgpuIntersection *ou
   const double t0 = now_ms();
   int rc = set_device(s);
   if (rc) return rc;
+  if (stats && s->ahead_valid) HIP_TRY(hipStreamSynchronize(s->ahead_stream)); // (shared counters, see render_frames_impl)
   if (stats) memset(stats, 0, sizeof(*stats));
   if (n == 0) return MGPU_OK;
   // device staging of the host-buffer entry point, kept with the scene (grow-only): Scene::Trace / BVHAccel::Traverse
@@ -1216,6 +1217,8 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
   RenderHold hold(s->device); // no server is (re)launched on this device until this call has enqueued its work
   if (!rc) rc = servers_retire_device(s->device); // a resident trace server leaves first: this launch wants every CU
   if (rc) return rc;
+  if (stats && s->ahead_valid && (hipStream_t)stream != s->ahead_stream) // a frame rendered ahead (mgpu_render) books into the same
+    HIP_TRY(hipStreamSynchronize(s->ahead_stream));                       // counters: it leaves before a call that wants to read them
   if (stats) memset(stats, 0, sizeof(*stats));
   const int win_w = x1 - x0;
   if (win_w == 0 || n_rows == 0) return MGPU_OK;
@@ -1866,6 +1869,14 @@ int mgpu_render_stream(MgpuScene *s, const double origin[3], const double corner
       hipError_t e = stream_states_resolve(s->cap, 0, s->d, P, s->stream, s->num_cu, fresh, &retries);
       s->stream_last_ms = now_ms() - tr0; // the resolution ends with a synchronisation (it reads the verification's verdict)
       s->stream_last_fresh = fresh;
+      if (e == hipErrorUnknown) { // its verification kept finding new sub-pixel features (64 attempts): the one-workgroup walk needs no classes
+        (void)hipGetLastError();
+        s->stream.key_has_plane = -1;
+        TRY_S(hipMemcpy(d_state, stream_state, 16, hipMemcpyHostToDevice));
+        TRY_S(launch_stream_states(s->cap, 0, s->d, P));
+        e = hipSuccess;
+        retries = 64;
+      }
       if (e != hipSuccess) {
         s->stream.key_has_plane = -1; // whatever is cached may be half-updated
         cleanup();

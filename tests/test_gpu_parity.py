@@ -1212,9 +1212,11 @@ def test_render_ahead_serves_the_next_pass_and_never_changes_a_frame():
     hits = 0
     for k, (cam, passes, pb, win, want, cont) in enumerate(calls):
         before = sc.render_ahead_stats()["hits"]
-        img, cnt, _ = sc.render(cam, W, H, mpl, passes, plane, M.RNG_HASH, seed=9, pass_base=pb, window=win, want_stats=want)
-        rimg, rcnt, _ = ref.render(cam, W, H, mpl, passes, plane, M.RNG_HASH, seed=9, pass_base=pb, window=win)
+        img, cnt, st = sc.render(cam, W, H, mpl, passes, plane, M.RNG_HASH, seed=9, pass_base=pb, window=win, want_stats=want)
+        rimg, rcnt, rst = ref.render(cam, W, H, mpl, passes, plane, M.RNG_HASH, seed=9, pass_base=pb, window=win)
         assert img.tobytes() == rimg.tobytes() and np.array_equal(cnt, rcnt), k
+        if want:  # a call that asks for statistics gets ITS frame's counters, not those of a frame rendered ahead that is still running
+            assert all(st[f] == rst[f] for f in ("real_rays", "nodes", "tris", "trace_calls", "paths")), (st, rst)
         served = sc.render_ahead_stats()["hits"] - before
         assert served == (1 if cont else 0), (k, served)
         hits += served
