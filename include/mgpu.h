@@ -307,7 +307,9 @@ int mgpu_frame_wait(MgpuFrame *frame, int slot, float *host_image, float **devic
  * frame k -- its 24.9 MB (1080p) then cross PCIe under frame k + 1's kernel and cost nothing (needs frames_in_flight >= 2; a
  * slot is not rendered into again before its copy has left it).  On one GPU the frames of a frame object with the read-back on
  * go down ONE stream, in order (two whole-GPU launches enqueued on two streams share the CUs and finish together, which leaves
- * nothing to hide the first copy under).  In a process that does not hold rank 0, mgpu_frame_wait_host waits until the slot's
+ * nothing to hide the first copy under).  With several GPUs the copy is enqueued by the render call itself, behind the frame's
+ * exchange (rank 0 renders an N-th of a frame while a whole frame crosses PCIe: the copies run as the frames arrive), and
+ * mgpu_frame_wait_host only waits for it.  In a process that does not hold rank 0, mgpu_frame_wait_host waits until the slot's
  * strips have left and returns MGPU_OK with *host_image = NULL. */
 int mgpu_frame_set_readback(MgpuFrame *frame, int on);
 int mgpu_frame_wait_host(MgpuFrame *frame, int slot, const float **host_image);
