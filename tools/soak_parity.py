@@ -7,7 +7,7 @@ import mallie_amd as M
 import oracle_lib as O
 n_views = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(2026)
-tot_px = tot_diff = tot_rays = 0
+tot_px = tot_diff = tot_rays = n_stream = n_retry = 0
 for mesh in ("cornell_obj", "teapot_obj"):
     g = O.load_golden(mesh)
     sc = M.Scene(g["verts"].astype(np.float64), g["faces"], g["matIDs"], g["normals"] if g["has_normals"] else None, None, g["nodes"], g["indices"])
@@ -29,6 +29,16 @@ for mesh in ("cornell_obj", "teapot_obj"):
         assert st["real_rays"] == ost["real_rays"] or d, (mesh, v)
         if d:
             print("  view %d of %s: %d differing pixels (%dx%d, mpl %d)" % (v, mesh, d, W, H, mpl), flush=True)
+        # the reference's own random stream, resolved across the chip (mgpu_stream.hip), every 3rd view: start states of every
+        # (pass, pixel), the state left behind and the image against the oracle's run in that stream
+        if v % 3 == 0:
+            ostate = np.array(O.REFERENCE_SEED, "<u4")
+            so, _, _, ostates = osc.render(frame, W, H, mpl, passes, plane, O.RNG_STREAM, stream_state=ostate, want_states=True)
+            si, _, _, state, states = sc.render_stream(frame, W, H, mpl, passes, plane, want_states=True)
+            ds = int((si != so).any(-1).sum()) + (0 if np.array_equal(states, ostates) and np.array_equal(state, ostate) else W * H)
+            tot_px += W * H; tot_diff += ds; n_stream += 1; n_retry += sc.stream_stats()["retries"]
+            if ds:
+                print("  stream view %d of %s: %d differing pixels / states (%dx%d, mpl %d, %d passes)" % (v, mesh, ds, W, H, mpl, passes), flush=True)
         # panoramic from inside / around the scene every 4th view
         if v % 4 == 0:
             stereo = int(rng.integers(0, 2))
@@ -39,4 +49,5 @@ for mesh in ("cornell_obj", "teapot_obj"):
             tot_px += W * H; tot_diff += dp
             if dp:
                 print("  pano view %d of %s: %d differing pixels" % (v, mesh, dp), flush=True)
-print("soak: %d views per scene, %d pixels, %d real rays: %d differing pixels" % (n_views, tot_px, tot_rays, tot_diff))
+print("soak: %d views per scene, %d pixels, %d real rays, %d frames in the reference's stream (retries of its resolution: %s): %d differing pixels" % (
+    n_views, tot_px, tot_rays, n_stream, n_retry, tot_diff))
