@@ -342,11 +342,12 @@ def extra_config(key, lib_path, torch, steps=5):
            "nodes_per_ray": round(st["nodes"] / st["real_rays"], 3), "tris_per_ray": round(st["tris"] / st["real_rays"], 3),
            "device_MB": round(sc.device_bytes() / 1e6, 1),
            "roofline": hbm_roofline(key, st, steps, kms, lib_path)}
+    ref16 = buf.clone()  # the last timed frame over the default tree
     if key in ("c3", "c4"):
         # the fast mode (fp32) on this configuration too: its time, and how far its frame is from the fp64 frame
         # of the same passes (buf holds the last timed frame).  Never the headline; north_star's tolerance is 1e-4.
         try:
-            ref64 = buf.clone()
+            ref64 = ref16
             sc.set_precision("fp32")
             for k in range(2):
                 render(k)
@@ -357,11 +358,27 @@ def extra_config(key, lib_path, torch, steps=5):
                                      "rms_per_pixel_l2_to_fp64_frame": float("%.3g" % float(l2.pow(2).mean().sqrt().item())),
                                      "pixels_moved_over_1e-3": float("%.3g" % float((l2 > 1e-3).double().mean().item())),
                                      "inside_north_star_1e-4": bool(float(l2.pow(2).mean().sqrt().item()) <= 1e-4)}
-            del ref64
         except Exception as e:  # an extra line must never take the headline down
             out["fast_mode_fp32"] = {"error": repr(e)}
+    # The same frames over the tree the reference's own builder makes with BVHBuildOptions::minLeafPrimitives = 8 instead of its
+    # default 16 (bvh_accel.h:33-43; a caller's choice, not this library's): the walk is instruction-bound in proportion to the
+    # nodes and triangles a ray visits, and with the scene in HBM smaller leaves trade ~2 triangle tests for ~1 node.
+    # The last timed frame over the other tree is compared byte for byte with the one over the default tree.
+    try:
+        sc.close()
+        sc = workloads.make_scene(cfg, min_leaf=8)
+        for k in range(2):
+            render(k)
+        torch.cuda.synchronize()
+        ms8, kms8, st8 = time_frames(sc, render, steps, torch.cuda.synchronize)
+        out["min_leaf_primitives_8"] = {"ms_per_frame": round(ms8, 3), "kernel_avg_ms": round(kms8, 3), "speedup_vs_default_tree": round(ms / ms8, 3),
+                                        "nodes_per_ray": round(st8["nodes"] / st8["real_rays"], 3), "tris_per_ray": round(st8["tris"] / st8["real_rays"], 3),
+                                        "device_MB": round(sc.device_bytes() / 1e6, 1),
+                                        "frame_equals_default_tree_frame": bool(torch.equal(buf, ref16))}
+    except Exception as e:  # an extra line must never take the headline down
+        out["min_leaf_primitives_8"] = {"error": repr(e)}
     sc.close()
-    del buf
+    del buf, ref16
     torch.cuda.empty_cache()
     return out
 

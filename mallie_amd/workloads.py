@@ -43,11 +43,14 @@ def n_tris(cfg):
     return int(len(_golden(cfg["mesh"])["faces"]))
 
 
-def make_scene(cfg, device=0):
-    """Scene of a configuration on `device`: BVH by this library's builder (device builder from 65 536 triangles up)."""
+def make_scene(cfg, device=0, min_leaf=None):
+    """Scene of a configuration on `device`: BVH by this library's builder (device builder from 65 536 triangles up).
+    min_leaf: BVHBuildOptions::minLeafPrimitives (bvh_accel.h:33-43) when not the reference's default of 16."""
     verts, faces, mats, normals = mesh_arrays(cfg)
     nodes = idx = None
-    if len(faces) >= 65536:
+    if min_leaf is not None:
+        nodes, idx, _ = mgpu.bvh_build(verts, faces, minLeaf=int(min_leaf), device=device if len(faces) >= 65536 else None)
+    elif len(faces) >= 65536:
         nodes, idx, _ = mgpu.bvh_build(verts, faces, device=device)
     return mgpu.Scene(verts, faces, mats, normals, None, nodes, idx, device=device)
 
