@@ -1239,6 +1239,7 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
   int block = kern == 2 ? 1024 : kBlock;
   size_t shmem = (size_t)(block / 64) * s->cap * 64 * sizeof(uint32_t);
   bool prim = false; // LDS-resident scene: the items' primary rays staged in LDS when 40 KB more fit (k_render_sm, PRIM)
+  size_t lds_hint_cap = 0;
   if (kern == 2) {
     shmem = lds_stack_bytes((size_t)(block / 64), (size_t)s->stack_need, (size_t)se_bytes);
     if (shmem + scene_lds > kLdsBudget) {
@@ -1249,6 +1250,9 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
       shmem += scene_lds;
       prim = render_sm_prim_bytes() != 0 && shmem + render_sm_prim_bytes() <= kLdsBudget && !getenv("MGPU_NO_PRIM");
       if (prim) shmem += render_sm_prim_bytes();
+      // ... and behind that the leaf hints (mgpu_render_sm.hip, kHintMinTris): one 64-byte record per leaf at most
+      if (!getenv("MGPU_NO_HINTS")) lds_hint_cap = std::min<size_t>((kLdsBudget - shmem) / 64, ((size_t)s->nn + 1) / 2);
+      shmem += lds_hint_cap * 64;
     }
   }
   // BVH in HBM: the wide traversal's far-child stacks, and -- one 1024-thread workgroup per CU instead of four of 256 -- the
@@ -1379,6 +1383,7 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
   P.lds_nodes_bytes = (uint32_t)(sizeof(MgpuNode) * s->nn);
   P.lds_tris_bytes = (uint32_t)(sizeof(DTri) * s->nf);
   P.stack_cap = (uint32_t)s->stack_need;
+  P.lds_hint_cap = kern == 2 ? (uint32_t)lds_hint_cap : 0u;
   if (treelet) P.lds_nodes_bytes = (uint32_t)(sizeof(WNode) * s->d.treelet_n); // what the HBM-resident kernel stages into LDS
   FScene fsc{};
   if (kern == 3) {

@@ -59,6 +59,7 @@ struct RenderParams {
   uint32_t *tile_cost;
   uint32_t lds_nodes_bytes, lds_tris_bytes; // k_render_sm<LDS_SCENE>: bytes of nodes / triangles staged into LDS
   uint32_t stack_cap;            // k_render_sm<LDS_SCENE>: stack entries per lane in LDS = tree depth + 1
+  uint32_t lds_hint_cap;         // k_render_sm<LDS_SCENE>: 64-byte leaf hint records that fit behind the scene (0: none), see kHintMinTris
   unsigned long long *wave_log;  // device or null: 4 words per wave (diagnostic builds only)
   double *probe;                 // device or null: kProbeStride doubles per PathTrace iteration of ONE path
   uint32_t probe_pixel, probe_pass; // full-frame pixel index and pass of the probed path

@@ -104,6 +104,15 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 #ifndef MGPU_TAIL_TABLE
 #define MGPU_TAIL_TABLE 1
 #endif
+#ifndef MGPU_LEAF_HINTS
+#define MGPU_LEAF_HINTS 1 // LDS-resident scene: two sub-boxes per large leaf, tested once when the leaf's TRI work starts (kHintMinTris)
+#endif
+#ifndef MGPU_HINT_MIN
+#define MGPU_HINT_MIN 4 // (8: 5.23-5.28, 6: 5.21-5.25, 4: 5.21 ms on C2; 12: 5.38; without hints 5.38-5.44)
+#endif
+#ifndef MGPU_HINT_WORTH
+#define MGPU_HINT_WORTH 0.85 // (0.7: 5.32-5.35, 0.95: 5.21-5.24)
+#endif
 #ifndef MGPU_TAIL_RECIP
 #define MGPU_TAIL_RECIP 1
 #endif
@@ -200,6 +209,90 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
     uint32_t s[4];
   };
   PrimRay *s_prim = reinterpret_cast<PrimRay *>(const_cast<unsigned char *>(lds_tris) + (((size_t)P.lds_tris_bytes + 15) & ~(size_t)15)) + (size_t)wave * 64;
+  // Leaf hints (LDS-resident scene, P.lds_hint_cap records of 64 bytes behind the staging above).  TestLeafNode
+  // (bvh_accel.cc:640-697) runs TriangleIsect on every triangle of a leaf whose box the ray hits -- up to 15 of them, 7.9 per ray
+  // on cornellbox_suzanne, one or none of which is hit.  For a leaf of kHintMinTris or more triangles the prologue splits the
+  // leaf's run [first, first + n) at the m that minimises area(box of the first m) * m + area(box of the rest) * (n - m) -- the
+  // ORDER of the run is the reference's and stays -- and keeps both boxes, padded and rounded outward to float, plus m.  When a
+  // lane's TRI work on the leaf starts, it tests its ray against the two boxes once (the kernel's own slab test, in double) and
+  // drops the part of the run whose box the ray misses (or enters beyond the best t): those triangles cannot be hit, and
+  // dropping a prefix or a suffix leaves the order of the remaining tests -- hence every `t > tBest` decision and the tie rule --
+  // as it was.  Dropped triangles are booked in n_tris as the tests the reference makes.
+  // Why a dropped triangle cannot be one TriangleIsect accepts: it accepts only rays through the triangle with 0 <= t <= best t,
+  // up to its own rounding: ~1e-15 of the operands, and up to ~4e-3 of the triangle's size for a ray within 1e-12 rad of its
+  // plane (|det| down to the reference's 1024 eps).  The boxes are padded by 2^-8 of their largest extent plus 2^-20 of the
+  // largest |coordinate|, which exceeds both and every rounding of the slab products; rays that are not `ray_plain` (an
+  // infinite or NaN product possible) never consult a hint.
+  constexpr uint32_t kHintMinTris = MGPU_HINT_MIN;
+  unsigned char *lds_hints = reinterpret_cast<unsigned char *>(s_prim - (size_t)wave * 64) + (PRIM ? (size_t)kWaves * 64 * sizeof(PrimRay) : 0);
+  if (LDS_SCENE && MGPU_LEAF_HINTS) {
+    __shared__ uint32_t s_nhints;
+    if (threadIdx.x == 0) s_nhints = 0u;
+    __syncthreads();
+    const uint32_t nn_lds = P.lds_nodes_bytes >> 6;
+    for (uint32_t i = threadIdx.x; i < nn_lds; i += BLOCK) {
+      uint32_t *nd = reinterpret_cast<uint32_t *>(const_cast<unsigned char *>(lds_nodes) + (size_t)i * 64);
+      if (nd[12] == 0u) continue; // interior node: its axis field is the split axis
+      uint32_t code = 0u; // a leaf's axis field (unused by the reference's traversal) becomes (hint + 1) << 16
+      const uint32_t n = nd[14], first = nd[15];
+      if (P.lds_hint_cap != 0u && n >= kHintMinTris && n <= 64u) {
+        auto grow = [&](uint32_t k, double *lo, double *hi) { // += the k-th triangle of the run: p0, p0 + e1, p0 + e2
+          const double *tp = reinterpret_cast<const double *>(lds_tris + (size_t)(first + k) * 80);
+          for (int a = 0; a < 3; ++a) {
+            const double p = tp[a], q = tp[a] + tp[3 + a], r = tp[a] + tp[6 + a];
+            lo[a] = fmin(lo[a], fmin(p, fmin(q, r)));
+            hi[a] = fmax(hi[a], fmax(p, fmax(q, r)));
+          }
+        };
+        auto half_area = [](const double *lo, const double *hi) {
+          const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+          return dx * dy + dy * dz + dz * dx;
+        };
+        const double inf = __builtin_inf();
+        double best = inf, whole = 0.0;
+        uint32_t best_m = 0u;
+        double alo[3] = {inf, inf, inf}, ahi[3] = {-inf, -inf, -inf};
+        for (uint32_t m = 1; m <= n; ++m) {
+          grow(m - 1, alo, ahi);
+          if (m == n) {
+            whole = half_area(alo, ahi) * (double)n;
+            break;
+          }
+          double blo[3] = {inf, inf, inf}, bhi[3] = {-inf, -inf, -inf};
+          for (uint32_t k = m; k < n; ++k) grow(k, blo, bhi);
+          const double c = half_area(alo, ahi) * (double)m + half_area(blo, bhi) * (double)(n - m);
+          if (c < best) {
+            best = c;
+            best_m = m;
+          }
+        }
+        if (best_m != 0u && best < MGPU_HINT_WORTH * whole) { // (a split that saves less than 15 % of the expected tests is not worth its two box tests)
+          const uint32_t h = atomicAdd(&s_nhints, 1u);
+          if (h < P.lds_hint_cap) {
+            float *rec = reinterpret_cast<float *>(lds_hints + (size_t)h * 64);
+            for (int part = 0; part < 2; ++part) {
+              double lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+              for (uint32_t k = part ? best_m : 0u; k < (part ? n : best_m); ++k) grow(k, lo, hi);
+              double ext = 0.0, big = 0.0;
+              for (int a = 0; a < 3; ++a) {
+                ext = fmax(ext, hi[a] - lo[a]);
+                big = fmax(big, fmax(fabs(lo[a]), fabs(hi[a])));
+              }
+              const double pad = ext * 0x1p-8 + big * 0x1p-20;
+              for (int a = 0; a < 3; ++a) {
+                rec[6 * part + a] = __double2float_rd(lo[a] - pad);
+                rec[6 * part + 3 + a] = __double2float_ru(hi[a] + pad);
+              }
+            }
+            reinterpret_cast<uint32_t *>(rec)[12] = best_m;
+            code = (h + 1u) << 16;
+          }
+        }
+      }
+      nd[13] = code;
+    }
+    __syncthreads();
+  }
   const int win_w = P.x1 - P.x0;
   const uint32_t tiles_x = (uint32_t)(win_w + 7) >> 3;
   const uint32_t tiles_y = (uint32_t)(P.n_rows + 7) >> 3;
@@ -292,6 +385,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
   unsigned long long u_hist = 0;
   uint32_t u_tail_steps = 0, u_bounce_steps = 0, u_start_steps = 0; // SHADE steps in which the sub-body ran (booked by its first lane)
   uint32_t u_node_it = 0, u_tri_it = 0; // loop iterations inside NODE / TRI steps (one lane of the wave books each)
+  uint32_t u_hint_fresh = 0, u_hint_dropped = 0, u_hint_empty = 0, u_hint_steps = 0; // leaf hints: consulted, triangles dropped, leaves dropped whole, TRI steps with a consultation
   unsigned long long cyc_node = 0, cyc_tri = 0, cyc_shade = 0, cyc_t0 = 0, cyc_s = 0;
   unsigned long long cyc_sub[6] = {0, 0, 0, 0, 0, 0};
 #define MGPU_TICK() (cyc_t0 = clock64())
@@ -310,10 +404,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
 #endif
   for (;;) {
     const unsigned long long mN = __ballot(st == ST_NODE);
-    const unsigned long long mT = __ballot(st == ST_TRI);
+    const unsigned long long mT0 = __ballot(st == ST_TRI);
     const unsigned long long mS = __ballot(st == ST_SHADE);
-    const int cN = __popcll(mN), cT = __popcll(mT), cS = __popcll(mS);
-    if ((cN | cT | cS) == 0) break;
+    const int cN = __popcll(mN), cT0 = __popcll(mT0), cS = __popcll(mS);
+    if ((cN | cT0 | cS) == 0) break;
 #ifdef MGPU_UTIL
     if (cyc_dry) ++dry_steps;
 #endif
@@ -322,8 +416,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
     // MGPU_SHADE_MIN lanes have a ray to finish, or MGPU_START_FORCE lanes are parked between paths, or nothing else is
     // runnable; otherwise NODE runs unless TRI has several times more lanes waiting (MGPU_NODE_WEIGHT_*).
     const int cReal = __popcll(__ballot(st == ST_SHADE && have_ray)); // lanes with a ray to finish (not parked between paths)
-    const bool run_shade = (cReal >= MGPU_SHADE_MIN) || (cN == 0 && cT == 0) || (cS - cReal >= (PRIM ? MGPU_START_FORCE_PRIM : (LDS_SCENE ? MGPU_START_FORCE_LDS : MGPU_START_FORCE_HBM)));
-    if (!run_shade && cN * (LDS_SCENE ? MGPU_NODE_WEIGHT_LDS : MGPU_NODE_WEIGHT_HBM) >= cT * (LDS_SCENE ? MGPU_TRI_WEIGHT_LDS : MGPU_TRI_WEIGHT_HBM)) {
+    const bool run_shade = (cReal >= MGPU_SHADE_MIN) || (cN == 0 && cT0 == 0) || (cS - cReal >= (PRIM ? MGPU_START_FORCE_PRIM : (LDS_SCENE ? MGPU_START_FORCE_LDS : MGPU_START_FORCE_HBM)));
+    if (!run_shade && cN * (LDS_SCENE ? MGPU_NODE_WEIGHT_LDS : MGPU_NODE_WEIGHT_HBM) >= cT0 * (LDS_SCENE ? MGPU_TRI_WEIGHT_LDS : MGPU_TRI_WEIGHT_HBM)) {
       // ================================ NODE step ================================
       MGPU_TICK();
       const bool all_plain = __ballot(st == ST_NODE && !ray_plain) == 0ull; // wave-uniform
@@ -375,6 +469,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
               } else if (meta.z != 0) {
                 tri_cur = (uint32_t)meta.w;
                 tri_end = (uint32_t)meta.w + (uint32_t)meta.z;
+                if (LDS_SCENE && MGPU_LEAF_HINTS) tri_end += (uint32_t)meta.y; // (hint + 1) << 16 or 0: taken off when the TRI work starts
                 st = ST_TRI;
               }
             }
@@ -407,10 +502,46 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
       // ================================ TRI step =================================
       MGPU_TICK();
       bool shared_done = false;
+      unsigned long long mT = mT0;
+      int cT = cT0;
+      if (LDS_SCENE && MGPU_LEAF_HINTS) { // leaves opened since the last TRI step: the hint's two boxes (see lds_hints above)
+        const bool fresh = st == ST_TRI && (tri_end >> 16) != 0u;
+        if (__ballot(fresh) != 0ull) {
+          if (fresh) {
+            const unsigned char *hp = lds_hints + (size_t)((tri_end >> 16) - 1u) * 64;
+            tri_end &= 0xFFFFu;
+            if (ray_plain) {
+              const float4 f0 = *reinterpret_cast<const float4 *>(hp), f1 = *reinterpret_cast<const float4 *>(hp + 16),
+                           f2 = *reinterpret_cast<const float4 *>(hp + 32);
+              const uint32_t m = *reinterpret_cast<const uint32_t *>(hp + 48);
+              const bool sx = (sgn & 1u) != 0u, sy = (sgn & 2u) != 0u, sz = (sgn & 4u) != 0u;
+              const bool hA = slab_hit<true>(make_double2((double)f0.x, (double)f0.y), make_double2((double)f0.z, (double)f0.w),
+                                             make_double2((double)f1.x, (double)f1.y), org, ix, iy, iz, sx, sy, sz, bt);
+              const bool hB = slab_hit<true>(make_double2((double)f1.z, (double)f1.w), make_double2((double)f2.x, (double)f2.y),
+                                             make_double2((double)f2.z, (double)f2.w), org, ix, iy, iz, sx, sy, sz, bt);
+              const uint32_t whole = tri_end - tri_cur, mid = tri_cur + m;
+              if (!hB) tri_end = mid;
+              if (!hA) tri_cur = hB ? mid : tri_end;
+              n_tris += whole - (tri_end - tri_cur); // the tests the reference makes on the dropped part
+#ifdef MGPU_UTIL
+              u_hint_fresh++;
+              u_hint_dropped += whole - (tri_end - tri_cur);
+              if (tri_cur == tri_end) u_hint_empty++;
+#endif
+            }
+            if (tri_cur == tri_end) st = sp < 0 ? ST_SHADE : ST_NODE; // nothing left of the leaf
+          }
+#ifdef MGPU_UTIL
+          if (lane == __ffsll((long long)__ballot(1)) - 1) u_hint_steps++;
+#endif
+          mT = __ballot(st == ST_TRI);
+          cT = __popcll(mT);
+        }
+      }
       const bool occ_sample = occ_sampled();
       const uint32_t occ_t0 = MGPU_OCC ? tri_cur : 0u;
 #if MGPU_SHARED_LEAVES
-      if (cT <= 32) { // mgpu_device.hpp, shared_leaves_step: 2, 4 (or 8) lanes per open leaf
+      if (cT != 0 && cT <= 32) { // mgpu_device.hpp, shared_leaves_step: 2, 4 (or 8) lanes per open leaf
         uint32_t my_trips = 0;
         shared_done = shared_leaves_step<LDS_SCENE, MGPU_TRIS_PER_STEP>(mT, cT, cT <= MGPU_SHARE8_MAX ? 3 : (cT <= 16 ? 2 : 1), lane,
                                                                        s_owner + wave * 64, st == ST_TRI, lds_tris, sc.tris, org, dir,
@@ -679,7 +810,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
       // ---- (2) path hand-out, executed by the whole wave (cursor variables are wave-uniform) ----
       // deferred start: with few lanes asking for a new path while others still traverse, the lanes stay parked (state
       // SHADE, no ray) and the path-start body runs later for more of them at once
-      const bool defer = !exhausted && (cN + cT) > 0 && __popcll(__ballot(want_pixel)) < (PRIM ? MGPU_START_MIN_PRIM : (LDS_SCENE ? MGPU_START_MIN_LDS : MGPU_START_MIN_HBM));
+      const bool defer = !exhausted && (cN + cT0) > 0 && __popcll(__ballot(want_pixel)) < (PRIM ? MGPU_START_MIN_PRIM : (LDS_SCENE ? MGPU_START_MIN_LDS : MGPU_START_MIN_HBM));
       for (;;) {
         const unsigned long long want = __ballot(want_pixel);
         if (!want || exhausted || defer) break;
@@ -951,6 +1082,19 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
       s_start += __shfl_down(s_start, off);
       c_tail += __shfl_down(c_tail, off);
       c_bounce += __shfl_down(c_bounce, off);
+    }
+    {
+      unsigned long long h0 = u_hint_fresh, h1 = u_hint_dropped, h2 = u_hint_empty, h3 = u_hint_steps;
+      for (int off = 32; off; off >>= 1) {
+        h0 += __shfl_down(h0, off);
+        h1 += __shfl_down(h1, off);
+        h2 += __shfl_down(h2, off);
+        h3 += __shfl_down(h3, off);
+      }
+      if (lane == 0) {
+        atomicAdd(&P.stats[6], h0 | (h3 << 32));
+        atomicAdd(&P.stats[7], h1 | (h2 << 32));
+      }
     }
     if (lane == 0) {
       atomicAdd(&P.stats[kUtilNodeSteps], a);

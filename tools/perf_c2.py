@@ -27,6 +27,10 @@ if os.environ.get("UTIL"):
     print("  inner loops: NODE %d iterations (%.2f per step, %.1f of 64 lanes busy per iteration), TRI %d iterations (%.2f per step, %.1f lanes); SHADE steps %d with %.1f lanes" % (
         nl, nl / max(1, ns), st["nodes"] / max(1, nl), tl, tl / max(1, ts_), st["tris"] / max(1, tl), outer, shl / max(1, outer)))
     print("  per outer iter: node steps %.2f (ideal %.2f)  tri steps %.2f (ideal %.2f)" % (ns / outer, st["nodes"] / 64 / outer, ts_ / outer, st["tris"] / 64 / outer))
+    if int(w[6]):
+        hf, hs, hd, he = int(w[6]) & 0xffffffff, int(w[6]) >> 32, int(w[7]) & 0xffffffff, int(w[7]) >> 32
+        print("  leaf hints: consulted for %d leaves (%.2f per ray) in %d TRI steps, dropped %d triangle tests (%.2f per ray, %.1f per consulted leaf), %d leaves dropped whole (%.1f%%)" % (
+            hf, hf / st["real_rays"], hs, hd, hd / st["real_rays"], hd / max(1, hf), he, 100.0 * he / max(1, hf)))
     cn, ct, cs = [int(x) for x in w[16:19]]
     cb, nb = 0, 0
     hb = [int(x) for x in w[28:32]]
