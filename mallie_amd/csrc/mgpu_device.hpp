@@ -294,6 +294,87 @@ template <int CAP, bool OVF = true> struct Stack {
   }
 };
 
+// ---- leaf hints ------------------------------------------------------------------------------------------------------
+// TestLeafNode (bvh_accel.cc:640-697) runs TriangleIsect on every triangle of a leaf whose box the ray hits -- up to 15 of them,
+// 7.9 per ray on cornellbox_suzanne, one or none of which is hit.  For a leaf of some size the run [first, first + n) of its
+// triangles is split at the m that minimises area(box of the first m) * m + area(box of the rest) * (n - m) -- the ORDER of the
+// run is the reference's and stays -- and both boxes are kept, padded and rounded outward to float, with m (16 floats: box A
+// lo / hi, box B lo / hi, m as bits, 3 unused).  When a lane's TRI work on the leaf starts it tests its ray against the two boxes once
+// (the kernel's own slab test, in double) and drops the part of the run whose box the ray misses or enters beyond the best t:
+// those triangles cannot be hit, and dropping a prefix or a suffix leaves the order of the remaining tests -- hence every
+// `t > tBest` decision and the tie rule -- as it was.  Dropped triangles are booked as the tests the reference makes.
+// Why a dropped triangle cannot be one TriangleIsect accepts: it accepts only rays through the triangle with 0 <= t <= best t,
+// up to its own rounding: ~1e-15 of the operands, and up to ~4e-3 of the triangle's size for a ray within 1e-12 rad of its plane
+// (|det| down to the reference's 1024 eps).  The boxes are padded by 2^-8 of their largest extent plus 2^-20 of their largest
+// |coordinate|, which exceeds both and every rounding of the slab products; rays that are not plain (an infinite or NaN product
+// possible, see slab_t) never consult a hint.
+// tri(k) -> pointer to the 9 doubles p0, e1, e2 of the run's k-th triangle.  Returns false when the best split saves less than
+// (1 - worth) of the expected tests (then it is not worth its two box tests).
+template <typename TriFn>
+__device__ __forceinline__ bool leaf_hint_make(TriFn tri, uint32_t n, double worth, float *rec) {
+  auto grow = [&](uint32_t k, double *lo, double *hi) { // += the k-th triangle: p0, p0 + e1, p0 + e2
+    const double *tp = tri(k);
+    for (int a = 0; a < 3; ++a) {
+      const double p = tp[a], q = tp[a] + tp[3 + a], r = tp[a] + tp[6 + a];
+      lo[a] = fmin(lo[a], fmin(p, fmin(q, r)));
+      hi[a] = fmax(hi[a], fmax(p, fmax(q, r)));
+    }
+  };
+  auto half_area = [](const double *lo, const double *hi) {
+    const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+  };
+  const double inf = __builtin_inf();
+  double best = inf, whole = 0.0;
+  uint32_t best_m = 0u;
+  double alo[3] = {inf, inf, inf}, ahi[3] = {-inf, -inf, -inf};
+  for (uint32_t m = 1; m <= n; ++m) {
+    grow(m - 1, alo, ahi);
+    if (m == n) {
+      whole = half_area(alo, ahi) * (double)n;
+      break;
+    }
+    double blo[3] = {inf, inf, inf}, bhi[3] = {-inf, -inf, -inf};
+    for (uint32_t k = m; k < n; ++k) grow(k, blo, bhi);
+    const double c = half_area(alo, ahi) * (double)m + half_area(blo, bhi) * (double)(n - m);
+    if (c < best) {
+      best = c;
+      best_m = m;
+    }
+  }
+  if (best_m == 0u || !(best < worth * whole)) return false; // (NaN boxes: no hint)
+  for (int part = 0; part < 2; ++part) {
+    double lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+    for (uint32_t k = part ? best_m : 0u; k < (part ? n : best_m); ++k) grow(k, lo, hi);
+    double ext = 0.0, big = 0.0;
+    for (int a = 0; a < 3; ++a) {
+      ext = fmax(ext, hi[a] - lo[a]);
+      big = fmax(big, fmax(fabs(lo[a]), fabs(hi[a])));
+    }
+    const double pad = ext * 0x1p-8 + big * 0x1p-20;
+    for (int a = 0; a < 3; ++a) {
+      rec[6 * part + a] = __double2float_rd(lo[a] - pad);
+      rec[6 * part + 3 + a] = __double2float_ru(hi[a] + pad);
+    }
+  }
+  rec[12] = __uint_as_float(best_m);
+  rec[13] = rec[14] = rec[15] = 0.0f;
+  return true;
+}
+// The consultation: [tri_cur, tri_end) = the leaf's whole run on entry, what is left of it on return; returns the number of
+// triangles dropped.  f0 .. f2 = the record's first 12 floats, m = its 13th as bits.  For a plain ray only.
+__device__ __forceinline__ uint32_t leaf_hint_apply(float4 f0, float4 f1, float4 f2, uint32_t m, V3 org, double ix, double iy, double iz,
+                                                    double bt, uint32_t &tri_cur, uint32_t &tri_end) {
+  const bool hA = slab_hit<true>(make_double2((double)f0.x, (double)f0.y), make_double2((double)f0.z, (double)f0.w),
+                                 make_double2((double)f1.x, (double)f1.y), org, ix, iy, iz, false, false, false, bt);
+  const bool hB = slab_hit<true>(make_double2((double)f1.z, (double)f1.w), make_double2((double)f2.x, (double)f2.y),
+                                 make_double2((double)f2.z, (double)f2.w), org, ix, iy, iz, false, false, false, bt);
+  const uint32_t whole = tri_end - tri_cur, mid = tri_cur + m;
+  if (!hB) tri_end = mid;
+  if (!hA) tri_cur = hB ? mid : tri_end;
+  return whole - (tri_end - tri_cur);
+}
+
 // ---- wide traversal (BVH in HBM) ------------------------------------------------------------------------------------
 // BVHAccel::Traverse (bvh_accel.cc:805-834) pops a node, tests ITS box against the best t so far, and on a hit pushes the
 // far child, then the near child.  A visited node costs one dependent fetch that way, and with the tree in HBM the walk

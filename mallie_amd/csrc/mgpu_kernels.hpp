@@ -215,6 +215,16 @@ void launch_scene_layout(hipStream_t s, const double *verts, const uint32_t *fac
                          const uint32_t *matIDs, const double *fv_normals, size_t nf, DTri *tris, double *slot_normal);
 // WNode records of the wide traversal (nn + 1 of them, the last is the super root)
 void launch_wide_layout(hipStream_t s, const MgpuNode *nodes, size_t nn, WNode *out);
+// Leaf hints (mgpu_device.hpp, leaf_hint_make): on / off, the smallest leaf that gets one, and what a split must save
+#ifndef MGPU_LEAF_HINTS
+#define MGPU_LEAF_HINTS 1 // LDS-resident scene: two sub-boxes per large leaf, tested once when the leaf's TRI work starts (kHintMinTris)
+#endif
+#ifndef MGPU_HINT_MIN
+#define MGPU_HINT_MIN 4 // (8: 5.23-5.28, 6: 5.21-5.25, 4: 5.21 ms on C2; 12: 5.38; without hints 5.38-5.44)
+#endif
+#ifndef MGPU_HINT_WORTH
+#define MGPU_HINT_WORTH 0.85 // (0.7: 5.32-5.35, 0.95: 5.21-5.24)
+#endif
 #ifndef MGPU_WIDE_STACK_LDS
 #define MGPU_WIDE_STACK_LDS 8 // (6 / 5 measured in round 3 with the treelet grown into the freed LDS: within 2 % either way)
 #endif

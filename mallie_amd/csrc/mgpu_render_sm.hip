@@ -78,6 +78,9 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 #ifndef MGPU_SHARE8_MAX
 #define MGPU_SHARE8_MAX 0 // open leaves up to which 8 lanes share one (0: never)
 #endif
+#ifndef MGPU_SHARE4_MAX
+#define MGPU_SHARE4_MAX 16 // ... up to which 4 lanes share one (above: 2)
+#endif
 #ifndef MGPU_SHADE_MIN
 #define MGPU_SHADE_MIN 36
 #endif
@@ -104,15 +107,6 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 #ifndef MGPU_TAIL_TABLE
 #define MGPU_TAIL_TABLE 1
 #endif
-#ifndef MGPU_LEAF_HINTS
-#define MGPU_LEAF_HINTS 1 // LDS-resident scene: two sub-boxes per large leaf, tested once when the leaf's TRI work starts (kHintMinTris)
-#endif
-#ifndef MGPU_HINT_MIN
-#define MGPU_HINT_MIN 4 // (8: 5.23-5.28, 6: 5.21-5.25, 4: 5.21 ms on C2; 12: 5.38; without hints 5.38-5.44)
-#endif
-#ifndef MGPU_HINT_WORTH
-#define MGPU_HINT_WORTH 0.85 // (0.7: 5.32-5.35, 0.95: 5.21-5.24)
-#endif
 #ifndef MGPU_TAIL_RECIP
 #define MGPU_TAIL_RECIP 1
 #endif
@@ -129,7 +123,7 @@ enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
 #define MGPU_SHARED_LEAVES 1
 #endif
 #ifndef MGPU_TRIS_PER_STEP
-#define MGPU_TRIS_PER_STEP 16
+#define MGPU_TRIS_PER_STEP 8 // trips of a TRI step (with leaf hints: 16: 5.22-5.25, 8: 5.12-5.14, 6: 5.24-5.26, 4: 5.10-5.13, 3: 5.29, 2: 5.24-5.26 ms on C2; teapot / 1 M grid 4.63 / 4.52, 4.59 / 4.50 at 8, 4.63 / 4.54 at 4)
 #endif
 #ifndef MGPU_SM_MIN_WAVES
 #define MGPU_SM_MIN_WAVES 4
@@ -209,20 +203,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
     uint32_t s[4];
   };
   PrimRay *s_prim = reinterpret_cast<PrimRay *>(const_cast<unsigned char *>(lds_tris) + (((size_t)P.lds_tris_bytes + 15) & ~(size_t)15)) + (size_t)wave * 64;
-  // Leaf hints (LDS-resident scene, P.lds_hint_cap records of 64 bytes behind the staging above).  TestLeafNode
-  // (bvh_accel.cc:640-697) runs TriangleIsect on every triangle of a leaf whose box the ray hits -- up to 15 of them, 7.9 per ray
-  // on cornellbox_suzanne, one or none of which is hit.  For a leaf of kHintMinTris or more triangles the prologue splits the
-  // leaf's run [first, first + n) at the m that minimises area(box of the first m) * m + area(box of the rest) * (n - m) -- the
-  // ORDER of the run is the reference's and stays -- and keeps both boxes, padded and rounded outward to float, plus m.  When a
-  // lane's TRI work on the leaf starts, it tests its ray against the two boxes once (the kernel's own slab test, in double) and
-  // drops the part of the run whose box the ray misses (or enters beyond the best t): those triangles cannot be hit, and
-  // dropping a prefix or a suffix leaves the order of the remaining tests -- hence every `t > tBest` decision and the tie rule --
-  // as it was.  Dropped triangles are booked in n_tris as the tests the reference makes.
-  // Why a dropped triangle cannot be one TriangleIsect accepts: it accepts only rays through the triangle with 0 <= t <= best t,
-  // up to its own rounding: ~1e-15 of the operands, and up to ~4e-3 of the triangle's size for a ray within 1e-12 rad of its
-  // plane (|det| down to the reference's 1024 eps).  The boxes are padded by 2^-8 of their largest extent plus 2^-20 of the
-  // largest |coordinate|, which exceeds both and every rounding of the slab products; rays that are not `ray_plain` (an
-  // infinite or NaN product possible) never consult a hint.
+  // Leaf hints (mgpu_device.hpp, leaf_hint_make).  LDS-resident scene: P.lds_hint_cap records of 64 bytes behind the staging above,
+  // made here from the LDS copy of the triangles; a leaf's axis field (unused by the reference's traversal) becomes (hint + 1) << 16,
+  // which the NODE step adds to tri_end when it opens the leaf (slots of an LDS-resident scene stay below 2^16).  (For the
+  // HBM-resident scene -- records made when the scene is created, found through packed leaf tags -- the record is one more
+  // dependent fetch in front of every TRI step: built, exact, 2-4 % slower; profiles/experiments/leaf_hints_hbm.diff.txt.)
   constexpr uint32_t kHintMinTris = MGPU_HINT_MIN;
   unsigned char *lds_hints = reinterpret_cast<unsigned char *>(s_prim - (size_t)wave * 64) + (PRIM ? (size_t)kWaves * 64 * sizeof(PrimRay) : 0);
   if (LDS_SCENE && MGPU_LEAF_HINTS) {
@@ -233,58 +218,16 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
     for (uint32_t i = threadIdx.x; i < nn_lds; i += BLOCK) {
       uint32_t *nd = reinterpret_cast<uint32_t *>(const_cast<unsigned char *>(lds_nodes) + (size_t)i * 64);
       if (nd[12] == 0u) continue; // interior node: its axis field is the split axis
-      uint32_t code = 0u; // a leaf's axis field (unused by the reference's traversal) becomes (hint + 1) << 16
+      uint32_t code = 0u;
       const uint32_t n = nd[14], first = nd[15];
       if (P.lds_hint_cap != 0u && n >= kHintMinTris && n <= 64u) {
-        auto grow = [&](uint32_t k, double *lo, double *hi) { // += the k-th triangle of the run: p0, p0 + e1, p0 + e2
-          const double *tp = reinterpret_cast<const double *>(lds_tris + (size_t)(first + k) * 80);
-          for (int a = 0; a < 3; ++a) {
-            const double p = tp[a], q = tp[a] + tp[3 + a], r = tp[a] + tp[6 + a];
-            lo[a] = fmin(lo[a], fmin(p, fmin(q, r)));
-            hi[a] = fmax(hi[a], fmax(p, fmax(q, r)));
-          }
-        };
-        auto half_area = [](const double *lo, const double *hi) {
-          const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-          return dx * dy + dy * dz + dz * dx;
-        };
-        const double inf = __builtin_inf();
-        double best = inf, whole = 0.0;
-        uint32_t best_m = 0u;
-        double alo[3] = {inf, inf, inf}, ahi[3] = {-inf, -inf, -inf};
-        for (uint32_t m = 1; m <= n; ++m) {
-          grow(m - 1, alo, ahi);
-          if (m == n) {
-            whole = half_area(alo, ahi) * (double)n;
-            break;
-          }
-          double blo[3] = {inf, inf, inf}, bhi[3] = {-inf, -inf, -inf};
-          for (uint32_t k = m; k < n; ++k) grow(k, blo, bhi);
-          const double c = half_area(alo, ahi) * (double)m + half_area(blo, bhi) * (double)(n - m);
-          if (c < best) {
-            best = c;
-            best_m = m;
-          }
-        }
-        if (best_m != 0u && best < MGPU_HINT_WORTH * whole) { // (a split that saves less than 15 % of the expected tests is not worth its two box tests)
+        float rec[16];
+        if (leaf_hint_make([&](uint32_t k) { return reinterpret_cast<const double *>(lds_tris + (size_t)(first + k) * 80); }, n,
+                           (double)MGPU_HINT_WORTH, rec)) {
           const uint32_t h = atomicAdd(&s_nhints, 1u);
           if (h < P.lds_hint_cap) {
-            float *rec = reinterpret_cast<float *>(lds_hints + (size_t)h * 64);
-            for (int part = 0; part < 2; ++part) {
-              double lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
-              for (uint32_t k = part ? best_m : 0u; k < (part ? n : best_m); ++k) grow(k, lo, hi);
-              double ext = 0.0, big = 0.0;
-              for (int a = 0; a < 3; ++a) {
-                ext = fmax(ext, hi[a] - lo[a]);
-                big = fmax(big, fmax(fabs(lo[a]), fabs(hi[a])));
-              }
-              const double pad = ext * 0x1p-8 + big * 0x1p-20;
-              for (int a = 0; a < 3; ++a) {
-                rec[6 * part + a] = __double2float_rd(lo[a] - pad);
-                rec[6 * part + 3 + a] = __double2float_ru(hi[a] + pad);
-              }
-            }
-            reinterpret_cast<uint32_t *>(rec)[12] = best_m;
+            float *dst = reinterpret_cast<float *>(lds_hints + (size_t)h * 64);
+            for (int k = 0; k < 16; ++k) dst[k] = rec[k];
             code = (h + 1u) << 16;
           }
         }
@@ -504,28 +447,21 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
       bool shared_done = false;
       unsigned long long mT = mT0;
       int cT = cT0;
-      if (LDS_SCENE && MGPU_LEAF_HINTS) { // leaves opened since the last TRI step: the hint's two boxes (see lds_hints above)
+      if (LDS_SCENE && MGPU_LEAF_HINTS) { // leaves opened since the last TRI step: their hints (mgpu_device.hpp, leaf_hint_make)
         const bool fresh = st == ST_TRI && (tri_end >> 16) != 0u;
         if (__ballot(fresh) != 0ull) {
           if (fresh) {
-            const unsigned char *hp = lds_hints + (size_t)((tri_end >> 16) - 1u) * 64;
+            const float *hp = reinterpret_cast<const float *>(lds_hints + (size_t)((tri_end >> 16) - 1u) * 64);
             tri_end &= 0xFFFFu;
             if (ray_plain) {
-              const float4 f0 = *reinterpret_cast<const float4 *>(hp), f1 = *reinterpret_cast<const float4 *>(hp + 16),
-                           f2 = *reinterpret_cast<const float4 *>(hp + 32);
-              const uint32_t m = *reinterpret_cast<const uint32_t *>(hp + 48);
-              const bool sx = (sgn & 1u) != 0u, sy = (sgn & 2u) != 0u, sz = (sgn & 4u) != 0u;
-              const bool hA = slab_hit<true>(make_double2((double)f0.x, (double)f0.y), make_double2((double)f0.z, (double)f0.w),
-                                             make_double2((double)f1.x, (double)f1.y), org, ix, iy, iz, sx, sy, sz, bt);
-              const bool hB = slab_hit<true>(make_double2((double)f1.z, (double)f1.w), make_double2((double)f2.x, (double)f2.y),
-                                             make_double2((double)f2.z, (double)f2.w), org, ix, iy, iz, sx, sy, sz, bt);
-              const uint32_t whole = tri_end - tri_cur, mid = tri_cur + m;
-              if (!hB) tri_end = mid;
-              if (!hA) tri_cur = hB ? mid : tri_end;
-              n_tris += whole - (tri_end - tri_cur); // the tests the reference makes on the dropped part
+              const float4 f0 = *reinterpret_cast<const float4 *>(hp), f1 = *reinterpret_cast<const float4 *>(hp + 4),
+                           f2 = *reinterpret_cast<const float4 *>(hp + 8);
+              const uint32_t m = __float_as_uint(hp[12]);
+              const uint32_t dropped = leaf_hint_apply(f0, f1, f2, m, org, ix, iy, iz, bt, tri_cur, tri_end);
+              n_tris += dropped; // the tests the reference makes on the dropped part
 #ifdef MGPU_UTIL
               u_hint_fresh++;
-              u_hint_dropped += whole - (tri_end - tri_cur);
+              u_hint_dropped += dropped;
               if (tri_cur == tri_end) u_hint_empty++;
 #endif
             }
@@ -543,7 +479,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
 #if MGPU_SHARED_LEAVES
       if (cT != 0 && cT <= 32) { // mgpu_device.hpp, shared_leaves_step: 2, 4 (or 8) lanes per open leaf
         uint32_t my_trips = 0;
-        shared_done = shared_leaves_step<LDS_SCENE, MGPU_TRIS_PER_STEP>(mT, cT, cT <= MGPU_SHARE8_MAX ? 3 : (cT <= 16 ? 2 : 1), lane,
+        shared_done = shared_leaves_step<LDS_SCENE, MGPU_TRIS_PER_STEP>(mT, cT, cT <= MGPU_SHARE8_MAX ? 3 : (cT <= MGPU_SHARE4_MAX ? 2 : 1), lane,
                                                                        s_owner + wave * 64, st == ST_TRI, lds_tris, sc.tris, org, dir,
                                                                        tri_cur, tri_end, bt, bu, bv, bslot, n_tris, my_trips);
         if (shared_done && occ_sample) occ_book(my_trips, MGPU_TRIS_PER_STEP, 2);
