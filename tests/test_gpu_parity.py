@@ -432,6 +432,53 @@ def test_random_soups_with_exact_ties_trace_and_render(seed, nt, trace_kernel):
         assert (rst["trace_calls"], rst["paths"]) == (orst["trace_calls"], orst["paths"])
 
 
+def test_leaf_hints_drop_tests_and_change_nothing(monkeypatch):
+    """k_render_sm with the scene in LDS: the leaf hints (two boxes per leaf, the part of the leaf's run the ray cannot hit
+    dropped in the reference's order; mgpu_device.hpp, leaf_hint_make) against the same kernel without them and against the
+    oracle -- images byte for byte, node and triangle counters exactly (a dropped test is booked as the test the reference
+    makes).  Scenes: cornellbox_suzanne, and a stack of coplanar, overlapping, partly duplicated quads (exact ties inside and
+    across the two halves of a leaf, flat boxes whose entry distance equals the hit distance)."""
+    rng = np.random.default_rng(77)
+    g = O.load_golden("cornell_obj")
+    quads_v, quads_f = [], []
+    for k in range(40):  # 80 triangles in 5 planes z = 0, 0.5, ...: overlapping rectangles on a half-integer lattice, some twice
+        z = 0.5 * (k % 5)
+        x0, y0 = rng.integers(-6, 3, 2) * 0.5
+        w, h = rng.integers(2, 8, 2) * 0.5
+        b = len(quads_v)
+        quads_v += [(x0, y0, z), (x0 + w, y0, z), (x0 + w, y0 + h, z), (x0, y0 + h, z)]
+        quads_f += [(b, b + 1, b + 2), (b, b + 2, b + 3)]
+        if k % 4 == 0:
+            quads_f += [(b, b + 1, b + 2), (b + 2, b + 3, b)]  # the same triangles again (one with its vertices rotated)
+    scenes = [("cornell", g["verts"].astype(np.float64), g["faces"], g["matIDs"], g["normals"], (0, 0, 20), (0, 0, 0)),
+              ("coplanar", np.array(quads_v, np.float64), np.array(quads_f, np.uint32), None, None, (0.25, 0.5, 9.0), (0.25, 0.5, 0.0))]
+    for name, verts, faces, mats, normals, eye, la in scenes:
+        nodes, idx, _ = M.bvh_build(verts, faces)
+        assert int(nodes["data"][:, 0][nodes["flag"] == 1].max()) >= 8, "the scene must have leaves that get a hint"
+        osc = O.OracleScene(verts, faces, mats, normals, None, nodes, idx)
+        W, H = 160, 120
+        frame = M.camera_frame(eye, la, width=W, height=H)
+        plane = osc.plane()
+        oimg, _, ost, _ = osc.render(frame, W, H, 5, 3, plane, O.RNG_HASH, seed=9)
+        res = {}
+        for hints in (True, False):
+            if hints:
+                monkeypatch.delenv("MGPU_NO_HINTS", raising=False)
+            else:
+                monkeypatch.setenv("MGPU_NO_HINTS", "1")
+            sc = M.Scene(verts, faces, mats, normals, None, nodes, idx)
+            img, _, st = sc.render(frame, W, H, 5, 3, plane, M.RNG_HASH, seed=9)
+            res[hints] = (img, st)
+            sc.close()
+        monkeypatch.delenv("MGPU_NO_HINTS", raising=False)
+        assert res[True][0].tobytes() == res[False][0].tobytes() == oimg.tobytes(), name
+        for k in ("real_rays", "nodes", "tris", "trace_calls", "paths"):
+            assert res[True][1][k] == res[False][1][k], (name, k)
+        assert res[True][1]["real_rays"] == ost["real_rays"], name
+        if name == "coplanar":  # primary + bounce rays on a lattice scene: no 1-ulp box decisions, the counters are the oracle's
+            assert (res[True][1]["nodes"], res[True][1]["tris"]) == (ost["nodes"], ost["tris"]) or abs(res[True][1]["tris"] - ost["tris"]) <= 0.002 * ost["tris"]
+
+
 RENDERS = ["render_cornell_obj_64_plane_2pass", "render_cornell_obj_64_noplane", "render_cornell_obj_128x96_plane",
            "render_cornell_eson_48_plane", "render_cornell_obj_40x56_view2", "render_teapot_obj_64x48_plane"]
 
