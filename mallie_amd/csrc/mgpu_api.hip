@@ -1251,7 +1251,9 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
       prim = render_sm_prim_bytes() != 0 && shmem + render_sm_prim_bytes() <= kLdsBudget && !getenv("MGPU_NO_PRIM");
       if (prim) shmem += render_sm_prim_bytes();
       // ... and behind that the leaf hints (mgpu_render_sm.hip, kHintMinTris): one 64-byte record per leaf at most
-      if (!getenv("MGPU_NO_HINTS")) lds_hint_cap = std::min<size_t>((kLdsBudget - shmem) / 64, ((size_t)s->nn + 1) / 2);
+      // (the record's number rides in the upper half of tri_end: slots and records of a scene that fits LDS stay far below 2^16)
+      if (!getenv("MGPU_NO_HINTS") && s->nf < 0x10000u)
+        lds_hint_cap = std::min<size_t>(std::min<size_t>((kLdsBudget - shmem) / 64, ((size_t)s->nn + 1) / 2), 0xFFFEu);
       shmem += lds_hint_cap * 64;
     }
   }
@@ -1334,13 +1336,17 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
   if (tiles >= ((uint64_t)1 << 28)) return fail(MGPU_ERR_INVALID, "window too large: %llu tiles", (unsigned long long)tiles);
   int group = passes;
   int fpl = 1; // frames per launch
+  // a scene of grey materials renders three equal channels (k_render_sm<GREY>): its planes hold ONE float per pixel and pass, and
+  // k_accumulate_tiled writes the sum to the three channels -- the same float additions per channel, a third of the plane traffic
+  const bool mono_planes = (kern == 1 || kern == 2) && dsc.grey != 0;
+  size_t plane_floats = 0;
   if (kern != 0 && passes > 1) {
     // 8 GiB: the 64 passes of the 3840x2160 configuration (6.4 GB) fit one launch.  Every launch ends with a drain (its last
     // paths finishing on a mostly idle GPU), so fewer, longer launches are faster: at 1 GiB the C5 frame took seven launches and
     // 272.5 ms, now one and 258.6; C3's 64 passes two launches and 18.0 ms, now one and 17.4.
     size_t budget = (size_t)8 << 30;
     if (const char *e = getenv("MGPU_PLANES_MAX_MB")) budget = (size_t)(atoll(e) < 1 ? 1 : atoll(e)) << 20;
-    const size_t plane_floats = (size_t)tiles * 192; // tile-major planes: 64 pixel slots per 8x8 tile (edge tiles padded)
+    plane_floats = (size_t)tiles * (mono_planes ? 64 : 192); // tile-major planes: 64 pixel slots per 8x8 tile (edge tiles padded)
     const size_t fit = budget / (plane_floats * sizeof(float));
     if ((size_t)group > fit) group = fit < 1 ? 1 : (int)fit;
     // the work cursor addresses (tile, pass) items with 28 bits per XCD part
@@ -1495,7 +1501,7 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
     if (kern == 0) return MGPU_OK;
     if (passes > 1) {
       const int last = passes - ((passes - 1) / group) * group;
-      launch_accumulate_tiled(st, R.p_planes, (size_t)tiles * 192, last, n_floats, win_w, d_image, d_count, passes > group);
+      launch_accumulate_tiled(st, R.p_planes, plane_floats, mono_planes, last, n_floats, win_w, d_image, d_count, passes > group);
       HIP_TRY(hipGetLastError());
     } else if (d_count) {
       launch_count_add(st, d_count, n_floats / 3, 1); // single pass: the kernel wrote the image itself
@@ -1511,7 +1517,7 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
       rc = launch_passes(nf * passes, (uint32_t)f0 * (uint32_t)passes);
       if (rc) return rc;
       for (int i = 0; i < nf; ++i) {
-        launch_accumulate_tiled(st, R.p_planes + (size_t)i * (size_t)passes * ((size_t)tiles * 192), (size_t)tiles * 192, passes, n_floats,
+        launch_accumulate_tiled(st, R.p_planes + (size_t)i * (size_t)passes * plane_floats, plane_floats, mono_planes, passes, n_floats,
                                 win_w, d_images[f0 + i], d_counts ? d_counts[f0 + i] : nullptr, false);
         HIP_TRY(hipGetLastError());
       }
@@ -1536,7 +1542,7 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
       rc = launch_passes(g, (uint32_t)f0 * (uint32_t)passes + (uint32_t)g0);
       if (rc) return rc;
       if (g0 + g < passes) { // not the last group: fold it into the image now, the planes are reused
-        launch_accumulate_tiled(st, R.p_planes, (size_t)tiles * 192, g, n_floats, win_w, d_image, d_count, g0 > 0);
+        launch_accumulate_tiled(st, R.p_planes, plane_floats, mono_planes, g, n_floats, win_w, d_image, d_count, g0 > 0);
         HIP_TRY(hipGetLastError());
       }
     }

@@ -205,8 +205,9 @@ hipError_t launch_trace_server(int cap, hipStream_t s, const DScene &sc, TraceMa
                                unsigned long long idle_ticks, unsigned long long life_ticks, unsigned long long max_polls,
                                uint32_t stage_nodes_bytes, uint32_t stage_tris_bytes); // != 0: the scene is copied into LDS
 void launch_count_add(hipStream_t s, int32_t *count, size_t npix, int passes); // single pass: count[px] += 1 only
-// pass accumulation from tile-major planes (k_render_sm with several passes): plane_stride = tiles * 192 floats
-void launch_accumulate_tiled(hipStream_t s, const float *planes, size_t plane_stride, int passes, size_t n_floats, int win_w,
+// pass accumulation from tile-major planes (k_render_sm with several passes): plane_stride = tiles * 192 floats, or tiles * 64 for
+// `mono` planes (one float per pixel: scenes of grey materials, whose three channels are equal)
+void launch_accumulate_tiled(hipStream_t s, const float *planes, size_t plane_stride, bool mono, int passes, size_t n_floats, int win_w,
                              float *image, int32_t *count, bool resume);
 // tile_order[0..n) = tile indices by descending cost (256 log buckets); zeroes cost[]. One workgroup.
 void launch_order_tiles(hipStream_t s, uint32_t *cost, uint32_t n_tiles, uint32_t *order);

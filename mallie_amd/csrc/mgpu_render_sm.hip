@@ -726,12 +726,18 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
             // Several passes: planes are TILE-major (a tile's 64 pixels = 768 contiguous bytes = six whole 128-byte lines that
             // only this (tile, pass) item writes; in image order a tile row is 96 bytes straddling lines shared with the
             // neighbouring tiles, i.e. with other waves on other XCDs, and HBM saw 2.1x the bytes).  One pass: the image itself.
-            float *dst = P.pass_stride ? P.out + (size_t)pass * P.pass_stride + ((size_t)(ly >> 3) * tiles_x + (lx >> 3)) * 192u +
-                                             (size_t)(((ly & 7u) << 3) + (lx & 7u)) * 3u
-                                       : P.out + 3 * ((size_t)ly * (size_t)win_w + lx);
-            dst[0] = (float)rad0;
-            dst[1] = (float)rad1;
-            dst[2] = (float)rad2;
+            // A GREY scene's three channels are equal: its planes hold one float per pixel (256 bytes per tile and pass), and
+            // k_accumulate_tiled writes the sum to the three channels.
+            if (GREY && P.pass_stride) {
+              P.out[(size_t)pass * P.pass_stride + ((size_t)(ly >> 3) * tiles_x + (lx >> 3)) * 64u + (size_t)(((ly & 7u) << 3) + (lx & 7u))] = (float)rad0;
+            } else {
+              float *dst = P.pass_stride ? P.out + (size_t)pass * P.pass_stride + ((size_t)(ly >> 3) * tiles_x + (lx >> 3)) * 192u +
+                                               (size_t)(((ly & 7u) << 3) + (lx & 7u)) * 3u
+                                         : P.out + 3 * ((size_t)ly * (size_t)win_w + lx);
+              dst[0] = (float)rad0;
+              dst[1] = (float)rad1;
+              dst[2] = (float)rad2;
+            }
             if (P.tile_cost && pass == 0) // what this path cost, for the next launch's hand-out order
               atomicAdd(P.tile_cost + ((ly >> 3) * tiles_x + (lx >> 3)), n_nodes + n_tris + 16u * n_rays - cost_base);
           }
@@ -1128,10 +1134,62 @@ __global__ __launch_bounds__(256) void k_accumulate_tiled(const float *__restric
   }
 }
 
-void launch_accumulate_tiled(hipStream_t s, const float *planes, size_t plane_stride, int passes, size_t n_floats, int win_w,
+// The same for planes of ONE float per pixel (grey scenes: the three channels of a pixel are equal in every pass, so their sums
+// are): 64 floats per tile, the sum written to the pixel's three channels.  VEC = 4: four pixels of a tile row = one float4 per
+// pass in, three float4 out.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_accumulate_tiled_mono(const float *__restrict__ planes, size_t plane_stride, int passes,
+                                                                uint32_t win_w, uint32_t n_rows, uint32_t tiles_x,
+                                                                float *__restrict__ image, int32_t *__restrict__ count, bool resume) {
+  const size_t p0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC; // float = pixel index inside a plane
+  if (p0 >= plane_stride) return;
+  const uint32_t tile = (uint32_t)(p0 >> 6), o = (uint32_t)(p0 & 63u);
+  const uint32_t r = o >> 3, c = o & 7u;
+  const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const uint32_t y = ty * 8u + r, x = tx * 8u + c;
+  if (y >= n_rows || x >= win_w) return; // padding of an edge tile
+  const size_t px = (size_t)y * win_w + x;
+  if (VEC == 4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (resume) {
+      const float4 i0 = *reinterpret_cast<const float4 *>(image + 3 * px), i1 = *reinterpret_cast<const float4 *>(image + 3 * px + 4),
+                   i2 = *reinterpret_cast<const float4 *>(image + 3 * px + 8);
+      acc = make_float4(i0.x, i0.w, i1.z, i2.y);
+    }
+    for (int p = 0; p < passes; ++p) {
+      const float4 v = *reinterpret_cast<const float4 *>(planes + (size_t)p * plane_stride + p0);
+      acc.x += v.x;
+      acc.y += v.y;
+      acc.z += v.z;
+      acc.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(image + 3 * px) = make_float4(acc.x, acc.x, acc.x, acc.y);
+    *reinterpret_cast<float4 *>(image + 3 * px + 4) = make_float4(acc.y, acc.y, acc.z, acc.z);
+    *reinterpret_cast<float4 *>(image + 3 * px + 8) = make_float4(acc.z, acc.w, acc.w, acc.w);
+    if (count)
+      for (uint32_t k = 0; k < 4; ++k) count[px + k] += passes;
+  } else {
+    float acc = resume ? image[3 * px] : 0.f;
+    for (int p = 0; p < passes; ++p) acc += planes[(size_t)p * plane_stride + p0];
+    image[3 * px] = image[3 * px + 1] = image[3 * px + 2] = acc;
+    if (count) count[px] += passes;
+  }
+}
+
+void launch_accumulate_tiled(hipStream_t s, const float *planes, size_t plane_stride, bool mono, int passes, size_t n_floats, int win_w,
                              float *image, int32_t *count, bool resume) {
   const uint32_t tiles_x = (uint32_t)(win_w + 7) >> 3;
   const uint32_t n_rows = (uint32_t)(n_floats / ((size_t)3 * win_w));
+  if (mono) {
+    if (win_w % 8 == 0 && ((uintptr_t)image & 15) == 0 && ((uintptr_t)planes & 15) == 0 && plane_stride % 4 == 0) {
+      hipLaunchKernelGGL(k_accumulate_tiled_mono<4>, dim3((unsigned)((plane_stride / 4 + 255) / 256)), dim3(256), 0, s, planes, plane_stride,
+                         passes, (uint32_t)win_w, n_rows, tiles_x, image, count, resume);
+    } else {
+      hipLaunchKernelGGL(k_accumulate_tiled_mono<1>, dim3((unsigned)((plane_stride + 255) / 256)), dim3(256), 0, s, planes, plane_stride,
+                         passes, (uint32_t)win_w, n_rows, tiles_x, image, count, resume);
+    }
+    return;
+  }
   if (win_w % 8 == 0 && ((uintptr_t)image & 15) == 0 && ((uintptr_t)planes & 15) == 0 && plane_stride % 4 == 0) {
     hipLaunchKernelGGL(k_accumulate_tiled<4>, dim3((unsigned)((plane_stride / 4 + 255) / 256)), dim3(256), 0, s, planes, plane_stride,
                        passes, (uint32_t)win_w, n_rows, tiles_x, image, count, resume);
