@@ -661,9 +661,10 @@ def main():
             if traffic and ksec > 0:
                 roof["hbm"] = {"measured_GBps": round(traffic / ksec / 1e9, 1), "frac_of_peak": round(traffic / ksec / 1e9 / HBM_PEAK_GBS, 4),
                                "fetch_bytes": int(2 * p["FETCH_SIZE"] * 1024), "write_bytes": int(p["WRITE_SIZE"] * 1024),
-                               "needed_write_bytes": int(12 * W * H * spp),
+                               "needed_write_bytes": int(4 * W * H * spp),
                                "note": "2*FETCH_SIZE + WRITE_SIZE per frame (one launch) of k_render_sm; needed_write = the per-pass radiance "
-                                       "planes it produces; WRITE_SIZE is uncalibrated on gfx950 (profiles/README.md)"}
+                                       "planes it produces (one float per pixel and pass: this scene's materials are grey, its three channels "
+                                       "equal; 12 bytes until round 4); WRITE_SIZE is uncalibrated on gfx950 (profiles/README.md)"}
         conf = {"workload": workloads.describe(cfg, n_tris) + "; 1 step = 1 frame = the next %d passes per pixel "
                             "(pass_base advances by %d per step)" % (spp, spp),
                 "parallelism": "replicated scene, interleaved 8-row strips x%d, 1 RCCL exchange/frame: %s" % (world, exchange)

@@ -57,8 +57,9 @@ for kern, ctr, d, known, what in (
         ("k_calib_read16", "FETCH_SIZE", "calib_fetch", GIB, "1 GiB streamed, 16 bytes per lane, coalesced"),
         ("k_calib_write16", "WRITE_SIZE", "calib_write", GIB, "1 GiB written, 16 bytes per lane, coalesced"),
         ("k_calib_write12", "WRITE_SIZE", "calib_write", 0.75 * GIB, "0.75 GiB written, three dwords per lane at 12-byte pitch"),
-        ("k_accumulate_tiled", "FETCH_SIZE", "acc_fetch", 16 * 12.0 * 1920 * 1080, "k_accumulate_tiled of a C2 frame: 16 planes of 24.9 MB read"),
-        ("k_accumulate_tiled", "WRITE_SIZE", "acc_write", 12.0 * 1920 * 1080, "k_accumulate_tiled of a C2 frame: the 24.9 MB image written")):
+        # (cornellbox_suzanne is a scene of grey materials: its planes hold one float per pixel and pass -- mgpu_api.hip, mono_planes)
+        ("k_accumulate_tiled", "FETCH_SIZE", "acc_fetch", 16 * 4.0 * 1920 * 1080, "k_accumulate_tiled_mono of a C2 frame: 16 planes of 8.3 MB read"),
+        ("k_accumulate_tiled", "WRITE_SIZE", "acc_write", 12.0 * 1920 * 1080, "k_accumulate_tiled_mono of a C2 frame: the 24.9 MB image written")):
     v, n = counter_sum(d, kern, ctr)
     if n:
         per = v / n * 1024.0  # KiB per launch -> bytes
