@@ -675,6 +675,10 @@ def main():
                              % (12e-6 * W * H, " and exchange" if world > 1 else "", host_frames_taken, args.steps)) if readback else "none: frames stay in HBM",
                 "rays_per_frame": int(rays / args.steps), "trace_calls_per_frame": int(trace_calls / args.steps),
                 "nodes_per_ray": round(nodes / rays, 3), "tris_per_ray": round(tris / rays, 3),
+                "work_counters": ("nodes / tris per ray = the reference's node pops and TriangleIsect calls (equal to the oracle's counters); with the "
+                                  "scene in LDS the leaf hints drop tests the ray cannot pass and book them as made -- on this workload 3.74 "
+                                  "of the 7.89 per ray (MGPU_UTIL build, DESIGN.md 4.1)") if key == "c2" else
+                                 "nodes / tris per ray = the reference's node pops and TriangleIsect calls (equal to the oracle's counters)",
                 "mtrace_calls_per_s": round(trace_calls / elapsed / 1e6, 2),
                 # what the multi-GPU machinery says about itself: communicator size read back from RCCL (ncclCommCount), the
                 # exchange step's device time per frame (HIP events on rank 0's communicator stream) and mean kernel time per
