@@ -98,6 +98,9 @@ struct MgpuScene {
   int stack_need = 1;  // entries a traversal can ever hold = tree_depth + 1
   int cap = 16;        // LDS stack entries per lane of the instantiated kernels
   double bmin[3], bmax[3];
+  // leaf hints (mgpu_device.hpp, leaf_hint_make): centre and half diagonal of the box of the vertices the faces use -- measured from
+  // the vertices, not taken from a caller's root node -- for scenes small enough to be rendered from LDS; hint_rho < 0: no hints
+  double hint_c[3] = {0, 0, 0}, hint_rho = -1.0;
   DScene d{};
   DScene d_created{}; // `d` as mgpu_scene_create left it (overflow columns null): what never changes afterwards.  The trace server
                       // launches from a caller's thread without host_mutex and must not read fields ensure_overflow rewrites
@@ -824,6 +827,33 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
   s->stack_need = depth + 1;
   s->cap = pick_stack_cap(s->stack_need);
   for (int k = 0; k < 3; k++) { s->bmin[k] = nodes[0].bmin[k]; s->bmax[k] = nodes[0].bmax[k]; }
+  if (sizeof(MgpuNode) * nn + sizeof(DTri) * nf <= kLdsBudget) {
+    double lo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, hi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+    bool finite = true;
+    for (size_t i = 0; i < 3 * nf; i++)
+      for (int k = 0; k < 3; k++) {
+        const double x = verts[3 * (size_t)faces[i] + k];
+        finite = finite && std::isfinite(x);
+        lo[k] = std::min(lo[k], x);
+        hi[k] = std::max(hi[k], x);
+      }
+    // ... and only when no ray the render kernel makes can be longer than 1 + 2^-10: a bounce direction is cos / sin weighted sum of
+    // an orthonormal pair and the shading normal (render.cc:271-339), the shading normal a convex combination of the face's three
+    for (size_t i = 0; fv_normals && finite && i < 3 * nf; i++) {
+      const double *n = fv_normals + 3 * i;
+      finite = n[0] * n[0] + n[1] * n[1] + n[2] * n[2] <= 1.0 + 0x1p-10;
+    }
+    if (finite) {
+      double r2 = 0.0;
+      for (int k = 0; k < 3; k++) {
+        s->hint_c[k] = 0.5 * lo[k] + 0.5 * hi[k];
+        const double h = std::max(hi[k] - s->hint_c[k], s->hint_c[k] - lo[k]);
+        r2 += h * h;
+      }
+      const double rho = std::sqrt(r2) * (1.0 + 0x1p-40);
+      if (std::isfinite(rho)) s->hint_rho = rho;
+    }
+  }
 
 #define TRY_OR_FREE(expr)        \
   do {                           \
@@ -1250,11 +1280,11 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
       shmem += scene_lds;
       prim = render_sm_prim_bytes() != 0 && shmem + render_sm_prim_bytes() <= kLdsBudget && !getenv("MGPU_NO_PRIM");
       if (prim) shmem += render_sm_prim_bytes();
-      // ... and behind that the leaf hints (mgpu_render_sm.hip, kHintMinTris): one 64-byte record per leaf at most
+      // ... and behind that the leaf hints (mgpu_render_sm.hip, kHintMinTris): one 96-byte record per leaf at most
       // (the record's number rides in the upper half of tri_end: slots and records of a scene that fits LDS stay far below 2^16)
-      if (!getenv("MGPU_NO_HINTS") && s->nf < 0x10000u)
-        lds_hint_cap = std::min<size_t>(std::min<size_t>((kLdsBudget - shmem) / 64, ((size_t)s->nn + 1) / 2), 0xFFFEu);
-      shmem += lds_hint_cap * 64;
+      if (!getenv("MGPU_NO_HINTS") && s->nf < 0x10000u && s->hint_rho >= 0.0)
+        lds_hint_cap = std::min<size_t>(std::min<size_t>((kLdsBudget - shmem) / (kHintFloats * 4), ((size_t)s->nn + 1) / 2), 0xFFFEu);
+      shmem += lds_hint_cap * (kHintFloats * 4);
     }
   }
   // BVH in HBM: the wide traversal's far-child stacks, and -- one 1024-thread workgroup per CU instead of four of 256 -- the
@@ -1390,6 +1420,20 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
   P.lds_tris_bytes = (uint32_t)(sizeof(DTri) * s->nf);
   P.stack_cap = (uint32_t)s->stack_need;
   P.lds_hint_cap = kern == 2 ? (uint32_t)lds_hint_cap : 0u;
+  P.hint_c[0] = P.hint_c[1] = P.hint_c[2] = P.hint_q2 = P.hint_q = 0.0;
+  if (P.lds_hint_cap) {
+    // Which rays consult the hints, and the |org - p0| |dir| the pads are sized for (mgpu_device.hpp, leaf_hint_make): origins no
+    // farther from the centre of the scene's vertices than this camera or the scene's own half diagonal, whichever is larger.
+    double q2 = 0.0;
+    for (int k = 0; k < 3; k++) {
+      P.hint_c[k] = s->hint_c[k];
+      q2 += (frame[k] - s->hint_c[k]) * (frame[k] - s->hint_c[k]);
+    }
+    const double Q = std::max(std::sqrt(q2), s->hint_rho) * (1.0 + 0x1p-20); // the kernel's own |org - c|^2 rounds a few 2^-53 off
+    P.hint_q2 = Q * Q;
+    P.hint_q = Q * (1.0 + 0x1p-20);
+    if (!std::isfinite(P.hint_q2) || !std::isfinite(s->hint_rho + P.hint_q)) P.lds_hint_cap = 0u;
+  }
   if (treelet) P.lds_nodes_bytes = (uint32_t)(sizeof(WNode) * s->d.treelet_n); // what the HBM-resident kernel stages into LDS
   FScene fsc{};
   if (kern == 3) {

@@ -298,20 +298,67 @@ template <int CAP, bool OVF = true> struct Stack {
 // TestLeafNode (bvh_accel.cc:640-697) runs TriangleIsect on every triangle of a leaf whose box the ray hits -- up to 15 of them,
 // 7.9 per ray on cornellbox_suzanne, one or none of which is hit.  For a leaf of some size the run [first, first + n) of its
 // triangles is split at the m that minimises area(box of the first m) * m + area(box of the rest) * (n - m) -- the ORDER of the
-// run is the reference's and stays -- and both boxes are kept, padded and rounded outward to float, with m (16 floats: box A
-// lo / hi, box B lo / hi, m as bits, 3 unused).  When a lane's TRI work on the leaf starts it tests its ray against the two boxes once
-// (the kernel's own slab test, in double) and drops the part of the run whose box the ray misses or enters beyond the best t:
-// those triangles cannot be hit, and dropping a prefix or a suffix leaves the order of the remaining tests -- hence every
-// `t > tBest` decision and the tie rule -- as it was.  Dropped triangles are booked as the tests the reference makes.
-// Why a dropped triangle cannot be one TriangleIsect accepts: it accepts only rays through the triangle with 0 <= t <= best t,
-// up to its own rounding: ~1e-15 of the operands, and up to ~4e-3 of the triangle's size for a ray within 1e-12 rad of its plane
-// (|det| down to the reference's 1024 eps).  The boxes are padded by 2^-8 of their largest extent plus 2^-20 of their largest
-// |coordinate|, which exceeds both and every rounding of the slab products; rays that are not plain (an infinite or NaN product
-// possible, see slab_t) never consult a hint.
-// tri(k) -> pointer to the 9 doubles p0, e1, e2 of the run's k-th triangle.  Returns false when the best split saves less than
-// (1 - worth) of the expected tests (then it is not worth its two box tests).
+// run is the reference's and stays -- and both boxes are kept, padded and rounded outward to float, with m and a cone around each
+// half's triangle normals (kHintFloats floats).  When a lane's TRI work on the leaf starts it tests its ray against the two boxes
+// once (the kernel's own slab test, in double) and drops the part of the run whose box the ray misses or enters beyond the best
+// t -- provided the ray is not grazing that part's triangles, see below: dropping a prefix or a suffix leaves the order of the
+// remaining tests -- hence every `t > tBest` decision and the tie rule -- as it was.  Dropped triangles are booked as the tests the
+// reference makes.
+//
+// Why a dropped triangle cannot be one TriangleIsect ACCEPTS (bvh_accel.cc:595-638) -- the rule, derived.  Notation: u = 2^-53 (one
+// rounding), s = org - p0, E = |e1| |e2|, Euclidean norms, |a| x+ |b| = the cross product of the absolute values with plus signs
+// (its norm is at most 2 / sqrt 3 |a| |b|, attained at a = b = (1, 1, 1)); hats are the values the reference computes, without FMA:
+//   p^ = fl(d x e2), det^ = fl(e1 . p^), s^ = fl(org - p0), q^ = fl(s^ x e1),
+//   u^ = fl(nu / det^), v^ = fl(nv / det^), t^ = fl(nt / det^) with nu = fl(s^ . p^), nv = fl(q^ . d), nt = fl(e2 . q^),
+// accepted iff |det^| >= 1024 eps = 2048 u, 0 <= u^, v^, u^ + v^ <= 1 and 0 <= t^ <= best t.  The exact identity behind the test is
+// s det = (s . p) e1 + (q . d) e2 - (e2 . q) d with p = d x e2, q = s x e1, det = e1 . p.  Put X = org + t^ d (exact arithmetic on the
+// computed t^) and Y = p0 + u^ e1 + v^ e2; then
+//   (X - Y) det^ = s (det^ - det) - (nu - s . p) e1 - (nv - q . d) e2 + (nt - e2 . q) d + (<= 3 u of each term of Y and X: the divisions).
+// A three-term dot product fl((a1 b1 + a2 b2) + a3 b3) with result r is off by <= u (1.5 |a| |b| + 2.5 |r|): three products, the
+// inner sum (= r - a3 b3, and |a3 b3| <= (sum |ai bi| + |r|) / 2), the outer sum.  All four results here are at most |det^| times
+// 1, u^, v^, t^, so their 2.5 |r| parts are a few u of |s|, |e1|, |e2|, t^ |d| after the division -- booked under (*) below.  Then:
+//   |p^ - p|     <= u (|d| x+ |e2| + |p|)                                   <= (2 / sqrt 3 + 1) u |d| |e2|  = 2.155 u |d| |e2|
+//   |det^ - det| <= 1.5 u |e1| |p^| + |e1| |p^ - p|                          <= 3.655 u |d| E
+//   |nu - s . p| <= 1.5 u |s^| |p^| + u |s| |p^| (s^ = s (1 + delta), by component) + |s| |p^ - p|    <= 4.655 u |s| |d| |e2|
+//   |q^ - q|     <= u (2 |s| x+ |e1| + |q|)  (each product carries s^'s rounding and its own)        <= 3.31 u |s| |e1|
+//   |nv - q . d| <= 1.5 u |q^| |d| + |q^ - q| |d|                                                     <= 4.81 u |s| |e1| |d|
+//   |nt - e2 . q| likewise                                                                            <= 4.81 u |s| E
+// so, for every test the reference ACCEPTS,
+//   |X - Y| <= 17.93 u |s| |d| E / |det^|  +  (*) <= ~20 u (|s| + |e1| + |e2| + t^ |d|).                                    (B)
+// With the ONLY guard the reference has, the absolute |det^| >= 2048 u, that is 8.76 / 1024 |s| |d| E: it grows with the distance
+// of the origin and with the square of the triangle's size, and it is attained in order of magnitude (a ray within 1e-12 rad of
+// a triangle's plane really is accepted ~1 / 1024 |s| |d| E outside the triangle: the round-4 review built one,
+// tests/test_hint_soundness_cpu.py measures 0.9 / 1024 on 10^6 accepted near-coplanar tests, tests/hint_family.py aims 10^4 of the
+// kernel's own primary rays at that band).  A pad of that size around every half makes the hints worthless on cornellbox_suzanne
+// (measured: 5.46 ms with it, 5.42 without hints, 5.12 with the unsound round-4 pad).  So the pad stays small and the rule gets a
+// second clause that keeps (B) small instead:
+//   a half is dropped iff  the ray misses its box padded by  pad = 2^-8 ext + 2^-40 (reach + largest |coordinate|)
+//                     and  |d . nbar| >= thr   (evaluated in float)
+// where (nbar, thr) is a cone around the unit normals n_k = +-(e1 x e2) / |e1 x e2| of the half's triangles -- rho = max |n_k - nbar|
+// -- sized so that the second clause implies, for EVERY triangle of the half,
+//   |det^_k| >= |e1 x e2| (|d . nbar| - |d| rho) - 3.655 u |d| E_k >= Dsafe := 17.93 u reach E_half / (2^-8 ext),
+// i.e. thr = [rho + max_k (Dsafe + 4 u E_k) / |e1 x e2|_k] (1 + 2^-9) + 2^-21 (|d| <= 1 + 2^-10; the float evaluation of d . nbar is within
+// 2^-22 of the exact one; nbar is the float vector the record holds, rho is measured against exactly that vector).  Then (B) gives
+// |X - Y| <= 2^-8 ext + (*) for any test of the half the reference accepts, X lies inside the padded box with the slack the slab
+// test's own roundings need (each of its products is off by <= 3 u |b - org| |1/d|, the slack of a point mu inside a slab is
+// mu |1/d|: 2^-40 against 3 u), at a parameter 0 <= t^ <= best t -- and all three clauses of the slab test (tmax > 0, tmin <= tmax,
+// tmin <= best t) are true.  So a half whose box FAILS the test while the cone clause holds has no triangle the reference accepts.
+// Rays grazing a half's triangles (inside its cone band) keep the half and test it in full; triangles that can never pass the
+// determinant guard (|e1 x e2| (1 + 2^-9) + 6 u E_k < 2048 u: zero-area ones) stay out of the cone.
+// What bounds |s| |d| by `reach`: a ray consults hints only when it is plain (slab_t), its origin satisfies |org - c| <= Q, where c is
+// the centre and rho_s the half diagonal of the box of the scene's vertices and Q = max(|eye - c|, rho_s) for the launch's camera
+// (camera rays and every bounce that starts inside the scene's box qualify; a bounce off the far ground plane does not, and tests
+// the whole run), and |d| <= 1 + 2^-10, which holds for every ray the kernel makes when the scene's shading normals are no longer
+// than 1 + 2^-11 (checked when the scene is created; else the scene gets no hints): reach = (Q + rho_s)(1 + 2^-9).
+// tri(k) -> pointer to the 9 doubles p0, e1, e2 of the run's k-th triangle.  rec: kHintFloats floats = box A lo / hi, box B lo / hi
+// (12), cone A (nbar, thr), cone B, m as bits, 3 unused.  Returns false when the best split saves less than (1 - worth) of the
+// expected tests (then it is not worth its two box tests).
+constexpr int kHintFloats = 24;
+#ifndef MGPU_HINT_CONE_MAX
+#define MGPU_HINT_CONE_MAX 0.2 // a half keeps the small pad + cone rule when its cone's threshold is at most this (|cos| of the grazing band it gives up)
+#endif
 template <typename TriFn>
-__device__ __forceinline__ bool leaf_hint_make(TriFn tri, uint32_t n, double worth, float *rec) {
+__device__ __forceinline__ bool leaf_hint_make(TriFn tri, uint32_t n, double worth, const double *c, double q, float *rec) {
   auto grow = [&](uint32_t k, double *lo, double *hi) { // += the k-th triangle: p0, p0 + e1, p0 + e2
     const double *tp = tri(k);
     for (int a = 0; a < 3; ++a) {
@@ -343,32 +390,100 @@ __device__ __forceinline__ bool leaf_hint_make(TriFn tri, uint32_t n, double wor
     }
   }
   if (best_m == 0u || !(best < worth * whole)) return false; // (NaN boxes: no hint)
+  const double u = 0x1p-53, up = 1.0 + 0x1p-9; // up: |d| <= 1 + 2^-10 and the roundings of this function
   for (int part = 0; part < 2; ++part) {
+    const uint32_t k0 = part ? best_m : 0u, k1 = part ? n : best_m;
     double lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
-    for (uint32_t k = part ? best_m : 0u; k < (part ? n : best_m); ++k) grow(k, lo, hi);
+    double e_half = 0.0, sum[3] = {0.0, 0.0, 0.0};
+    // the triangle's e1 x e2, its length and E_k; `live`: it can pass the determinant guard at all
+    auto normal = [&](uint32_t k, double *nk, double &len, double &ek) -> bool {
+      const double *tp = tri(k);
+      nk[0] = tp[4] * tp[8] - tp[5] * tp[7];
+      nk[1] = tp[5] * tp[6] - tp[3] * tp[8];
+      nk[2] = tp[3] * tp[7] - tp[4] * tp[6];
+      len = sqrt(nk[0] * nk[0] + nk[1] * nk[1] + nk[2] * nk[2]);
+      ek = sqrt(tp[3] * tp[3] + tp[4] * tp[4] + tp[5] * tp[5]) * sqrt(tp[6] * tp[6] + tp[7] * tp[7] + tp[8] * tp[8]) * up;
+      return !(len * up + 6.0 * u * ek < 2048.0 * u);
+    };
+    for (uint32_t k = k0; k < k1; ++k) {
+      grow(k, lo, hi);
+      double nk[3], len, ek;
+      if (!normal(k, nk, len, ek)) continue;
+      e_half = fmax(e_half, ek);
+      if (len > 0.0) {
+        const double sg = (nk[0] * sum[0] + nk[1] * sum[1] + nk[2] * sum[2]) < 0.0 ? -1.0 : 1.0;
+        for (int a = 0; a < 3; ++a) sum[a] += sg * nk[a] / len;
+      }
+    }
     double ext = 0.0, big = 0.0;
     for (int a = 0; a < 3; ++a) {
       ext = fmax(ext, hi[a] - lo[a]);
       big = fmax(big, fmax(fabs(lo[a]), fabs(hi[a])));
     }
-    const double pad = ext * 0x1p-8 + big * 0x1p-20;
+    // reach of THIS half: |org - p0| |d| <= (q + the farthest corner of the half's box from c) (1 + 2^-9) for every consulting ray
+    double far2 = 0.0;
+    for (int a = 0; a < 3; ++a) {
+      const double f = fmax(fabs(lo[a] - c[a]), fabs(hi[a] - c[a]));
+      far2 += f * f;
+    }
+    const double reach = (q + sqrt(far2)) * up;
+    const double pad_geo = ext * 0x1p-8, slack = 0x1p-40 * (reach + big);
+    // the cone: nbar = the float rounding of the normalised sum of the (sign-aligned) unit normals; rho and thr against that vector
+    const double sl = sqrt(sum[0] * sum[0] + sum[1] * sum[1] + sum[2] * sum[2]);
+    float nb[3] = {0.0f, 0.0f, 0.0f};
+    if (sl > 0.0)
+      for (int a = 0; a < 3; ++a) nb[a] = (float)(sum[a] / sl);
+    const double d_safe = 17.93 * u * reach * e_half / pad_geo; // (inf or NaN for a half without extent: never safe, see below)
+    double thr = 0.0; // a half none of whose triangles is live can always be dropped
+    for (uint32_t k = k0; k < k1; ++k) {
+      double nk[3], len, ek;
+      if (!normal(k, nk, len, ek)) continue;
+      double dm = 0.0, dp = 0.0;
+      for (int a = 0; a < 3; ++a) {
+        const double x = nk[a] / len;
+        dm += (x - (double)nb[a]) * (x - (double)nb[a]);
+        dp += (x + (double)nb[a]) * (x + (double)nb[a]);
+      }
+      const double t = sqrt(fmin(dm, dp)) * up + (d_safe + 4.0 * u * ek) / len * up + 0x1p-21;
+      thr = (t > thr) ? t : ((t == t) ? thr : inf); // NaN (len == 0, no extent): never safe
+    }
+    // Which of the two sound rules this half gets: a tight cone (its triangles share a plane, or nearly: the Cornell walls, a floor
+    // triangle that the builder put into a leaf of Suzanne's) keeps the small pad; any other half takes the pad that covers (B) at
+    // the determinant guard, kappa E_half reach with kappa = 9 / 1024 > 8.76 / 1024, and needs no cone (thr = 0: always passes).
+    double pad = pad_geo + slack;
+    float thr_f = __double2float_ru(thr);
+    if (!(thr <= (double)MGPU_HINT_CONE_MAX)) {
+      pad = (9.0 / 1024.0) * e_half * reach + slack;
+      thr_f = 0.0f;
+    }
+    if (!(pad < inf)) return false;
     for (int a = 0; a < 3; ++a) {
       rec[6 * part + a] = __double2float_rd(lo[a] - pad);
       rec[6 * part + 3 + a] = __double2float_ru(hi[a] + pad);
     }
+    rec[12 + 4 * part + 0] = nb[0];
+    rec[12 + 4 * part + 1] = nb[1];
+    rec[12 + 4 * part + 2] = nb[2];
+    rec[12 + 4 * part + 3] = thr_f;
   }
-  rec[12] = __uint_as_float(best_m);
-  rec[13] = rec[14] = rec[15] = 0.0f;
+  rec[20] = __uint_as_float(best_m);
+  rec[21] = rec[22] = rec[23] = 0.0f;
   return true;
 }
 // The consultation: [tri_cur, tri_end) = the leaf's whole run on entry, what is left of it on return; returns the number of
-// triangles dropped.  f0 .. f2 = the record's first 12 floats, m = its 13th as bits.  For a plain ray only.
-__device__ __forceinline__ uint32_t leaf_hint_apply(float4 f0, float4 f1, float4 f2, uint32_t m, V3 org, double ix, double iy, double iz,
-                                                    double bt, uint32_t &tri_cur, uint32_t &tri_end) {
-  const bool hA = slab_hit<true>(make_double2((double)f0.x, (double)f0.y), make_double2((double)f0.z, (double)f0.w),
-                                 make_double2((double)f1.x, (double)f1.y), org, ix, iy, iz, false, false, false, bt);
-  const bool hB = slab_hit<true>(make_double2((double)f1.z, (double)f1.w), make_double2((double)f2.x, (double)f2.y),
-                                 make_double2((double)f2.z, (double)f2.w), org, ix, iy, iz, false, false, false, bt);
+// triangles dropped.  f0 .. f2 = the record's boxes, cA / cB = its cones, m = its split.  For a ray that may consult hints only.
+// (The cone clauses are evaluated for every consulting lane, not only behind a missed box: six float FMAs against a second,
+// dependent trip to LDS in the middle of the step.)
+__device__ __forceinline__ uint32_t leaf_hint_apply(float4 f0, float4 f1, float4 f2, float4 cA, float4 cB, uint32_t m, V3 org, V3 dir, double ix,
+                                                    double iy, double iz, double bt, uint32_t &tri_cur, uint32_t &tri_end) {
+  const float dx = (float)dir.x, dy = (float)dir.y, dz = (float)dir.z;
+  // (NaN compares false: the half counts as grazed and stays)
+  const bool sA = fabsf(__builtin_fmaf(dx, cA.x, __builtin_fmaf(dy, cA.y, dz * cA.z))) >= cA.w;
+  const bool sB = fabsf(__builtin_fmaf(dx, cB.x, __builtin_fmaf(dy, cB.y, dz * cB.z))) >= cB.w;
+  const bool hA = !sA || slab_hit<true>(make_double2((double)f0.x, (double)f0.y), make_double2((double)f0.z, (double)f0.w),
+                                        make_double2((double)f1.x, (double)f1.y), org, ix, iy, iz, false, false, false, bt);
+  const bool hB = !sB || slab_hit<true>(make_double2((double)f1.z, (double)f1.w), make_double2((double)f2.x, (double)f2.y),
+                                        make_double2((double)f2.z, (double)f2.w), org, ix, iy, iz, false, false, false, bt);
   const uint32_t whole = tri_end - tri_cur, mid = tri_cur + m;
   if (!hB) tri_end = mid;
   if (!hA) tri_cur = hB ? mid : tri_end;

@@ -59,7 +59,10 @@ struct RenderParams {
   uint32_t *tile_cost;
   uint32_t lds_nodes_bytes, lds_tris_bytes; // k_render_sm<LDS_SCENE>: bytes of nodes / triangles staged into LDS
   uint32_t stack_cap;            // k_render_sm<LDS_SCENE>: stack entries per lane in LDS = tree depth + 1
-  uint32_t lds_hint_cap;         // k_render_sm<LDS_SCENE>: 64-byte leaf hint records that fit behind the scene (0: none), see kHintMinTris
+  uint32_t lds_hint_cap;         // k_render_sm<LDS_SCENE>: leaf hint records (kHintFloats floats) that fit behind the scene (0: none), see kHintMinTris
+  // ... and which rays may consult them (mgpu_device.hpp, leaf_hint_make): origins with |org - hint_c|^2 <= hint_q2 = hint_q^2, which
+  // bounds |org - p0| of such a ray against every triangle and sizes pads and cones (host: render_frames_impl)
+  double hint_c[3], hint_q2, hint_q;
   unsigned long long *wave_log;  // device or null: 4 words per wave (diagnostic builds only)
   double *probe;                 // device or null: kProbeStride doubles per PathTrace iteration of ONE path
   uint32_t probe_pixel, probe_pass; // full-frame pixel index and pass of the probed path

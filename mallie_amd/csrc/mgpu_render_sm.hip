@@ -203,7 +203,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
     uint32_t s[4];
   };
   PrimRay *s_prim = reinterpret_cast<PrimRay *>(const_cast<unsigned char *>(lds_tris) + (((size_t)P.lds_tris_bytes + 15) & ~(size_t)15)) + (size_t)wave * 64;
-  // Leaf hints (mgpu_device.hpp, leaf_hint_make).  LDS-resident scene: P.lds_hint_cap records of 64 bytes behind the staging above,
+  // Leaf hints (mgpu_device.hpp, leaf_hint_make).  LDS-resident scene: P.lds_hint_cap records of 96 bytes behind the staging above,
   // made here from the LDS copy of the triangles; a leaf's axis field (unused by the reference's traversal) becomes (hint + 1) << 16,
   // which the NODE step adds to tri_end when it opens the leaf (slots of an LDS-resident scene stay below 2^16).  (For the
   // HBM-resident scene -- records made when the scene is created, found through packed leaf tags -- the record is one more
@@ -221,13 +221,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
       uint32_t code = 0u;
       const uint32_t n = nd[14], first = nd[15];
       if (P.lds_hint_cap != 0u && n >= kHintMinTris && n <= 64u) {
-        float rec[16];
+        float rec[kHintFloats];
         if (leaf_hint_make([&](uint32_t k) { return reinterpret_cast<const double *>(lds_tris + (size_t)(first + k) * 80); }, n,
-                           (double)MGPU_HINT_WORTH, rec)) {
+                           (double)MGPU_HINT_WORTH, P.hint_c, P.hint_q, rec)) {
           const uint32_t h = atomicAdd(&s_nhints, 1u);
           if (h < P.lds_hint_cap) {
-            float *dst = reinterpret_cast<float *>(lds_hints + (size_t)h * 64);
-            for (int k = 0; k < 16; ++k) dst[k] = rec[k];
+            float *dst = reinterpret_cast<float *>(lds_hints + (size_t)h * (kHintFloats * 4));
+            for (int k = 0; k < kHintFloats; ++k) dst[k] = rec[k];
             code = (h + 1u) << 16;
           }
         }
@@ -292,6 +292,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
   double ix = 0, iy = 0, iz = 0;
   uint32_t sgn = 0; // bit k: dir[k] < 0 (dirSign, bvh_accel.cc:786-790)
   bool ray_plain = false; // this ray may take the min/max form of the slab test (see the NODE step)
+  bool ray_hints = false; // ... and may consult leaf hints (mgpu_device.hpp, leaf_hint_make: its origin is within the launch's reach)
   int sp = -1;           // LDS_SCENE: index of the stack top; wide form: number of far children on the stack
   uint32_t cur = kWNone; // wide form: record to enter next (kWNone: pop)
   double bt = kDblMax, bu = 0, bv = 0;
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
   unsigned long long u_hist = 0;
   uint32_t u_tail_steps = 0, u_bounce_steps = 0, u_start_steps = 0; // SHADE steps in which the sub-body ran (booked by its first lane)
   uint32_t u_node_it = 0, u_tri_it = 0; // loop iterations inside NODE / TRI steps (one lane of the wave books each)
+  unsigned long long u_hc[4] = {0, 0, 0, 0};
   uint32_t u_hint_fresh = 0, u_hint_dropped = 0, u_hint_empty = 0, u_hint_steps = 0; // leaf hints: consulted, triangles dropped, leaves dropped whole, TRI steps with a consultation
   unsigned long long cyc_node = 0, cyc_tri = 0, cyc_shade = 0, cyc_t0 = 0, cyc_s = 0;
   unsigned long long cyc_sub[6] = {0, 0, 0, 0, 0, 0};
@@ -451,17 +453,26 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
         const bool fresh = st == ST_TRI && (tri_end >> 16) != 0u;
         if (__ballot(fresh) != 0ull) {
           if (fresh) {
-            const float *hp = reinterpret_cast<const float *>(lds_hints + (size_t)((tri_end >> 16) - 1u) * 64);
+            const float *hp = reinterpret_cast<const float *>(lds_hints + (size_t)((tri_end >> 16) - 1u) * (kHintFloats * 4));
             tri_end &= 0xFFFFu;
-            if (ray_plain) {
+            if (ray_hints) {
               const float4 f0 = *reinterpret_cast<const float4 *>(hp), f1 = *reinterpret_cast<const float4 *>(hp + 4),
-                           f2 = *reinterpret_cast<const float4 *>(hp + 8);
-              const uint32_t m = __float_as_uint(hp[12]);
-              const uint32_t dropped = leaf_hint_apply(f0, f1, f2, m, org, ix, iy, iz, bt, tri_cur, tri_end);
+                           f2 = *reinterpret_cast<const float4 *>(hp + 8), cA = *reinterpret_cast<const float4 *>(hp + 12),
+                           cB = *reinterpret_cast<const float4 *>(hp + 16);
+              const uint32_t m = __float_as_uint(hp[20]);
+              const uint32_t dropped = leaf_hint_apply(f0, f1, f2, cA, cB, m, org, dir, ix, iy, iz, bt, tri_cur, tri_end);
               n_tris += dropped; // the tests the reference makes on the dropped part
 #ifdef MGPU_UTIL
               u_hint_fresh++;
               u_hint_dropped += dropped;
+#ifdef MGPU_UTIL_HINTCLASS
+              {
+                const double cx = 0.5 * ((double)f0.x + (double)f0.w) - org.x, cy = 0.5 * ((double)f0.y + (double)f1.x) - org.y, cz = 0.5 * ((double)f0.z + (double)f1.y) - org.z;
+                const double d2 = cx * cx + cy * cy + cz * cz;
+                const int cls = pathLength == 1 ? 0 : (d2 < 2.25 ? 1 : (d2 < 25.0 ? 2 : 3));
+                u_hc[cls] += 1ull | ((unsigned long long)dropped << 32);
+              }
+#endif
               if (tri_cur == tri_end) u_hint_empty++;
 #endif
             }
@@ -923,6 +934,17 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
           sgn = (dir.x < 0.0 ? 1u : 0u) | (dir.y < 0.0 ? 2u : 0u) | (dir.z < 0.0 ? 4u : 0u);
           const bool inv_ok = inverse_dir_w(dir, ix, iy, iz); // 1.0 / dir, no zero guard, as the reference
           ray_plain = sc.boxes_ordered && inv_ok && origin_is_finite(org);
+          if (LDS_SCENE && MGPU_LEAF_HINTS) {
+            // the rays leaf_hint_make's cones are sized for: an origin within the launch's reach of the scene's centre (camera rays by
+            // construction, bounces that start inside the scene's box); their directions are no longer than 1 + 2^-10 in a scene
+            // that gets hints at all (shading normals of length <= 1 + 2^-11, checked when the scene is created)
+#ifdef MGPU_EXP_HINT_NOCHECK // (experiment, unsound: what the origin test costs)
+            ray_hints = ray_plain;
+#else
+            const double ox = org.x - P.hint_c[0], oy = org.y - P.hint_c[1], oz = org.z - P.hint_c[2];
+            ray_hints = ray_plain && ox * ox + oy * oy + oz * oz <= P.hint_q2;
+#endif
+          }
           bt = kDblMax; bu = 0.0; bv = 0.0; bslot = kNoHit;
           sp = 0;
           have_ray = true;
@@ -1002,9 +1024,14 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
   if (threadIdx.x < 8 && P.stats && s_occ[threadIdx.x]) atomicAdd(&P.stats[kOccNodeTrips + threadIdx.x], (unsigned long long)s_occ[threadIdx.x]);
 #endif
 #ifdef MGPU_UTIL
+#ifdef MGPU_UTIL_HINTCLASS
+  for (int k = 0; k < 4; ++k)
+    if (u_hc[k]) atomicAdd(&P.stats[28 + k], u_hc[k]); // consultations | dropped tests << 32
+#else
   if (u_hist)
     for (int k = 0; k < 4; ++k)
       if ((u_hist >> (16 * k)) & 0xffffull) atomicAdd(&P.stats[28 + k], (u_hist >> (16 * k)) & 0xffffull);
+#endif
   {
     unsigned long long a = u_node, b = u_tri, cc = u_shade, d = u_shade_lanes;
     unsigned long long e_rays = n_rays - dry_rays, e_act = dry_active, e_plen = dry_plen, it_n = u_node_it, it_t = u_tri_it;

@@ -1,0 +1,123 @@
+"""CPU side of the leaf-hint soundness argument (mallie_amd/csrc/mgpu_device.hpp, leaf_hint_make):
+ * the error bound the pads are derived from, checked on millions of near-coplanar rays the reference's TriangleIsect accepts;
+ * the adversarial family of tests/hint_family.py: the oracle accepts rays the round-4 pad would have dropped (so the family
+   bites), and the round-5 rule drops none of them.
+The GPU half -- the same scenes rendered by k_render_sm with hints on / off against the oracle -- is in tests/test_gpu_parity.py."""
+import numpy as np
+
+import hint_family as HF
+import oracle_lib as O
+
+
+def test_start_state_gives_the_requested_jitter_words():
+    rng = np.random.default_rng(1)
+    for _ in range(500):
+        k1, k2 = [int(v) for v in rng.integers(0, 2 ** 32, 2)]
+        assert HF.xorshift_outputs(HF.state_for_draws(k1, k2), 2) == [k1, k2]
+    # ... and the oracle's generator agrees on what those words are
+    st = np.array(HF.state_for_draws(123456789, 4000000000), "<u4")
+    a = O.lib().mo_xorshift128(st.ctypes.data)
+    b = O.lib().mo_xorshift128(st.ctypes.data)
+    assert (a, b) == (123456789 / 4294967296.0, 4000000000 / 4294967296.0)
+
+
+def test_triangle_isect_error_bound_on_near_coplanar_rays():
+    """|X - Y| <= 8.76 / 1024 |org - p0| |dir| |e1| |e2| for every accepted test (X = org + t dir, Y = p0 + u e1 + v e2 with the
+    COMPUTED t, u, v): bound (B) of leaf_hint_make at the reference's determinant threshold.  Rays through random points of random triangles,
+    tilted 1e-16 .. 1e-9 rad out of the triangle's plane, from 1 to 100 triangle sizes away."""
+    rng = np.random.default_rng(2)
+    worst, worst_b, accepted, near = 0.0, 0.0, 0, 0
+    for rnd in range(8):
+        n = 400000
+        p0 = rng.uniform(-5, 5, (n, 3))
+        size = 10 ** rng.uniform(-1, 1, (n, 1))
+        e1 = rng.normal(size=(n, 3)) * size
+        e2 = rng.normal(size=(n, 3)) * size
+        if rnd % 2:  # slivers: e2 nearly parallel to e1
+            e2 = e1 * rng.uniform(0.2, 1.5, (n, 1)) + e2 * 10 ** rng.uniform(-6, -1, (n, 1))
+        nrm = HF.cross(e1, e2)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        a, b = rng.uniform(-0.02, 1.02, (2, n, 1))
+        b = b * (1.0 - a)
+        y = p0 + a * e1 + b * e2
+        w = rng.normal(size=(n, 2, 1))
+        inplane = w[:, 0] * e1 + w[:, 1] * e2
+        inplane /= np.linalg.norm(inplane, axis=1, keepdims=True)
+        psi = 10 ** rng.uniform(-16, -9, (n, 1)) * rng.choice([-1.0, 1.0], (n, 1))
+        d = inplane + psi * nrm
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        dist = size * 10 ** rng.uniform(0, 2, (n, 1))
+        org = y - dist * d
+        # TriangleIsect, one triangle per ray
+        p = HF.cross(d, e2)
+        det = HF.dot(e1, p)
+        with np.errstate(all="ignore"):
+            inv = 1.0 / det
+            s = org - p0
+            q = HF.cross(s, e1)
+            u, v, t = HF.dot(s, p) * inv, HF.dot(q, d) * inv, HF.dot(e2, q) * inv
+            ok = ~(np.abs(det) < HF.EPS1024) & ~((u < 0) | (u > 1)) & ~((v < 0) | (u + v > 1)) & ~(t < 0)
+        x = org + t[:, None] * d
+        yy = p0 + u[:, None] * e1 + v[:, None] * e2
+        r = np.linalg.norm(x - yy, axis=1)
+        scale = np.linalg.norm(s, axis=1) * np.linalg.norm(d, axis=1) * np.linalg.norm(e1, axis=1) * np.linalg.norm(e2, axis=1) / 1024.0
+        ratio = np.where(ok, r / scale, 0.0)
+        worst = max(worst, float(ratio.max()))
+        with np.errstate(all="ignore"):  # (B) itself: |X - Y| |det| <= 17.93 u |s| |d| E, whatever the determinant
+            rb = np.where(ok, r * np.abs(det) / (scale * 1024.0 * 2.0 ** -53), 0.0)
+        worst_b = max(worst_b, float(rb.max()))
+        accepted += int(ok.sum())
+        near += int((ok & (np.abs(det) < 4 * HF.EPS1024)).sum())
+    assert accepted > 500000 and near > 2000, (accepted, near)  # the sample reaches the threshold
+    assert worst <= 8.76, worst
+    assert worst_b <= 17.93, worst_b
+    assert worst >= 0.5, worst  # ... and the bound is not vacuous: errors of that order of magnitude do occur
+    print("largest |X - Y| 1024 / (|s| |d| |e1| |e2|) over %d accepted tests (%d within 4x of the det threshold): %.3f; largest |X - Y| |det| / (u |s| |d| |e1| |e2|): %.3f" % (accepted, near, worst, worst_b))
+
+
+def _leaf_run(case):
+    """the single leaf of a family scene, in the reference builder's order: (p0, e1, e2) per slot, slot of face 0"""
+    nodes, idx, _ = O.bvh_build(case["verts"], case["faces"])
+    assert len(nodes) == 1 and nodes[0]["flag"] == 1 and int(nodes[0]["data"][0]) == 5
+    v = case["verts"][case["faces"][idx]]
+    return np.stack([v[:, 0], v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]], 1), int(np.where(idx == 0)[0][0]), nodes, idx
+
+
+def test_adversarial_family_bites_the_round4_pad_and_not_the_round5_rule():
+    cases = HF.family()
+    total, old_drops, new_drops, accepted_total = 0, 0, 0, 0
+    for c in cases:
+        # the vectorised ray generator is the oracle's, bit for bit
+        for i in (0, 7, c["W"] - 1, c["W"] + 3):
+            p, x = divmod(i, c["W"])
+            w = HF.xorshift_outputs(c["table"][p, c["row"], x], 2)
+            ju, jv = np.float32(w[0] / 4294967296.0 - 0.5), np.float32(w[1] / 4294967296.0 - 0.5)
+            r = O.generate_ray(c["frame"], float(np.float32(x) + ju), float(np.float32(c["row"]) + jv))
+            assert np.array_equal(r[:3], c["band_org"][i]) and np.array_equal(r[3:], c["band_dir"][i])
+        run, slot0, nodes, idx = _leaf_run(c)
+        osc = O.OracleScene(c["verts"], c["faces"], None, None, None, nodes, idx)
+        rays = np.hstack([c["band_org"], c["band_dir"]])
+        ref = osc.trace(rays)
+        hit_t = (ref["hit"] == 1) & (ref["faceID"] == 0)
+        ok, t, _, _, _ = HF.triangle_isect(c["band_org"], c["band_dir"], run[slot0, 0], run[slot0, 1], run[slot0, 2])
+        assert np.array_equal(ok, hit_t)  # the restated TriangleIsect decides like the oracle (the small triangles are far off the rays)
+        assert np.array_equal(t[ok], ref["t"][ok])
+        total += len(rays)
+        accepted_total += int(hit_t.sum())
+        centre, q = HF.reach_of(c["verts"], c["faces"], c["frame"][0:3])
+        for rule in ("r4", "r5"):
+            hb = HF.hint_boxes(run, rule=rule, centre=centre, q=q)
+            if hb is None:  # no hint: nothing dropped
+                continue
+            keep = HF.hint_keeps(hb[1] if slot0 < hb[0] else hb[2], c["band_org"], c["band_dir"])
+            wrong = int((hit_t & ~keep).sum())
+            if rule == "r4":
+                old_drops += wrong
+            else:
+                new_drops += wrong
+    assert total >= 10000
+    assert accepted_total > 1000
+    assert old_drops >= 200, old_drops  # the family really aims at the gap the round-4 review found
+    assert new_drops == 0, new_drops
+    print("family: %d rays, %d accepted by the reference, %d of those outside the round-4 box, %d outside the round-5 box" % (
+        total, accepted_total, old_drops, new_drops))
