@@ -332,7 +332,7 @@ template <int CAP, bool OVF = true> struct Stack {
 // kernel's own primary rays at that band).  A pad of that size around every half makes the hints worthless on cornellbox_suzanne
 // (measured: 5.46 ms with it, 5.42 without hints, 5.12 with the unsound round-4 pad).  So the pad stays small and the rule gets a
 // second clause that keeps (B) small instead:
-//   a half is dropped iff  the ray misses its box padded by  pad = 2^-8 ext + 2^-40 (reach + largest |coordinate|)
+//   a half is dropped iff  the ray misses its box padded by  pad = 2^-8 ext + slack, slack >= 2^-40 (reach + largest |coordinate|),
 //                     and  |d . nbar| >= thr   (evaluated in float)
 // where (nbar, thr) is a cone around the unit normals n_k = +-(e1 x e2) / |e1 x e2| of the half's triangles -- rho = max |n_k - nbar|
 // -- sized so that the second clause implies, for EVERY triangle of the half,
@@ -427,7 +427,8 @@ __device__ __forceinline__ bool leaf_hint_make(TriFn tri, uint32_t n, double wor
       far2 += f * f;
     }
     const double reach = (q + sqrt(far2)) * up;
-    const double pad_geo = ext * 0x1p-8, slack = 0x1p-40 * (reach + big);
+    const double cbig = fmax(fabs(c[0]), fmax(fabs(c[1]), fabs(c[2])));
+    const double pad_geo = ext * 0x1p-8, slack = 0x1p-20 * (cbig + 2.0 * reach + big); // (2^-40 (reach + big) for the double form)
     // the cone: nbar = the float rounding of the normalised sum of the (sign-aligned) unit normals; rho and thr against that vector
     const double sl = sqrt(sum[0] * sum[0] + sum[1] * sum[1] + sum[2] * sum[2]);
     float nb[3] = {0.0f, 0.0f, 0.0f};
@@ -472,18 +473,29 @@ __device__ __forceinline__ bool leaf_hint_make(TriFn tri, uint32_t n, double wor
 }
 // The consultation: [tri_cur, tri_end) = the leaf's whole run on entry, what is left of it on return; returns the number of
 // triangles dropped.  f0 .. f2 = the record's boxes, cA / cB = its cones, m = its split.  For a ray that may consult hints only.
+// Evaluated in FLOAT (the boxes are floats; the ray's origin, inverse direction and direction are rounded to nearest, the best t
+// upwards): every float slab product is the exact one of a plane shifted by <= 2^-24 |org| and is off by <= 3.1 x 2^-24 of itself,
+// which the 2^-20 (|c| + 2 reach + |coordinate|) that leaf_hint_make adds to every pad turns into slack on the right side of all three
+// clauses; |1 / d| < 2^100 (part of the ray's permission) keeps the products finite.  Half the issue slots of the double form.
 // (The cone clauses are evaluated for every consulting lane, not only behind a missed box: six float FMAs against a second,
 // dependent trip to LDS in the middle of the step.)
+__device__ __forceinline__ bool slab_hit_f32(float lx, float ly, float lz, float hx, float hy, float hz, float ox, float oy, float oz, float ix,
+                                             float iy, float iz, float bt_up) {
+  const float ax = (lx - ox) * ix, bx = (hx - ox) * ix, ay = (ly - oy) * iy, by = (hy - oy) * iy, az = (lz - oz) * iz, bz = (hz - oz) * iz;
+  const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+  const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+  return (tmax > 0.0f) && (tmin <= tmax) && (tmin <= bt_up);
+}
 __device__ __forceinline__ uint32_t leaf_hint_apply(float4 f0, float4 f1, float4 f2, float4 cA, float4 cB, uint32_t m, V3 org, V3 dir, double ix,
                                                     double iy, double iz, double bt, uint32_t &tri_cur, uint32_t &tri_end) {
   const float dx = (float)dir.x, dy = (float)dir.y, dz = (float)dir.z;
+  const float ox = (float)org.x, oy = (float)org.y, oz = (float)org.z, jx = (float)ix, jy = (float)iy, jz = (float)iz;
+  const float bt_up = __double2float_ru(bt);
   // (NaN compares false: the half counts as grazed and stays)
   const bool sA = fabsf(__builtin_fmaf(dx, cA.x, __builtin_fmaf(dy, cA.y, dz * cA.z))) >= cA.w;
   const bool sB = fabsf(__builtin_fmaf(dx, cB.x, __builtin_fmaf(dy, cB.y, dz * cB.z))) >= cB.w;
-  const bool hA = !sA || slab_hit<true>(make_double2((double)f0.x, (double)f0.y), make_double2((double)f0.z, (double)f0.w),
-                                        make_double2((double)f1.x, (double)f1.y), org, ix, iy, iz, false, false, false, bt);
-  const bool hB = !sB || slab_hit<true>(make_double2((double)f1.z, (double)f1.w), make_double2((double)f2.x, (double)f2.y),
-                                        make_double2((double)f2.z, (double)f2.w), org, ix, iy, iz, false, false, false, bt);
+  const bool hA = !sA || slab_hit_f32(f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, ox, oy, oz, jx, jy, jz, bt_up);
+  const bool hB = !sB || slab_hit_f32(f1.z, f1.w, f2.x, f2.y, f2.z, f2.w, ox, oy, oz, jx, jy, jz, bt_up);
   const uint32_t whole = tri_end - tri_cur, mid = tri_cur + m;
   if (!hB) tri_end = mid;
   if (!hA) tri_cur = hB ? mid : tri_end;

@@ -939,10 +939,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
             // construction, bounces that start inside the scene's box); their directions are no longer than 1 + 2^-10 in a scene
             // that gets hints at all (shading normals of length <= 1 + 2^-11, checked when the scene is created)
 #ifdef MGPU_EXP_HINT_NOCHECK // (experiment, unsound: what the origin test costs)
-            ray_hints = ray_plain;
+            ray_hints = ray_plain && fabs(ix) < 0x1p100 && fabs(iy) < 0x1p100 && fabs(iz) < 0x1p100;
 #else
             const double ox = org.x - P.hint_c[0], oy = org.y - P.hint_c[1], oz = org.z - P.hint_c[2];
-            ray_hints = ray_plain && ox * ox + oy * oy + oz * oz <= P.hint_q2;
+            ray_hints = ray_plain && ox * ox + oy * oy + oz * oz <= P.hint_q2 && fabs(ix) < 0x1p100 && fabs(iy) < 0x1p100 && fabs(iz) < 0x1p100;
 #endif
           }
           bt = kDblMax; bu = 0.0; bv = 0.0; bslot = kNoHit;

@@ -136,7 +136,7 @@ def hint_boxes(tris, worth=0.85, rule="r5", centre=None, q=None, cone_max=0.2):
             continue
         reach = (q + np.sqrt((np.maximum(np.abs(lo - centre), np.abs(hi - centre)) ** 2).sum())) * up
         pad_geo = ext * 2.0 ** -8
-        slack = 2.0 ** -40 * (reach + big)
+        slack = 2.0 ** -20 * (np.abs(centre).max() + 2.0 * reach + big)
         nk = cross(tris[a:b, 1], tris[a:b, 2])
         ln = np.sqrt((nk ** 2).sum(1))
         ek = np.sqrt((tris[a:b, 1] ** 2).sum(1)) * np.sqrt((tris[a:b, 2] ** 2).sum(1)) * up
@@ -170,7 +170,18 @@ def hint_boxes(tris, worth=0.85, rule="r5", centre=None, q=None, cone_max=0.2):
 def hint_keeps(half, org, d, bt=DBL_MAX):
     """leaf_hint_apply for one half (lo, hi, cone): True where the half stays in the run."""
     lo, hi, cone = half
-    keep = slab_plain(lo, hi, org, d, bt)
+    if cone is None:  # the round-4 library tested in double
+        return slab_plain(lo, hi, org, d, bt)
+    with np.errstate(all="ignore"):  # the float form of leaf_hint_apply: origin, 1 / d (a double division first) rounded to nearest
+        of, jf = org.astype(np.float32), (1.0 / d).astype(np.float32)
+        lof, hif = lo.astype(np.float32), hi.astype(np.float32)
+        btf = np.float32(bt)
+        if float(btf) < bt:
+            btf = np.nextafter(btf, np.float32(np.inf))
+        a, b = (lof[None, :] - of) * jf, (hif[None, :] - of) * jf
+        tmin = np.maximum(np.maximum(np.minimum(a[:, 0], b[:, 0]), np.minimum(a[:, 1], b[:, 1])), np.minimum(a[:, 2], b[:, 2]))
+        tmax = np.minimum(np.minimum(np.maximum(a[:, 0], b[:, 0]), np.maximum(a[:, 1], b[:, 1])), np.maximum(a[:, 2], b[:, 2]))
+        keep = (tmax > 0) & (tmin <= tmax) & (tmin <= btf)
     if cone is not None:
         nb, thr = cone
         df = d.astype(np.float32)
@@ -201,7 +212,7 @@ def _quat_to(dir0):
     return np.array([ax[0] * np.sin(ang / 2), ax[1] * np.sin(ang / 2), ax[2] * np.sin(ang / 2), np.cos(ang / 2)])
 
 
-def make_case(S, L, phi, perm=(0, 1, 2), sign=(1, 1, 1), seed=0, W=512, H=8, passes=2, tries=60):
+def make_case(S, L, phi, perm=(0, 1, 2), sign=(1, 1, 1), seed=0, W=512, H=8, passes=2, tries=60, mixed=False):
     """One scene.  T = right triangle with legs S (along a coordinate axis) and S sqrt 2 (along a face diagonal), in a plane through
     the eye; the camera looks along that plane at angle phi to the first leg from distance L, and the middle image row's rays (all
     passes) cross the line of the first leg from 2 % of S inside T's corner p1 to several % outside.  The tilt of T against the rays'
@@ -266,7 +277,11 @@ def make_case(S, L, phi, perm=(0, 1, 2), sign=(1, 1, 1), seed=0, W=512, H=8, pas
     # four small triangles far behind T, beside the rays' plane: the leaf's "rest"
     far = eye + (L + 6.0 * S + 2.0) * d[W // 2] + 0.05 * S * n
     verts, faces = [tri[0], tri[1], tri[2]], [(0, 1, 2)]
-    for k in range(4):
+    if mixed:  # a small triangle inside T's box, 60 degrees off T's plane: T's half is no longer planar and takes the padded-box rule
+        b = tri[0] + 0.3 * S * (exp + eyp) + 0.02 * S * n
+        verts += [b, b + 0.05 * S * exp, b + 0.05 * S * (0.5 * eyp + 0.866 * n)]
+        faces.append((3, 4, 5))
+    for k in range(4 - (1 if mixed else 0)):
         b = far + 0.02 * S * (k * exp + (k % 2) * eyp)
         i = len(verts)
         verts += [b, b + 0.01 * S * exp, b + 0.01 * S * eyp + 0.003 * S * n]
@@ -284,5 +299,5 @@ FAMILY = [  # (S, L, phi in degrees, axis permutation, signs): sizes 0.3 .. 10, 
 
 
 def family(W=512, H=8, passes=2):
-    return [make_case(S, L, np.deg2rad(phi), perm, sign, seed=100 + i, W=W, H=H, passes=passes)
+    return [make_case(S, L, np.deg2rad(phi), perm, sign, seed=100 + i, W=W, H=H, passes=passes, mixed=(i % 3 == 2))
             for i, (S, L, phi, perm, sign) in enumerate(FAMILY)]
