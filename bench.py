@@ -631,6 +631,9 @@ def main():
         alg_bytes_launch = (st["nodes"] * B_NODE + st["tris"] * B_TRI + st["real_rays"] * B_RAY) / n_launch
         kernel_avg_ms = per_rank_kernel[0]
         ksec = kernel_avg_ms * 1e-3
+        # the workloads' scenes carry no material table (every hit multiplies by the default 0.5 grey): grey, i.e. ONE float
+        # per pixel and pass in the planes, unless the three-channel kernel is forced
+        scene_is_grey = os.environ.get("MGPU_GREY", "1") != "0"
         if key != "c2":
             # HBM-resident configurations: kernel time of a FRAME (a frame whose planes exceed 1 GiB takes several launches)
             roof = hbm_roofline(key, st, args.steps, kernel_avg_ms * n_launch / args.steps, lib_path) if world == 1 else \
@@ -640,9 +643,17 @@ def main():
             p, why = pmc_for("c2", lib_path) if world == 1 else (None, "PMC passes are single-GPU")
             traffic = hbm_bytes(p)
             alg_gbs = alg_bytes_launch / ksec / 1e9 if ksec > 0 else 0.0
-            ginst = p["SQ_INSTS_VALU"] / ksec / 1e9 if p and "SQ_INSTS_VALU" in p and ksec > 0 else None
+            ginst_run = p["SQ_INSTS_VALU"] / ksec / 1e9 if p and "SQ_INSTS_VALU" in p and ksec > 0 else None
+            # `achieved` / `frac` over the kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of the SAME
+            # library (profiles/<tag>_summary.txt; pmc_current.json carries it as traced_kernel_avg_ms) -- the reproducible figure; the
+            # traced run is a few % slower than this one (its read-backs become blit kernels) -- and the figure over THIS run's own
+            # HIP-event kernel time beside it
+            traced_ms = p.get("traced_kernel_avg_ms") if p else None
+            ginst = p["SQ_INSTS_VALU"] / (traced_ms * 1e-3) / 1e9 if ginst_run and traced_ms else ginst_run
             roof = {"bound": "valu", "unit": "Ginst/s", "peak": round(VALU_PEAK_GINST, 1),
                     "achieved": round(ginst, 1) if ginst else None, "frac": round(ginst / VALU_PEAK_GINST, 4) if ginst else None,
+                    "frac_over": ("kernel average of the traced bench run in profiles/ (%.3f ms)" % traced_ms) if traced_ms and ginst_run else "this run's HIP-event kernel time",
+                    "frac_this_run": round(ginst_run / VALU_PEAK_GINST, 4) if ginst_run else None,
                     "traffic": traffic, "kernel": "k_render_sm", "kernel_avg_ms": round(kernel_avg_ms, 3), "pmc_source": why,
                     "valu": None, "hbm": None,
                     "algorithmic_vs_hbm": {"bytes_per_launch": int(alg_bytes_launch), "GBps": round(alg_gbs, 1),
@@ -661,10 +672,10 @@ def main():
             if traffic and ksec > 0:
                 roof["hbm"] = {"measured_GBps": round(traffic / ksec / 1e9, 1), "frac_of_peak": round(traffic / ksec / 1e9 / HBM_PEAK_GBS, 4),
                                "fetch_bytes": int(2 * p["FETCH_SIZE"] * 1024), "write_bytes": int(p["WRITE_SIZE"] * 1024),
-                               "needed_write_bytes": int(4 * W * H * spp),
+                               "needed_write_bytes": int((4 if scene_is_grey else 12) * W * H * spp),
                                "note": "2*FETCH_SIZE + WRITE_SIZE per frame (one launch) of k_render_sm; needed_write = the per-pass radiance "
-                                       "planes it produces (one float per pixel and pass: this scene's materials are grey, its three channels "
-                                       "equal; 12 bytes until round 4); WRITE_SIZE is uncalibrated on gfx950 (profiles/README.md)"}
+                                       "planes it produces (one float per pixel and pass when the scene's materials are grey -- three equal "
+                                       "channels -- else three); WRITE_SIZE is uncalibrated on gfx950 (profiles/README.md)"}
         conf = {"workload": workloads.describe(cfg, n_tris) + "; 1 step = 1 frame = the next %d passes per pixel "
                             "(pass_base advances by %d per step)" % (spp, spp),
                 "parallelism": "replicated scene, interleaved 8-row strips x%d, 1 RCCL exchange/frame: %s" % (world, exchange)
@@ -676,8 +687,8 @@ def main():
                 "rays_per_frame": int(rays / args.steps), "trace_calls_per_frame": int(trace_calls / args.steps),
                 "nodes_per_ray": round(nodes / rays, 3), "tris_per_ray": round(tris / rays, 3),
                 "work_counters": ("nodes / tris per ray = the reference's node pops and TriangleIsect calls (equal to the oracle's counters); with the "
-                                  "scene in LDS the leaf hints drop tests the ray cannot pass and book them as made -- on this workload 3.74 "
-                                  "of the 7.89 per ray (MGPU_UTIL build, DESIGN.md 4.1)") if key == "c2" else
+                                  "scene in LDS the leaf hints drop tests the ray provably cannot pass and book them as made (how many: "
+                                  "tools/perf_hint_classes.py on a diagnostic build, DESIGN.md 4.1)") if key == "c2" else
                                  "nodes / tris per ray = the reference's node pops and TriangleIsect calls (equal to the oracle's counters)",
                 "mtrace_calls_per_s": round(trace_calls / elapsed / 1e6, 2),
                 # what the multi-GPU machinery says about itself: communicator size read back from RCCL (ncclCommCount), the
@@ -704,6 +715,8 @@ def main():
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            # what `value` / `ms_per_step` time (since round 4; rounds 1-3 timed "frame_resident_in_hbm", reported below)
+            "headline_definition": "r4+: SURVEY 8(d)'s frame = all passes of a frame + its read-back to pinned host memory, frames in flight >= 2" if readback else "frames left in HBM",
             "config": conf,
             "roofline": roof,
         }

@@ -147,11 +147,6 @@ int mgpu_trace_queue_stats(MgpuScene *scene, uint64_t *launches, uint64_t *calls
  * mgpu_trace_server_retire: asks a live launch to leave and returns when it has (a few tens of microseconds). */
 int mgpu_trace_server_stats(MgpuScene *scene, uint64_t *launches, uint64_t *calls, int *alive, double *device_us);
 int mgpu_trace_server_retire(MgpuScene *scene);
-/* Measurement aid (bench.py): rays[0..n) traced as n ONE-ray mgpu_trace calls issued by `threads` host threads of this
- * library's own (thread t takes rays t, t + threads, ...), i.e. the reference's calling pattern of Scene::Trace without a
- * binding's per-call overhead in the clock; out / hit receive the records, *calls_per_s the rate (first call outside the clock). */
-int mgpu_trace_calls_measure(MgpuScene *scene, const MgpuRay *rays, size_t n, int threads, MgpuIntersection *out, uint8_t *hit,
-                             double *calls_per_s);
 /* The same with rays, records and hit flags resident in device memory (d_out 16-byte aligned), enqueued on `stream`
  * (a hipStream_t, NULL = default stream) without synchronising; with stats != NULL the call waits for the kernel and
  * returns its counters and time. */
@@ -204,7 +199,6 @@ int mgpu_render_stream(MgpuScene *scene, const double origin[3], const double co
  * Images do not depend on it.  mgpu_render_ahead_stats: calls served from a frame rendered ahead / calls that were not. */
 int mgpu_scene_set_render_ahead(MgpuScene *scene, int on);
 int mgpu_render_ahead_stats(MgpuScene *scene, unsigned long long *hits, unsigned long long *misses);
-int mgpu_debug_stream_classes(MgpuScene *scene, unsigned char *out, size_t npix); /* diagnostic: the cached classes, 0 / 1 / 2 per pixel */
 int mgpu_stream_stats(MgpuScene *scene, double *resolve_ms, int *classified, unsigned long long *retries, uint32_t *uncertain_pixels);
 /* Render() with its `step` argument (render.cc:657-696): step == 1 is mgpu_render with passes = 1 on the whole frame.
  * step > 1 traces one path per step x step block -- the path of the block's top-left pixel (its jitter, its RNG start
@@ -370,33 +364,6 @@ int mgpu_render_panoramic_device(MgpuScene *scene, const double origin[3], int W
  * them first and return that call's own counts).  mgpu_stats_read synchronises the device and returns the running
  * totals (kernel_ms / total_ms are left 0); reset != 0 zeroes them afterwards. */
 int mgpu_stats_read(MgpuScene *scene, MgpuStats *out, int reset);
-
-/* Diagnostic: the 32 raw device counter words (layout in mallie_amd/csrc/mgpu_kernels.hpp; words 8.. are only filled by
- * -DMGPU_UTIL experiment builds). */
-int mgpu_debug_words(MgpuScene *scene, unsigned long long *out32);
-
-/* Active-lane accounting of the render kernel's three bodies (NODE: box tests, TRI: triangle tests, SHADE: the rest of a
- * PathTrace iteration), accumulated like the work counters (mgpu_stats_read resets them too).  The kernel books about one
- * step in `sample_every` (chosen by the low bits of the shader clock, whatever the step does): `*_trips` = trips of the
- * body's loop the wave made on the booked steps, `*_lanes` = lanes active summed over those trips, so
- * lanes / (64 * trips) is the body's active-lane fraction; `node_steps` / `tri_steps` / `shade_steps` = steps booked
- * (SHADE has one trip per step).  Synchronises the device. */
-typedef struct {
-  uint64_t node_trips, node_lanes, tri_trips, tri_lanes, shade_steps, shade_lanes, node_steps, tri_steps;
-  uint32_t sample_every, pad_;
-} MgpuOccupancy;
-int mgpu_occupancy_read(MgpuScene *scene, MgpuOccupancy *out);
-
-/* Diagnostic (MGPU_WAVE_LOG=1 + -DMGPU_UTIL builds): 8 words per wave, `out` holds 8 * n_waves words:
- * {start, end, time the work cursor was found dry (100 MHz device ticks), XCC id | rays << 8,
- *  rays traced after dry, lanes alive at dry | their pathLength sum << 16, NODE | TRI << 20 | SHADE << 40 steps after dry,
- *  scheduling rounds after dry}. */
-int mgpu_debug_wave_log(MgpuScene *scene, unsigned long long *out, size_t n_waves);
-
-/* Diagnostic: the cost-ordered hand-out state of the last render launch: per 8x8 tile (row-major over the rendered
- * window) the cost measured by that launch, and the order in which it handed the tiles out.  Either pointer may be NULL;
- * n_tiles must not exceed the launch's tile count.  Synchronises the device. */
-int mgpu_debug_tile_order(MgpuScene *scene, uint32_t *cost_out, uint32_t *order_out, size_t n_tiles);
 
 /* Per-launch kernel timing for asynchronous use: after mgpu_timing_enable(scene, 1) every mgpu_render_strips_device call
  * made with stats == NULL brackets its kernel with HIP events on the launch stream (no synchronisation).

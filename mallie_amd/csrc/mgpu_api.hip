@@ -1,4 +1,4 @@
-// mgpu_api.hip -- host side of the C ABI declared in include/mgpu.h.
+// mgpu_api.hip -- host side of the C ABI declared in include/mgpu.h (and of the instrumentation in include/mgpu_internal.h).
 //
 // Scene upload re-lays the reference's Mesh + BVHAccel arrays out for the device (see mgpu_device.hpp: nodes verbatim,
 // triangles pre-gathered per leaf slot with edges precomputed, shading normals per slot) and the entry points launch
@@ -9,6 +9,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -23,6 +24,7 @@
 #include <vector>
 
 #include "mgpu_kernels.hpp"
+#include "../../include/mgpu_internal.h"
 
 using namespace mgpu;
 
@@ -189,6 +191,7 @@ struct MgpuScene {
   unsigned long long srv_idle_us = 1000, srv_life_us = 100000; // MGPU_TRACE_SERVER_IDLE_US / _LIFE_US
   bool tile_order_on = true;   // MGPU_TILE_ORDER (read once, when the scene is created)
   unsigned tile_order_every = 4; // MGPU_TILE_ORDER_EVERY
+  int tile_order_z = INT_MIN;    // MGPU_TILE_ORDER_Z: forces the hand-out order of HBM-resident scenes (render_frames_impl); INT_MIN: by launch size
 };
 
 namespace {
@@ -963,6 +966,7 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
   if (const char *e = getenv("MGPU_TRACE_SERVER_IDLE_US")) s->srv_idle_us = (unsigned long long)(atoll(e) < 1 ? 1 : atoll(e));
   if (const char *e = getenv("MGPU_TRACE_SERVER_LIFE_US")) s->srv_life_us = (unsigned long long)(atoll(e) < 100 ? 100 : atoll(e));
   if (const char *e = getenv("MGPU_TILE_ORDER")) s->tile_order_on = atoi(e) != 0;
+  if (const char *e = getenv("MGPU_TILE_ORDER_Z")) s->tile_order_z = atoi(e);
   if (const char *e = getenv("MGPU_TILE_ORDER_EVERY")) s->tile_order_every = atoi(e) < 1 ? 1u : (unsigned)atoi(e);
   *out = s;
   return MGPU_OK;
@@ -1462,6 +1466,13 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
   P.tile_order = nullptr;
   P.tile_cost = nullptr;
   const bool use_order = kern != 0 && tiles >= 2 * blocks && s->tile_order_on;
+  // BVH in HBM, a launch long enough that its end does not matter (>= 1024 work items per wave: the 3840 x 2160 x 64 spp frame of the
+  // 10 M-triangle grid has 2 025, the 1080p frames 126 and 506): the order follows the Z-order curve of the tile grid
+  // (k_order_tiles_z), so that what an XCD's waves work on together -- and its L2 holds -- is a compact image region: C5 254.3 ->
+  // 239.9 ms; on the short launches the cost sort wins (C4 4.49 vs 4.98 ms along the curve, 4.54 with 8 cost classes).
+  // MGPU_TILE_ORDER_Z overrides: 0 = the 256-bucket cost sort, 1 = the pure curve, n = n octave classes, -p = cheapest p % last.
+  int z_classes = 0;
+  if (kern == 1) z_classes = s->tile_order_z != INT_MIN ? s->tile_order_z : (tiles * (uint64_t)group * (uint64_t)fpl >= 1024ull * blocks * (uint64_t)(block / 64) ? 1 : 0);
   if (use_order) {
     if (tiles > R.tile_cap) {
       HIP_TRY(hipDeviceSynchronize());
@@ -1493,7 +1504,7 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
     const unsigned every = s->tile_order_every;
     auto renews = [&](unsigned age) { return age < 2 || age % every == 0; };
     if (renews(R.order_age)) {
-      launch_order_tiles(st, R.p_tile_cost, (uint32_t)tiles, R.p_tile_order); // outside the kernel-time bracket
+      launch_order_tiles(st, R.p_tile_cost, (uint32_t)tiles, R.p_tile_order, (uint32_t)((win_w + 7) / 8), (uint32_t)((n_rows + 7) / 8), z_classes); // outside the kernel-time bracket
       HIP_TRY(hipGetLastError());
     }
     P.tile_cost = renews(R.order_age + 1) ? R.p_tile_cost : nullptr;
@@ -1579,7 +1590,7 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
     for (int g0 = 0; g0 < passes; g0 += group) {
       if (use_order && g0 > 0 && P.tile_cost) { // only a launch that recorded costs has anything to sort by (a sort of the
         // zeroed table would put the later groups, and the following frames, back into image order)
-        launch_order_tiles(st, R.p_tile_cost, (uint32_t)tiles, R.p_tile_order);
+        launch_order_tiles(st, R.p_tile_cost, (uint32_t)tiles, R.p_tile_order, (uint32_t)((win_w + 7) / 8), (uint32_t)((n_rows + 7) / 8), z_classes);
         HIP_TRY(hipGetLastError());
       }
       const int g = passes - g0 < group ? passes - g0 : group;

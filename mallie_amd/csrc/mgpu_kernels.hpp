@@ -213,7 +213,9 @@ void launch_count_add(hipStream_t s, int32_t *count, size_t npix, int passes); /
 void launch_accumulate_tiled(hipStream_t s, const float *planes, size_t plane_stride, bool mono, int passes, size_t n_floats, int win_w,
                              float *image, int32_t *count, bool resume);
 // tile_order[0..n) = tile indices by descending cost (256 log buckets); zeroes cost[]. One workgroup.
-void launch_order_tiles(hipStream_t s, uint32_t *cost, uint32_t n_tiles, uint32_t *order);
+// z_classes > 0 (tiles_x * tiles_y == n_tiles): along the Z-order curve of the tile grid, stably split into that many cost classes
+// (k_order_tiles_z: scenes whose BVH stays in HBM); 0: the 256-bucket counting sort
+void launch_order_tiles(hipStream_t s, uint32_t *cost, uint32_t n_tiles, uint32_t *order, uint32_t tiles_x = 0, uint32_t tiles_y = 0, int z_classes = 0);
 // slot-ordered DTri records + per-slot shading normals (9 doubles with face-varying normals, else the geometric normal)
 void launch_scene_layout(hipStream_t s, const double *verts, const uint32_t *faces, const uint32_t *indices,
                          const uint32_t *matIDs, const double *fv_normals, size_t nf, DTri *tris, double *slot_normal);

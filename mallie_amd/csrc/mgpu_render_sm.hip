@@ -1299,8 +1299,130 @@ __global__ __launch_bounds__(1024) void k_order_tiles(uint32_t *__restrict__ cos
   }
 }
 
-void launch_order_tiles(hipStream_t s, uint32_t *cost, uint32_t n_tiles, uint32_t *order) {
-  hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(1024), 0, s, cost, n_tiles, order);
+// k_order_tiles_z: the same hand-out order for scenes whose BVH stays in HBM, where WHICH tiles an XCD's waves work on together
+// decides what its 4 MB of L2 holds: tiles along the Z-order (Morton) curve of the tile grid, stably split into cost classes --
+// class = octaves below the most expensive tile, at most kZClasses -- expensive classes first.  Inside a class neighbours on the
+// curve stay neighbours in the hand-out, so a contiguous eighth of the order (what one XCD draws from, see the work cursor) is a
+// few compact image regions instead of whatever the atomics of the 256-bucket sort left next to each other.  classes == 1: the
+// pure curve.  One 1024-thread workgroup; thread t owns codes [t * per, (t + 1) * per) of the curve in both passes, which makes
+// the placement deterministic.  cost[] is zeroed for the next launch.
+constexpr int kZClasses = 8;
+__device__ __forceinline__ uint32_t z_compact(uint32_t v) { // every second bit of v, packed
+  v &= 0x55555555u;
+  v = (v | (v >> 1)) & 0x33333333u;
+  v = (v | (v >> 2)) & 0x0F0F0F0Fu;
+  v = (v | (v >> 4)) & 0x00FF00FFu;
+  v = (v | (v >> 8)) & 0x0000FFFFu;
+  return v;
+}
+__global__ __launch_bounds__(1024) void k_order_tiles_z(uint32_t *__restrict__ cost, uint32_t tiles_x, uint32_t tiles_y, int classes,
+                                                        uint32_t *__restrict__ order) {
+  __shared__ uint32_t cnt[kZClasses][1024];
+  __shared__ uint32_t class_base[kZClasses];
+  __shared__ uint32_t max_cost;
+  const uint32_t tid = threadIdx.x, n = tiles_x * tiles_y;
+  uint32_t side = 1;
+  while (side < tiles_x || side < tiles_y) side <<= 1;
+  const uint32_t codes = side * side, per = (codes + 1023u) / 1024u;
+  if (tid == 0) max_cost = 0;
+  __syncthreads();
+  if (classes > 1 || classes < 0) {
+    uint32_t m = 0;
+    for (uint32_t i = tid; i < n; i += 1024) m = max(m, cost[i]);
+    for (int off = 32; off; off >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, off));
+    if ((tid & 63u) == 0u) atomicMax(&max_cost, m);
+    __syncthreads();
+  }
+  const uint32_t top = max_cost ? 31u - (uint32_t)__clz((int)max_cost) : 0u; // floor(log2) of the largest cost
+  // classes < 0: two classes, the cheapest -classes per cent of the tiles (by the 256-bucket histogram of k_order_tiles) last
+  __shared__ uint32_t hist[256], tail_bucket;
+  auto bucket = [](uint32_t c) -> uint32_t {
+    if (c < 8) return c;
+    const uint32_t e = 31u - (uint32_t)__clz((int)c);
+    const uint32_t b = 8u * (e - 2u) + ((c >> (e - 3u)) & 7u);
+    return b > 255u ? 255u : b;
+  };
+  if (classes < 0) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 1024) atomicAdd(&hist[bucket(cost[i])], 1u);
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t want = (uint32_t)(((uint64_t)n * (uint64_t)(-classes)) / 100u);
+      uint32_t run = 0, b = 0;
+      while (b < 256u && run + hist[b] <= want) run += hist[b++];
+      tail_bucket = b; // buckets below b form the tail (none when the cheapest bucket alone is larger than the share asked for)
+    }
+    __syncthreads();
+  }
+  auto cls = [&](uint32_t c) -> uint32_t {
+    if (classes < 0) return (max_cost != 0u && bucket(c) < tail_bucket) ? 1u : 0u;
+    if (classes <= 1 || max_cost == 0u) return 0u;
+    const uint32_t e = c ? 31u - (uint32_t)__clz((int)c) : 0u;
+    return min(top - e, (uint32_t)classes - 1u);
+  };
+  uint32_t mine[kZClasses];
+  for (int k = 0; k < kZClasses; ++k) mine[k] = 0;
+  for (uint32_t code = tid * per; code < min((tid + 1u) * per, codes); ++code) {
+    const uint32_t tx = z_compact(code), ty = z_compact(code >> 1);
+    if (tx < tiles_x && ty < tiles_y) {
+      const uint32_t k = cls(cost[ty * tiles_x + tx]);
+      for (int q = 0; q < kZClasses; ++q) mine[q] += (q == (int)k) ? 1u : 0u; // (no dynamic indexing of a register array)
+    }
+  }
+  for (int k = 0; k < kZClasses; ++k) cnt[k][tid] = mine[k];
+  __syncthreads();
+  // exclusive scan over the threads, class by class: wave k takes class k (1024 counts = 16 per lane)
+  if ((tid >> 6) < (uint32_t)kZClasses) {
+    const uint32_t k = tid >> 6, lane = tid & 63u;
+    uint32_t v[16], sum = 0;
+    for (int j = 0; j < 16; ++j) {
+      v[j] = cnt[k][lane * 16 + j];
+      sum += v[j];
+    }
+    uint32_t incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+      if ((int)lane >= off) incl += o;
+    }
+    uint32_t run = incl - sum;
+    for (int j = 0; j < 16; ++j) {
+      cnt[k][lane * 16 + j] = run;
+      run += v[j];
+    }
+    if (lane == 63u) class_base[k] = incl; // the class's total, for now
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (int k = 0; k < kZClasses; ++k) {
+      const uint32_t t = class_base[k];
+      class_base[k] = run;
+      run += t;
+    }
+  }
+  __syncthreads();
+  uint32_t at[kZClasses];
+  for (int k = 0; k < kZClasses; ++k) at[k] = class_base[k] + cnt[k][tid];
+  for (uint32_t code = tid * per; code < min((tid + 1u) * per, codes); ++code) {
+    const uint32_t tx = z_compact(code), ty = z_compact(code >> 1);
+    if (tx < tiles_x && ty < tiles_y) {
+      const uint32_t tile = ty * tiles_x + tx, k = cls(cost[tile]);
+      uint32_t pos = 0;
+      for (int q = 0; q < kZClasses; ++q)
+        if (q == (int)k) pos = at[q]++;
+      order[pos] = tile;
+    }
+  }
+  __syncthreads(); // every cost has been read twice by now
+  for (uint32_t i = tid; i < n; i += 1024) cost[i] = 0;
+}
+
+void launch_order_tiles(hipStream_t s, uint32_t *cost, uint32_t n_tiles, uint32_t *order, uint32_t tiles_x, uint32_t tiles_y, int z_classes) {
+  if (z_classes != 0 && (uint64_t)tiles_x * tiles_y == n_tiles && tiles_x <= 32768u && tiles_y <= 32768u)
+    hipLaunchKernelGGL(k_order_tiles_z, dim3(1), dim3(1024), 0, s, cost, tiles_x, tiles_y, z_classes > kZClasses ? kZClasses : (z_classes < -99 ? -99 : z_classes), order);
+  else
+    hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(1024), 0, s, cost, n_tiles, order);
 }
 
 // =====================================================================================================================
