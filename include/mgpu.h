@@ -303,7 +303,8 @@ int mgpu_frame_wait(MgpuFrame *frame, int slot, float *host_image, float **devic
  * go down ONE stream, in order (two whole-GPU launches enqueued on two streams share the CUs and finish together, which leaves
  * nothing to hide the first copy under).  With several GPUs the copy is enqueued by the render call itself, behind the frame's
  * exchange (rank 0 renders an N-th of a frame while a whole frame crosses PCIe: the copies run as the frames arrive), and
- * mgpu_frame_wait_host only waits for it.  In a process that does not hold rank 0, mgpu_frame_wait_host waits until the slot's
+ * mgpu_frame_wait_host only waits for it.  A frame that is not taken before its slot is rendered into again is lost: the slot then
+ * holds the newer frame, and that is what a later mgpu_frame_wait_host hands out.  In a process that does not hold rank 0, mgpu_frame_wait_host waits until the slot's
  * strips have left and returns MGPU_OK with *host_image = NULL. */
 int mgpu_frame_set_readback(MgpuFrame *frame, int on);
 int mgpu_frame_wait_host(MgpuFrame *frame, int slot, const float **host_image);
@@ -362,7 +363,8 @@ int mgpu_render_panoramic_device(MgpuScene *scene, const double origin[3], int W
 
 /* Device work counters accumulate over every mgpu_render* call made with stats == NULL (calls with stats != NULL zero
  * them first and return that call's own counts).  mgpu_stats_read synchronises the device and returns the running
- * totals (kernel_ms / total_ms are left 0); reset != 0 zeroes them afterwards. */
+ * totals (kernel_ms / total_ms are left 0); reset != 0 zeroes them afterwards.  With the render-ahead on
+ * (mgpu_scene_set_render_ahead) the totals include the frames rendered ahead, served or dropped. */
 int mgpu_stats_read(MgpuScene *scene, MgpuStats *out, int reset);
 
 /* Per-launch kernel timing for asynchronous use: after mgpu_timing_enable(scene, 1) every mgpu_render_strips_device call

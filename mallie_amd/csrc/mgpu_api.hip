@@ -160,8 +160,9 @@ struct MgpuScene {
     uint32_t pass_base;
     uint64_t seed;
   };
-  bool ahead_on = false, ahead_valid = false;
-  AheadKey ahead_key;
+  bool ahead_on = false, ahead_valid = false, ahead_last_valid = false;
+  AheadKey ahead_key;  // what the frame rendered ahead was rendered for
+  AheadKey ahead_last; // the previous call's arguments: a frame is rendered ahead only for a caller seen to continue a sequence
   void *p_ahead[2] = {nullptr, nullptr}; // device frames: the one being copied out and the one rendered ahead
   size_t ahead_bytes = 0;
   int ahead_buf = 0;                     // which of the two holds the frame rendered ahead
@@ -1406,8 +1407,10 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
       size_t free_b = 0, total_b = 0;
       const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
       if (!known) (void)hipGetLastError();
-      // leave a quarter of what is free to the caller's own buffers
-      rc = (known && need * sizeof(float) > free_b - free_b / 4) ? MGPU_ERR_OOM : dev_alloc(s, (void **)&R.p_planes, need * sizeof(float));
+      // leave a quarter of what is free to the caller's own buffers -- while there is something smaller to fall back to; the
+      // smallest layout (one pass of one frame) is simply tried
+      const bool can_shrink = fpl > 1 || group > 1;
+      rc = (known && can_shrink && need * sizeof(float) > free_b - free_b / 4) ? MGPU_ERR_OOM : dev_alloc(s, (void **)&R.p_planes, need * sizeof(float));
       if (!rc) {
         R.planes_floats = need;
         break;
@@ -1716,15 +1719,26 @@ int mgpu_render(MgpuScene *s, const double origin[3], const double corner[3], co
     }
     HIP_TRY(hipEventRecord(s->ahead_done, s->ahead_stream));
     HIP_TRY(hipEventSynchronize(s->ahead_done)); // this call's frame is complete
-    // the next call's frame, under this call's copy
+    // The next call's frame, under this call's copy -- once the caller has been SEEN to come back for the next passes: this call
+    // repeats the previous one's arguments with pass_base moved on by `passes`.  (A caller that renders one frame -- the console
+    // driver, main_console.cc:70 -- or moves the camera every call never pays for a frame nobody asks for, nor waits for one
+    // when the scene is destroyed.)  A speculative launch that fails (no memory for its planes, say) is dropped, not reported:
+    // the frame this call was asked for is complete.
     s->ahead_valid = false;
-    if (pass_base + (uint32_t)passes >= pass_base) {
-      rc = enqueue(pass_base + (uint32_t)passes, s->p_ahead[1 - cur]);
-      if (rc) return rc;
-      s->ahead_key = key;
-      s->ahead_key.pass_base = pass_base + (uint32_t)passes;
-      s->ahead_buf = 1 - cur;
-      s->ahead_valid = true;
+    MgpuScene::AheadKey follows = s->ahead_last;
+    follows.pass_base += (uint32_t)passes;
+    const bool in_sequence = s->ahead_last_valid && memcmp(&key, &follows, sizeof(key)) == 0;
+    s->ahead_last = key;
+    s->ahead_last_valid = true;
+    if (in_sequence && pass_base + (uint32_t)passes >= pass_base) {
+      if (enqueue(pass_base + (uint32_t)passes, s->p_ahead[1 - cur]) == MGPU_OK) {
+        s->ahead_key = key;
+        s->ahead_key.pass_base = pass_base + (uint32_t)passes;
+        s->ahead_buf = 1 - cur;
+        s->ahead_valid = true;
+      } else {
+        (void)hipGetLastError();
+      }
     }
     hipError_t ce = hipMemcpy(image_out + 3 * (size_t)y0 * W, s->p_ahead[cur], img_bytes, hipMemcpyDeviceToHost);
     if (ce != hipSuccess) return fail(MGPU_ERR_HIP, "hipMemcpy of the frame failed: %s", hipGetErrorString(ce));
@@ -2010,6 +2024,7 @@ int mgpu_scene_set_render_ahead(MgpuScene *s, int on) {
 
 int mgpu_render_ahead_stats(MgpuScene *s, unsigned long long *hits, unsigned long long *misses) {
   if (!s) return fail(MGPU_ERR_INVALID, "scene is NULL");
+  std::lock_guard<std::mutex> host_lock(s->host_mutex); // (a render call may be in the middle of updating them)
   if (hits) *hits = s->ahead_hits;
   if (misses) *misses = s->ahead_misses;
   return MGPU_OK;
@@ -2017,6 +2032,7 @@ int mgpu_render_ahead_stats(MgpuScene *s, unsigned long long *hits, unsigned lon
 
 int mgpu_debug_stream_classes(MgpuScene *s, unsigned char *out, size_t npix) { // diagnostic: the cached classification (0 / 1 / 2)
   if (!s || !out) return fail(MGPU_ERR_INVALID, "NULL argument");
+  std::lock_guard<std::mutex> host_lock(s->host_mutex); // (mgpu_render_stream reallocates the scratch under this lock)
   if (!s->stream.cls || npix > s->stream.npix_cap) return fail(MGPU_ERR_INVALID, "no classification of that size is cached");
   int rc = set_device(s);
   if (rc) return rc;
@@ -2026,6 +2042,7 @@ int mgpu_debug_stream_classes(MgpuScene *s, unsigned char *out, size_t npix) { /
 
 int mgpu_stream_stats(MgpuScene *s, double *resolve_ms, int *classified, unsigned long long *retries, uint32_t *uncertain_pixels) {
   if (!s) return fail(MGPU_ERR_INVALID, "scene is NULL");
+  std::lock_guard<std::mutex> host_lock(s->host_mutex); // (mgpu_render_stream reallocates the scratch under this lock)
   if (resolve_ms) *resolve_ms = s->stream_last_ms;
   if (classified) *classified = s->stream_last_fresh ? 1 : 0;
   if (retries) *retries = s->stream_retries;

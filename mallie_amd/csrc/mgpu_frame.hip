@@ -734,12 +734,14 @@ int mgpu_frame_set_readback(MgpuFrame *f, int on) {
 int mgpu_frame_wait_host(MgpuFrame *f, int slot, const float **host_image) {
   if (!f || slot < 0 || slot >= f->in_flight || !host_image) return ffail(MGPU_ERR_INVALID, "bad frame / slot / NULL argument");
   *host_image = nullptr;
-  for (Member &m : f->members) {
-    FHIP(hipSetDevice(m.device));
+  for (Member &m : f->members) // every other member first: its strips have left when this returns, wherever rank 0 stands in the list
     if (m.rank != 0) {
+      FHIP(hipSetDevice(m.device));
       FHIP(hipEventSynchronize(m.slot[slot].exchanged));
-      continue;
     }
+  for (Member &m : f->members) {
+    if (m.rank != 0) continue;
+    FHIP(hipSetDevice(m.device));
     Slot &s = m.slot[slot];
     if (!(s.copy_wanted || s.copy_pending) || !s.host)
       return ffail(MGPU_ERR_INVALID, "slot %d has no read-back in flight (mgpu_frame_set_readback before the render call)", slot);

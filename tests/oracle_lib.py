@@ -43,9 +43,10 @@ def lib():
     global _lib
     if _lib is None:
         src = os.path.join(ORACLE_DIR, "mallie_oracle.c")
-        if not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        path = os.environ.get("MALLIE_ORACLE_LIB", LIB_PATH)  # tests/test_sanitizers_cpu.py: the ASan + UBSan build of the same source
+        if path == LIB_PATH and (not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src)):
             build()
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         vp, sz, u64, u32, i32, dbl = C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_int, C.c_double
         L.mo_bvh_build.argtypes = [vp, sz, vp, sz, dbl, i32, i32, i32, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), vp]
         L.mo_bvh_build.restype = i32

@@ -445,3 +445,19 @@ def test_facade_build_routes_large_meshes_to_the_device_builder(driver, tmp_path
     nodes, idx, _ = M.bvh_build(verts, faces)
     for mode in ("device", "host"):
         assert out[mode]["nodes"].tobytes() == nodes.tobytes() and np.array_equal(out[mode]["indices"], idx), mode
+
+
+@pytest.mark.gpu
+def test_threaded_callers_stress_driver(tmp_path_factory):
+    """tests/cpp/stress_driver.cc: 16 threads of one-ray Scene::Trace-shaped callers (mailbox server + submission queue), frames
+    rendered beside them, scenes created and destroyed meanwhile; every record must equal the batched call's, every frame the
+    first frame's bytes.  (tools/sanitize_gpu.sh runs the same driver against ASan / TSan builds of the library:
+    profiles/r5_sanitizers.txt.)"""
+    out = str(tmp_path_factory.mktemp("stress") / "stress_driver")
+    libdir = os.path.dirname(M.lib_path())
+    cmd = ["g++", "-O1", "-std=c++11", "-pthread", os.path.join(ROOT, "tests", "cpp", "stress_driver.cc"), "-L", libdir,
+           "-lmallie_mgpu", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([out, "16", "400", "6"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "0 records differ" in r.stdout and "0 failed calls" in r.stdout, r.stdout + r.stderr

@@ -1292,13 +1292,22 @@ def test_render_ahead_serves_the_next_pass_and_never_changes_a_frame():
     plane = sc.plane()
     t = O.load_golden("trace_cornell_obj")
     sc.set_render_ahead(True)
-    # (camera, passes, pass_base, window, want_stats, continues the sequence?)
-    calls = [(cam_a, 1, 0, None, False, False), (cam_a, 1, 1, None, False, True), (cam_a, 1, 2, None, False, True),
-             (cam_b, 1, 3, None, False, False), (cam_b, 1, 4, None, False, True), (cam_b, 2, 5, None, False, False),
-             (cam_b, 2, 7, None, False, True), (cam_b, 2, 9, (0, 16, W, 80), False, False), (cam_b, 2, 11, (0, 16, W, 80), False, True),
-             (cam_b, 2, 13, (0, 16, W, 80), True, False), (cam_b, 2, 15, (0, 16, W, 80), False, False), (cam_a, 1, 40, None, False, False)]
-    hits = 0
-    for k, (cam, passes, pb, win, want, cont) in enumerate(calls):
+    # (camera, passes, pass_base, window, want_stats).  A frame is rendered ahead only once a call has been SEEN to continue its
+    # predecessor (same arguments, pass_base moved on by `passes`): the third call of a sequence is the first one served.
+    calls = [(cam_a, 1, 0, None, False), (cam_a, 1, 1, None, False), (cam_a, 1, 2, None, False), (cam_a, 1, 3, None, False),
+             (cam_b, 1, 4, None, False), (cam_b, 1, 5, None, False), (cam_b, 1, 6, None, False), (cam_b, 2, 7, None, False),
+             (cam_b, 2, 9, None, False), (cam_b, 2, 11, None, False), (cam_b, 2, 13, (0, 16, W, 80), False),
+             (cam_b, 2, 15, (0, 16, W, 80), False), (cam_b, 2, 17, (0, 16, W, 80), False), (cam_b, 2, 19, (0, 16, W, 80), True),
+             (cam_b, 2, 21, (0, 16, W, 80), False), (cam_a, 1, 40, None, False)]
+    hits, last, armed = 0, None, None  # the rule, restated: what the previous call asked for, what has been rendered ahead
+    for k, (cam, passes, pb, win, want) in enumerate(calls):
+        key = (cam.tobytes(), passes, win)
+        if want:  # a call that asks for statistics takes the plain path and leaves the render-ahead state alone
+            expect = 0
+        else:
+            expect = 1 if armed == (key, pb) else 0
+            armed = (key, pb + passes) if last == (key, pb - passes) else None
+            last = (key, pb)
         before = sc.render_ahead_stats()["hits"]
         img, cnt, st = sc.render(cam, W, H, mpl, passes, plane, M.RNG_HASH, seed=9, pass_base=pb, window=win, want_stats=want)
         rimg, rcnt, rst = ref.render(cam, W, H, mpl, passes, plane, M.RNG_HASH, seed=9, pass_base=pb, window=win)
@@ -1306,7 +1315,7 @@ def test_render_ahead_serves_the_next_pass_and_never_changes_a_frame():
         if want:  # a call that asks for statistics gets ITS frame's counters, not those of a frame rendered ahead that is still running
             assert all(st[f] == rst[f] for f in ("real_rays", "nodes", "tris", "trace_calls", "paths")), (st, rst)
         served = sc.render_ahead_stats()["hits"] - before
-        assert served == (1 if cont else 0), (k, served)
+        assert served == expect, (k, served, expect)
         hits += served
         if k == 5:  # a ray batch in between: the frame rendered ahead is on the GPU while it runs
             out, hit = sc.trace(t["rays"][:300])
