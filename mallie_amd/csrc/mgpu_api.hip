@@ -94,6 +94,7 @@ struct MgpuScene {
   int device = 0;
   size_t nv = 0, nf = 0, nn = 0, nm = 0;
   int tree_depth = 0;  // deepest node level (root = 0)
+  uint32_t max_leaf_tris = 0; // largest leaf
   bool boxes_ordered = false; // bmin <= bmax in every reachable node (lets the kernels take the min/max slab test)
   int precision = MGPU_PRECISION_FP64; // mgpu_scene_set_precision: which render kernel family the render entry points use
   StreamScratch stream; // MGPU_RNG_STREAM: scratch of the chip-wide resolution, and the cached classification of a camera's pixels
@@ -110,7 +111,8 @@ struct MgpuScene {
   void *p_nodes = nullptr, *p_tris = nullptr, *p_slotn = nullptr, *p_mat = nullptr, *p_verts = nullptr,
        *p_fnodes = nullptr, *p_ftris = nullptr, *p_fnormals = nullptr, *p_fdiffuse = nullptr, // fast mode (float copies)
        *p_faces = nullptr, *p_fvn = nullptr, *p_fvuv = nullptr, *p_overflow = nullptr, *p_wnodes = nullptr,
-       *p_woverflow = nullptr, *p_treelet = nullptr;
+       *p_woverflow = nullptr, *p_treelet = nullptr, *p_treelet5 = nullptr;
+  uint32_t treelet5_n = 0; // the smaller table k_render_w5 holds (two workgroups per CU share the LDS)
   size_t overflow_lanes = 0, woverflow_lanes = 0;
   uint32_t *p_counters = nullptr;         // kCounterRing work counters
   double stream_last_ms = 0.0;           // wall time of the last chip-wide resolution (all passes of the call)
@@ -217,12 +219,13 @@ int upload(MgpuScene *s, void **p, const void *src, size_t bytes) {
 }
 
 // Validates the tree (child / leaf ranges in bounds, no cycles through an explicit visit budget) and returns its depth.
-int tree_depth(const MgpuNode *nodes, size_t nn, size_t nf, int *depth_out, bool *boxes_ordered) {
+int tree_depth(const MgpuNode *nodes, size_t nn, size_t nf, int *depth_out, bool *boxes_ordered, uint32_t *max_leaf_out = nullptr) {
   struct Item { uint32_t node; int depth; };
   std::vector<Item> stack;
   stack.push_back({0u, 0});
   size_t visited = 0;
   int depth = 0;
+  uint32_t max_leaf = 0;
   while (!stack.empty()) {
     Item it = stack.back();
     stack.pop_back();
@@ -241,8 +244,10 @@ int tree_depth(const MgpuNode *nodes, size_t nn, size_t nf, int *depth_out, bool
       if ((size_t)n.data[1] + n.data[0] > nf)
         return fail(MGPU_ERR_INVALID, "leaf %u: range [%u,+%u) exceeds %zu faces", it.node, n.data[1], n.data[0], nf);
       if (n.data[0] >= kWInterior) return fail(MGPU_ERR_INVALID, "leaf %u: %u triangles in one leaf", it.node, n.data[0]);
+      if (n.data[0] > max_leaf) max_leaf = n.data[0];
     }
   }
+  if (max_leaf_out) *max_leaf_out = max_leaf;
   *depth_out = depth;
   return MGPU_OK; // *boxes_ordered was initialised by the caller
 }
@@ -403,8 +408,8 @@ int slot_overflow(MgpuScene *s, RenderSlot &r, size_t lanes, DScene &d) {
 }
 
 // The same for the wide traversal of the HBM-resident render kernel.
-int slot_woverflow(MgpuScene *s, RenderSlot &r, size_t lanes, DScene &d) {
-  const int extra = s->tree_depth - kWideStackLds;
+int slot_woverflow(MgpuScene *s, RenderSlot &r, size_t lanes, DScene &d, int lds_entries = kWideStackLds) {
+  const int extra = s->tree_depth - lds_entries;
   d.wstack_overflow = nullptr;
   d.woverflow_cap = 0;
   if (extra <= 0) return MGPU_OK;
@@ -818,7 +823,8 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
     if (indices[i] >= nf) return fail(MGPU_ERR_INVALID, "indices[%zu] = %u >= %zu faces", i, indices[i], nf);
   int depth = 0;
   bool boxes_ordered = true;
-  int rc = tree_depth(nodes, nn, nf, &depth, &boxes_ordered);
+  uint32_t max_leaf = 0;
+  int rc = tree_depth(nodes, nn, nf, &depth, &boxes_ordered, &max_leaf);
   if (rc) return rc;
   if (depth + 1 > 512) return fail(MGPU_ERR_STACK, "tree depth %d needs more than the reference's 512 stack entries", depth);
 
@@ -827,6 +833,7 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
   s->device = device;
   s->nv = nv; s->nf = nf; s->nn = nn; s->nm = nm;
   s->tree_depth = depth;
+  s->max_leaf_tris = max_leaf;
   s->boxes_ordered = boxes_ordered;
   s->stack_need = depth + 1;
   s->cap = pick_stack_cap(s->stack_need);
@@ -937,6 +944,15 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
       TRY_OR_FREE(upload(s, &s->p_treelet, tl.data(), tl.size() * sizeof(WNode)));
       s->d.treelet = (const WNode *)s->p_treelet;
       s->d.treelet_n = (uint32_t)tl.size();
+      // k_render_w5 (mgpu_render_w5.hip): two 640-thread workgroups per CU, each with its own, smaller table
+      const bool w5_small = getenv("MGPU_W5_BLOCK") && atoi(getenv("MGPU_W5_BLOCK")) == 320; // (experiment: four workgroups of five waves)
+      const size_t per_wg = (size_t)160 * 1024 / (w5_small ? 4 : 2) - 4096, w5_waves = (w5_small ? 5 : 10) * render_w5_wave_bytes();
+      const size_t w5_max = per_wg > w5_waves ? (per_wg - w5_waves) / sizeof(WNode) : 0;
+      if (w5_max >= 1 && getenv("MGPU_W5") && atoi(getenv("MGPU_W5")) != 0) { // (opt-in while the kernel is an experiment)
+        build_treelet(nodes, nn, std::min(max_records, w5_max), tl);
+        TRY_OR_FREE(upload(s, &s->p_treelet5, tl.data(), tl.size() * sizeof(WNode)));
+        s->treelet5_n = (uint32_t)tl.size();
+      }
     }
   }
   s->d.wstack_overflow = nullptr;
@@ -981,7 +997,7 @@ int mgpu_scene_destroy(MgpuScene *s) {
   (void)hipDeviceSynchronize();
   void *ptrs[] = {s->p_nodes, s->p_tris, s->p_slotn, s->p_mat, s->p_verts, s->p_faces, s->p_fvn, s->p_fvuv,
                   s->p_overflow, s->p_counters, s->p_stats, s->p_wave_log, s->p_host_img, s->p_trace, s->p_wnodes,
-                  s->p_woverflow, s->p_fnodes, s->p_ftris, s->p_fnormals, s->p_fdiffuse, s->p_treelet};
+                  s->p_woverflow, s->p_fnodes, s->p_ftris, s->p_fnormals, s->p_fdiffuse, s->p_treelet, s->p_treelet5};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (s->p_trace_pinned) (void)hipHostFree(s->p_trace_pinned);
@@ -1301,6 +1317,25 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
 #endif
   if (kern == 1) shmem = (size_t)(block / 64) * WStack<kWideStackLds>::kWaveBytes + (treelet ? (size_t)s->d.treelet_n * sizeof(WNode) : 0);
   int per_cu = kern == 2 || treelet ? 1 : (kern == 1 ? 4 : 2); // workgroups per CU: 16 waves per CU for the state-machine kernels
+  // k_render_w5 (mgpu_render_w5.hip): the same walk with the state divided by hand for five waves per SIMD -- grey scenes whose
+  // references fit the 12-byte stack entries (mgpu_device.hpp, WStackP), path lengths and windows that fit the packed cold words
+  bool w5 = false;
+  if (kern == 1 && treelet && s->p_treelet5 && s->d.grey && s->nf < (1u << 24) && s->nn < (1u << 30) && s->max_leaf_tris < 64u && maxPathLength <= 255 &&
+      passes <= 0xFFFF && win_w <= 0xFFFF && n_rows <= 0xFFFF && s->precision != MGPU_PRECISION_FP32) {
+    const char *e = getenv("MGPU_W5");
+    w5 = e && atoi(e) != 0;
+  }
+  uint32_t w5_treelet_n = 0;
+  if (w5) {
+    const char *e = getenv("MGPU_W5_BLOCK");
+    block = e && atoi(e) == 320 ? 320 : 640;
+    per_cu = block == 640 ? 2 : 4;
+    const size_t per_wg = (size_t)160 * 1024 / (size_t)per_cu - 4096, waves = (size_t)(block / 64) * render_w5_wave_bytes();
+    w5_treelet_n = (uint32_t)std::min<size_t>(s->treelet5_n, per_wg > waves ? (per_wg - waves) / sizeof(WNode) : 0);
+    if (w5_treelet_n < 1 || w5_treelet_n < s->treelet5_n) w5 = false; // (a prefix of the table is not a table: its references point past it)
+    else shmem = waves + (size_t)w5_treelet_n * sizeof(WNode);
+    if (!w5) { block = 1024; per_cu = 1; }
+  }
   // fast mode (mgpu_scene_set_precision): k_render_f32 on the float copy of the scene -- 32-byte nodes and 48-byte
   // triangles, so scenes twice the size still fit in LDS beside the stacks
   bool f32_lds = false;
@@ -1329,7 +1364,7 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
   rc = slot_overflow(s, R, blocks * block, dsc);
   if (rc) return rc;
   if (kern == 1) {
-    rc = slot_woverflow(s, R, blocks * block, dsc);
+    rc = slot_woverflow(s, R, blocks * block, dsc, w5 ? render_w5_stack_entries() : kWideStackLds);
     if (rc) return rc;
   }
 
@@ -1442,6 +1477,11 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
     if (!std::isfinite(P.hint_q2) || !std::isfinite(s->hint_rho + P.hint_q)) P.lds_hint_cap = 0u;
   }
   if (treelet) P.lds_nodes_bytes = (uint32_t)(sizeof(WNode) * s->d.treelet_n); // what the HBM-resident kernel stages into LDS
+  if (w5) {
+    P.lds_nodes_bytes = (uint32_t)(sizeof(WNode) * w5_treelet_n);
+    dsc.treelet = (const WNode *)s->p_treelet5;
+    dsc.treelet_n = w5_treelet_n;
+  }
   FScene fsc{};
   if (kern == 3) {
     P.lds_nodes_bytes = (uint32_t)(sizeof(FNode) * s->nn);
@@ -1549,6 +1589,8 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
       HIP_TRY(hipGetLastError());
     } else if (kern == 3) {
       HIP_TRY(launch_render_f32(s->cap, f32_lds, dim3((unsigned)blocks), st, shmem, fsc, P));
+    } else if (w5) {
+      HIP_TRY(launch_render_w5(block, dim3((unsigned)blocks), st, shmem, dsc, P));
     } else {
       HIP_TRY(launch_render_sm(se_bytes, kern == 2, prim, block, dim3((unsigned)blocks), st, shmem, dsc, P));
     }

@@ -551,14 +551,53 @@ template <int K> struct WStack {
   }
 };
 
+// The same stack with 12-byte entries (k_render_w5, mgpu_render_w5.hip): {ref, tag} in one word.  Leaf child: first slot (< 2^24) |
+// triangle count (< 64) << 24; interior child: kPkInterior | its reference (node index < 2^30, or kWTreelet | table index).  The
+// host launches that kernel only for scenes whose references fit (mgpu_api.hip, w5_eligible).
+constexpr uint32_t kPkInterior = 0x40000000u;
+template <int K> struct WStackP {
+  __attribute__((address_space(3))) uint32_t *rt; // &s_rt[wave][0][lane]
+  __attribute__((address_space(3))) double *tm;   // &s_tm[wave][0][lane]
+  uint4 *overflow;                                // this lane's column, entries K.. (null when the tree is shallow)
+  __device__ __forceinline__ void put(int i, uint32_t ref, uint32_t tag, double t) const {
+    const uint32_t pk = tag == kWInterior ? (ref | kPkInterior) : (ref | (tag << 24));
+    if (i < K) {
+      rt[i * 64] = pk;
+      tm[i * 64] = t;
+    } else {
+      const unsigned long long tb = (unsigned long long)__double_as_longlong(t);
+      overflow[i - K] = make_uint4(pk, 0u, (uint32_t)tb, (uint32_t)(tb >> 32));
+    }
+  }
+  __device__ __forceinline__ void get(int i, uint32_t &ref, uint32_t &tag, double &t) const {
+    uint32_t pk;
+    if (i < K) {
+      pk = rt[i * 64];
+      t = tm[i * 64];
+    } else {
+      const uint4 a = overflow[i - K];
+      pk = a.x;
+      t = __longlong_as_double((long long)(((unsigned long long)a.w << 32) | (unsigned long long)a.z));
+    }
+    const bool interior = (pk & kPkInterior) != 0u;
+    ref = interior ? (pk & ~kPkInterior) : (pk & 0x00FFFFFFu);
+    tag = interior ? kWInterior : (pk >> 24);
+  }
+  static constexpr size_t kWaveBytes = (size_t)K * 64 * (sizeof(uint32_t) + sizeof(double));
+  __device__ __forceinline__ void bind(unsigned char *wave_base, int lane) {
+    tm = (__attribute__((address_space(3))) double *)(wave_base) + lane;
+    rt = (__attribute__((address_space(3))) uint32_t *)(wave_base + (size_t)K * 64 * sizeof(double)) + lane;
+  }
+};
+
 enum : int { WT_NODE = 0, WT_TRI = 1, WT_DONE = 2 };
 
 // Up to REPS interior nodes for the calling lane.  `cur` = record to enter next (kWNone: take one from the stack), `sp` =
 // entries on the stack.  Returns WT_TRI with [tri_cur, tri_end) set when a leaf was opened, WT_DONE when the stack ran
 // empty, WT_NODE when the repetitions are used up.  n_nodes += 2 per record entered.
 // TL: references with kWTreelet set are read from the treelet table at `tl` in LDS.
-template <bool kPlain, int REPS, int K, bool TL = false>
-__device__ __forceinline__ int wide_node_step(const WNode *__restrict__ wn, const WStack<K> &stk, V3 org, double ix,
+template <bool kPlain, int REPS, int K, bool TL = false, typename STK = WStack<K>>
+__device__ __forceinline__ int wide_node_step(const WNode *__restrict__ wn, const STK &stk, V3 org, double ix,
                                               double iy, double iz, bool sx, bool sy, bool sz, uint32_t sgn /* sx | sy << 1 | sz << 2 */,
                                               double bt, uint32_t &cur,
                                               int &sp, uint32_t &tri_cur, uint32_t &tri_end, uint32_t &n_nodes,

@@ -98,6 +98,11 @@ int pick_stack_cap(int needed_entries);
 // wave-scheduled state-machine renderer (mgpu_render_sm.hip); shmem = stacks (+ scene when lds_scene)
 hipError_t launch_render_sm(int stack_entry_bytes, bool lds_scene, bool prim, int block, dim3 grid, hipStream_t s, size_t shmem, const DScene &sc,
                             const RenderParams &p);
+// k_render_w5 (mgpu_render_w5.hip): the HBM-resident walk with its state divided by hand for five waves per SIMD.  block = 640 | 320;
+// shmem = block / 64 * render_w5_wave_bytes() + the treelet's bytes (p.lds_nodes_bytes)
+hipError_t launch_render_w5(int block, dim3 grid, hipStream_t s, size_t shmem, const DScene &sc, const RenderParams &p);
+size_t render_w5_wave_bytes();   // LDS per wave: far-child stack + SHADE-only state
+int render_w5_stack_entries();   // far-child stack entries per lane it keeps in LDS
 size_t render_sm_prim_bytes(); // LDS the LDS-resident variant wants behind the scene for its primary-ray staging (0: compiled out)
 // LDS-resident scene: a stack entry is a node index -- 1 byte up to 256 nodes, 2 up to 65 536 (larger trees never fit) --
 // and a lane needs tree depth + 1 of them (bvh_accel.cc:805-834: a pop, then at most two pushes per level)

@@ -265,6 +265,28 @@ __global__ __launch_bounds__(kSBlock) void k_stream_classify(DScene sc, StreamPa
     const int gx = (int)(pix % (uint32_t)P.W), gy = (int)(pix / (uint32_t)P.W);
     int hits = 0;
     const float a[5] = {-0.5f, 0.5f, -0.5f, 0.5f, 0.0f}, b[5] = {-0.5f, -0.5f, 0.5f, 0.5f, 0.0f};
+    // The plane's horizon, analytically (round-4 review item 4).  Plane::intersect accepts a ray iff |v.n| > 1024 FLT_EPSILON and
+    // t = -(o.n + d) / (v.n) > 0 (prim-plane.cc:8-44): both conditions change only where v.n passes through the band
+    // [-1024 eps, +1024 eps].  v.n is a smooth function of the sample position, all but linear over one pixel: when the interval its
+    // four corner values span, widened by a sixteenth of its width, reaches that band, some jitter of this pixel may be accepted and another
+    // refused -- the pixel is uncertain from the first call on, whatever the sixteen probes below would have said (they found
+    // the 0.08-pixel band of the reference's default view one failed verification at a time).  Marking more pixels uncertain is
+    // always safe: an uncertain pixel's flag is traced, not assumed.
+    if (P.has_plane) {
+      const V3 n = v3((double)P.plane[0], (double)P.plane[1], (double)P.plane[2]);
+      float lo = __builtin_inff(), hi = -__builtin_inff();
+      for (int k = 0; k < 4; ++k) {
+        const V3 d = camera_dir(P.frame, (double)((float)gx + a[k]), (double)((float)gy + b[k]));
+        const float vn = (float)dot(normalized_w(d), n); // plane_hit's own expression
+        lo = fminf(lo, vn);
+        hi = fmaxf(hi, vn);
+      }
+      const float thr = 1.1920929e-07f * 1024.0f, pad = 0.0625f * (hi - lo) + 1.0e-9f; // (second-order terms of v.n across a pixel are ~1e-3 of its span; the float rounding of v.n ~1e-11)
+      if (!(lo - pad > thr) && !(hi + pad < -thr)) { // (a NaN lands here too)
+        cls[pix] = 2;
+        continue;
+      }
+    }
     for (int k = 0; k < 5; ++k) hits += primary_hits<CAP>(sc, stk, P, gx, gy, a[k], b[k], c) ? 1 : 0;
     // ... and kClassifyRandom jitters of the pixel's own: features thinner than a pixel that touch neither a corner nor the centre --
     // seen at once on the reference's default view: the eye sits at the height of the Cornell box's floor, and between the walls'

@@ -826,6 +826,51 @@ def test_grey_and_three_channel_kernels_agree(monkeypatch):
     assert imgs[0].tobytes() == imgs[1].tobytes() == oimg.tobytes()
 
 
+@pytest.mark.parametrize("block", ["640", "320"])
+def test_hand_partitioned_five_wave_kernel_equals_the_default(block, monkeypatch):
+    """k_render_w5 (mgpu_render_w5.hip; opt-in with MGPU_W5=1): the HBM-resident walk with its state divided by hand between
+    registers and LDS for five waves per SIMD.  Same frames byte for byte, same counters word for word as k_render_sm on the same
+    scene -- a suzanne grid too large for LDS, several passes (planes), one pass (the image itself), a window with edge tiles,
+    cornellbox through the forced HBM path against the oracle -- and scenes it cannot take (three-channel materials) fall back."""
+    from mallie_amd.scenes import suzanne_grid
+    c = O.load_golden("cornell_obj")
+    verts, faces, mats, normals = suzanne_grid(c["verts"], c["faces"], 6)
+    W, H = 320, 200
+    frame = M.camera_frame((0.0, 40.0, 80.0), (0.0, 0.0, 0.0), width=W, height=H)
+    ref = M.Scene(verts, faces, mats, normals, None)
+    plane = ref.plane()
+    monkeypatch.setenv("MGPU_W5", "1")
+    monkeypatch.setenv("MGPU_W5_BLOCK", block)
+    sc = M.Scene(verts, faces, mats, normals, None)  # (its smaller treelet is made when the scene is created)
+    for (mpl, passes, win) in [(5, 4, None), (9, 1, None), (3, 2, (3, 5, 301, 187)), (1, 3, None)]:
+        monkeypatch.setenv("MGPU_W5", "1")
+        img, cnt, st = sc.render(frame, W, H, mpl, passes, plane, M.RNG_HASH, seed=11, pass_base=2, window=win)
+        monkeypatch.setenv("MGPU_W5", "0")
+        rimg, rcnt, rst = ref.render(frame, W, H, mpl, passes, plane, M.RNG_HASH, seed=11, pass_base=2, window=win)
+        assert img.tobytes() == rimg.tobytes() and np.array_equal(cnt, rcnt), (mpl, passes, win)
+        assert all(st[f] == rst[f] for f in ("real_rays", "nodes", "tris", "trace_calls", "paths")), (st, rst)
+    # the Cornell scene through the HBM path, against the oracle
+    monkeypatch.setenv("MGPU_W5", "1")
+    monkeypatch.setenv("MGPU_RENDER_KERNEL", "sm")
+    g = O.load_golden("cornell_obj")
+    sc2 = M.Scene(g["verts"].astype(np.float64), g["faces"], g["matIDs"], g["normals"], None, g["nodes"], g["indices"])
+    osc = O.scene_from_golden("cornell_obj")
+    W2, H2 = 96, 80
+    cam = M.camera_frame((0, 0, 20), (0, 0, 0), width=W2, height=H2)
+    img, cnt, st = sc2.render(cam, W2, H2, 5, 4, sc2.plane(), M.RNG_HASH, seed=42, pass_base=3)
+    oimg, ocnt, ost, _ = osc.render(cam, W2, H2, 5, 4, osc.plane(), O.RNG_HASH, seed=42, pass_base=3)
+    assert_images_match(img, oimg, "k_render_w5 vs oracle")
+    assert np.array_equal(cnt, ocnt)
+    assert_same_work(st, ost)
+    # three-channel materials: not its scene, k_render_sm takes it
+    matd = np.array([[0.25, 0.5, 0.75], [0.75, 0.75, 0.75]])
+    ids = (np.arange(len(g["faces"])) % 2).astype("u4")
+    sc3 = M.Scene(g["verts"].astype(np.float64), g["faces"], ids, g["normals"], None, g["nodes"], g["indices"], mat_diffuse=matd)
+    osc3 = O.OracleScene(g["verts"].astype(np.float64), g["faces"], ids, g["normals"], None, g["nodes"], g["indices"], mat_diffuse=matd)
+    img3 = sc3.render(cam, W2, H2, 4, 2, sc3.plane(), M.RNG_HASH, seed=3)[0]
+    assert_images_match(img3, osc3.render(cam, W2, H2, 4, 2, osc3.plane(), O.RNG_HASH, seed=3)[0], "coloured scene with MGPU_W5=1")
+
+
 def test_render_window_and_edge_sizes():
     sc, osc = gpu_scene("cornell_obj"), O.scene_from_golden("cornell_obj")
     plane = osc.plane()
