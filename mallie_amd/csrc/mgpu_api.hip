@@ -1988,15 +1988,14 @@ int mgpu_render_stream(MgpuScene *s, const double origin[3], const double corner
       }
       uint32_t retries = 0;
       const double tr0 = now_ms();
-      hipError_t e = stream_states_resolve(s->cap, 0, s->d, P, s->stream, s->num_cu, fresh, &retries);
+      bool unsettled = false;
+      hipError_t e = stream_states_resolve(s->cap, 0, s->d, P, s->stream, s->num_cu, fresh, &retries, &unsettled);
       s->stream_last_ms = now_ms() - tr0; // the resolution ends with a synchronisation (it reads the verification's verdict)
       s->stream_last_fresh = fresh;
-      if (e == hipErrorUnknown) { // its verification kept finding new sub-pixel features (64 attempts): the one-workgroup walk needs no classes
-        (void)hipGetLastError();
+      if (e == hipSuccess && unsettled) { // its verification kept finding new sub-pixel features (64 attempts): the one-workgroup walk needs no classes
         s->stream.key_has_plane = -1;
         TRY_S(hipMemcpy(d_state, stream_state, 16, hipMemcpyHostToDevice));
         TRY_S(launch_stream_states(s->cap, 0, s->d, P));
-        e = hipSuccess;
         retries = 64;
       }
       if (e != hipSuccess) {

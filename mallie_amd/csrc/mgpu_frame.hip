@@ -15,6 +15,10 @@
 #include <dlfcn.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -157,6 +161,79 @@ struct MgpuFrame {
   // not rendered into again before the copy has left it.  mgpu_frame_wait_host hands the pinned buffer out.
   bool readback = false;
   bool broken = false; // a render call failed half-way: streams and slots are out of step, only destroy is allowed
+  // One process driving several GPUs: the launch phase of a render call (waits, the render launch, its events -- ~40 us of host
+  // time per member) is enqueued by one thread PER MEMBER, so that a call costs the slowest member's enqueue, not their sum
+  // (0.33 ms per call at eight members against an ideal eighth-frame of 0.65 ms: profiles/r4_multi_ranks_on_one_gpu.txt).
+  // MGPU_FRAME_ENQUEUE_THREADS=1 (opt-in).  The exchange phase stays on the caller's thread: it
+  // is one RCCL group / one chain of copies on rank 0's stream.
+  struct EnqueuePool *pool = nullptr;
+};
+
+// One worker thread per member of a frame object that drives several GPUs from one process (MgpuFrame::pool).  run() hands every
+// worker the same job (called with the worker's member index) and returns when all of them have finished: the largest return code,
+// and that worker's error text in the caller's thread-local message buffer.
+struct EnqueuePool {
+  struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    const std::function<int(size_t)> *job = nullptr; // posted by run(), cleared by the worker
+    bool quit = false, done = true;
+    int rc = MGPU_OK;
+    char err[512] = "";
+  };
+  std::vector<Worker *> workers;
+  explicit EnqueuePool(size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+      Worker *w = new Worker();
+      w->th = std::thread([w, i] {
+        std::unique_lock<std::mutex> lk(w->mu);
+        for (;;) {
+          w->cv.wait(lk, [w] { return w->quit || w->job != nullptr; });
+          if (w->quit) return;
+          const std::function<int(size_t)> *job = w->job;
+          lk.unlock();
+          const int rc = (*job)(i);
+          lk.lock();
+          w->rc = rc;
+          if (rc) snprintf(w->err, sizeof(w->err), "%s", g_ferr); // this thread's message, for the caller's thread
+          w->job = nullptr;
+          w->done = true;
+          w->cv.notify_all();
+        }
+      });
+      workers.push_back(w);
+    }
+  }
+  ~EnqueuePool() {
+    for (Worker *w : workers) {
+      {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->quit = true;
+      }
+      w->cv.notify_all();
+      w->th.join();
+      delete w;
+    }
+  }
+  int run(const std::function<int(size_t)> &job) {
+    for (Worker *w : workers) {
+      std::lock_guard<std::mutex> lk(w->mu);
+      w->job = &job;
+      w->done = false;
+      w->cv.notify_all();
+    }
+    int rc = MGPU_OK;
+    for (Worker *w : workers) {
+      std::unique_lock<std::mutex> lk(w->mu);
+      w->cv.wait(lk, [w] { return w->done; });
+      if (w->rc && !rc) {
+        rc = w->rc;
+        snprintf(g_ferr, sizeof(g_ferr), "%s", w->err);
+      }
+    }
+    return rc;
+  }
 };
 
 namespace {
@@ -332,6 +409,8 @@ int mgpu_frame_unique_id(unsigned char id[128]) {
 
 int mgpu_frame_destroy(MgpuFrame *f) {
   if (!f) return MGPU_OK;
+  delete f->pool; // (its workers are idle between render calls)
+  f->pool = nullptr;
   for (Member &m : f->members) {
     (void)hipSetDevice(m.device);
     (void)hipDeviceSynchronize();
@@ -433,6 +512,10 @@ int mgpu_frame_create(MgpuScene *const *scenes, const int *devices, int n, int W
     mgpu_frame_destroy(f);
     return rc;
   }
+  if (n >= 2) { // (MgpuFrame::pool; opt-in until it has been measured on hardware: MGPU_FRAME_ENQUEUE_THREADS=1)
+    const char *e = getenv("MGPU_FRAME_ENQUEUE_THREADS");
+    if (e && atoi(e) != 0) f->pool = new (std::nothrow) EnqueuePool((size_t)n);
+  }
   *out = f;
   return MGPU_OK;
 }
@@ -490,7 +573,9 @@ static int render_frames_enqueue(MgpuFrame *f, const double cam[12], int maxPath
   const int W = f->W, H = f->H, sh = f->strip_h, world = f->world;
   const bool exchange = world > 1 || f->force_exchange;
   const bool block = f->exchange_mode == MGPU_EXCHANGE_BLOCK;
-  for (Member &m : f->members) {
+  // the launch phase of one member (its own device, streams and events: members do not touch each other's here)
+  auto launch_member = [&](size_t mi) -> int {
+    Member &m = f->members[mi];
     FHIP(hipSetDevice(m.device));
     hipStream_t rs = render_stream(f, m, ks[0]); // the launch and the copies of the whole batch
     // the slots' previous frames must have left their buffers: their exchange is the last thing that touched them
@@ -518,6 +603,17 @@ static int render_frames_enqueue(MgpuFrame *f, const double cam[12], int maxPath
       FHIP(hipEventRecord(s.rendered, rs));
     }
     if (exchange) FHIP(hipStreamWaitEvent(m.comm_stream, m.slot[ks[n - 1]].rendered, 0));
+    return MGPU_OK;
+  };
+  if (f->pool) {
+    const std::function<int(size_t)> job = launch_member;
+    const int rc = f->pool->run(job);
+    if (rc) return rc;
+  } else {
+    for (size_t mi = 0; mi < f->members.size(); ++mi) {
+      const int rc = launch_member(mi);
+      if (rc) return rc;
+    }
   }
   Member *root = nullptr; // the member that holds rank 0 (copy transport: the one that moves everybody's bytes)
   for (Member &m : f->members)

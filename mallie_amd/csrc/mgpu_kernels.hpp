@@ -178,8 +178,9 @@ struct StreamScratch {
 };
 size_t stream_scratch_sarr_cap(size_t npix);
 size_t stream_scratch_f_bytes();
+// *unsettled_out: the verification asked for more than 64 repetitions -- no table was written; the caller takes k_stream_states
 hipError_t stream_states_resolve(int cap, hipStream_t st, const DScene &sc, const StreamParams &p, StreamScratch &scratch, int num_cu, bool fresh_camera,
-                                 uint32_t *retries_out);
+                                 uint32_t *retries_out, bool *unsettled_out);
 void stream_jump_matrices(uint32_t *out /* kStreamJumpBits * 128 * 4 words */);
 // k_trace_sm (mgpu_trace_sm.hip): persistent, wave-scheduled batched trace; `counter` = one zeroed device word
 hipError_t launch_trace_sm(dim3 grid, hipStream_t s, const DScene &sc, const MgpuRay *rays, uint32_t n,

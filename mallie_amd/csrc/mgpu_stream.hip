@@ -519,7 +519,8 @@ template <typename K> hipError_t grant_lds(K kern, size_t dyn) {
   } while (0)
 
 template <int CAP>
-hipError_t resolve_cap(hipStream_t st, const DScene &sc, StreamParams P, StreamScratch &X, int num_cu, bool fresh_camera, uint32_t *retries_out) {
+hipError_t resolve_cap(hipStream_t st, const DScene &sc, StreamParams P, StreamScratch &X, int num_cu, bool fresh_camera, uint32_t *retries_out,
+                       bool *unsettled_out) {
   const uint32_t npix = (uint32_t)P.W * (uint32_t)P.H;
   const uint32_t E = 3u * (uint32_t)(P.maxPathLength - 1);
   // jump levels: the largest exponent is a whole pass's draws
@@ -540,7 +541,11 @@ hipError_t resolve_cap(hipStream_t st, const DScene &sc, StreamParams P, StreamS
   if (fresh_camera) hipLaunchKernelGGL(k_stream_classify<CAP>, dim3(wide), dim3(kSBlock), 0, st, sc, P, X.cls);
   uint32_t retries = 0;
   for (;; ++retries) {
-    if (retries > 64) return hipErrorUnknown; // every retry makes at least one more pixel uncertain; this is not convergence trouble
+    if (retries > 64) { // every retry makes at least one more pixel uncertain; this is not convergence trouble
+      *unsettled_out = true; // (a verdict of its own, not a HIP error code: the caller falls back to the one-workgroup walk)
+      if (retries_out) *retries_out = retries;
+      return hipSuccess;
+    }
     hipLaunchKernelGGL(k_stream_scan_partial, dim3(n_blocks), dim3(kSBlock), 0, st, X.cls, npix, X.block_sum);
     hipLaunchKernelGGL(k_stream_scan_blocks, dim3(1), dim3(kSBlock), 0, st, X.block_sum, n_blocks, X.totals);
     hipLaunchKernelGGL(k_stream_scan_final, dim3(n_blocks), dim3(kSBlock), 0, st, X.cls, npix, X.block_sum, X.C, X.J, X.U);
@@ -581,11 +586,12 @@ size_t stream_scratch_sarr_cap(size_t npix) { return (npix + kRoundL - 1) / kRou
 size_t stream_scratch_f_bytes() { return 2 * (size_t)kRoundCand; }
 
 hipError_t stream_states_resolve(int cap, hipStream_t st, const DScene &sc, const StreamParams &p, StreamScratch &scratch, int num_cu, bool fresh_camera,
-                                 uint32_t *retries_out) {
+                                 uint32_t *retries_out, bool *unsettled_out) {
+  *unsettled_out = false;
   switch (cap) {
-  case 16: return resolve_cap<16>(st, sc, p, scratch, num_cu, fresh_camera, retries_out);
-  case 24: return resolve_cap<24>(st, sc, p, scratch, num_cu, fresh_camera, retries_out);
-  default: return resolve_cap<32>(st, sc, p, scratch, num_cu, fresh_camera, retries_out);
+  case 16: return resolve_cap<16>(st, sc, p, scratch, num_cu, fresh_camera, retries_out, unsettled_out);
+  case 24: return resolve_cap<24>(st, sc, p, scratch, num_cu, fresh_camera, retries_out, unsettled_out);
+  default: return resolve_cap<32>(st, sc, p, scratch, num_cu, fresh_camera, retries_out, unsettled_out);
   }
 }
 

@@ -1447,17 +1447,19 @@ def test_c_abi_frame_readback_runs_under_the_next_frame(world, in_flight, monkey
     fr.close()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "block"), (3, "strips"), (8, "block"), (8, "strips")])
-def test_c_abi_frame_with_several_ranks_on_one_gpu(world, mode, monkeypatch):
+@pytest.mark.parametrize("world,mode,threads", [(2, "block", "0"), (3, "strips", "0"), (8, "block", "0"), (8, "strips", "0"), (3, "block", "1"), (8, "block", "1")])
+def test_c_abi_frame_with_several_ranks_on_one_gpu(world, mode, threads, monkeypatch):
     """The N > 1 machinery of mgpu_frame_* with N = 2, 3, 8 ranks on the ONE GPU of the test box: MGPU_FRAME_TRANSPORT=copy puts a
     device-to-device copy where every ncclSend / ncclRecv pair would be and lets the ranks share a device; everything else is
     the production path -- one scene per rank, every rank renders ITS interleaved strips (ragged height: the last strip is
     partial and some ranks own one strip more than others), rank 0's staging area and strided placement (block) or per-strip
     pieces (strips), slot events, three frames in flight, a batch of three frames per launch.  Every assembled frame must equal
-    the single-launch frame of the same passes byte for byte."""
+    the single-launch frame of the same passes byte for byte.  threads = "1": the launch phase of a render call enqueued by one
+    host thread per member (MGPU_FRAME_ENQUEUE_THREADS, mgpu_frame.hip: EnqueuePool)."""
     import torch
     monkeypatch.setenv("MGPU_FRAME_TRANSPORT", "copy")
     monkeypatch.setenv("MGPU_FRAME_EXCHANGE", mode)
+    monkeypatch.setenv("MGPU_FRAME_ENQUEUE_THREADS", threads)
     scenes = [gpu_scene("cornell_obj") for _ in range(world)]
     W, H, mpl, passes = 200, 203, 5, 2
     cam = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
