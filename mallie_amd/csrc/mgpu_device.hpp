@@ -15,6 +15,26 @@
 #define MGPU_SAMPLE_MATH 1 // 0 = acos/sincos transcription, 1 = algebraically reduced evaluation (default)
 #endif
 
+// ---- what the wave64 emulator of the tests (tests/emu, -DMGPU_EMU) needs spelled differently; on the GPU these ARE the statements they name ----
+#ifndef MGPU_EMU
+// no-op statements that pin loaded values to registers where they stand (keeps loads of one record together)
+#define MGPU_KEEP1(a) asm volatile("" : "+v"(a))
+#define MGPU_KEEP2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#define MGPU_KEEP4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#define MGPU_XCC_ID(v) asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)) // which XCD this wave runs on
+#define MGPU_DYN_SHARED(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
+// Does ANY lane executing this -- possibly divergent -- code satisfy p?  Only for choices between two forms that give every lane
+// the same bits (a shorter instruction sequence when all lanes qualify); the emulator lets every lane answer for itself.
+#define MGPU_ANY(p) (__ballot(p) != 0ull)
+#else
+#define MGPU_KEEP1(a) ((void)0)
+#define MGPU_KEEP2(a, b) ((void)0)
+#define MGPU_KEEP4(a, b, c, d) ((void)0)
+#define MGPU_XCC_ID(v) ((v) = emu::g_cur->block_idx.x)
+#define MGPU_DYN_SHARED(T, name) T *name = reinterpret_cast<T *>(emu::g_cur->dyn_shared)
+#define MGPU_ANY(p) (p)
+#endif
+
 #include "mgpu_sincos.hpp"
 
 namespace mgpu {
@@ -157,7 +177,7 @@ __device__ __forceinline__ V3 normalized(V3 a) {
 __device__ __forceinline__ V3 normalized_w(V3 a) {
   const double d2 = a.x * a.x + a.y * a.y + a.z * a.z;
   const bool ok = d2 > 1.0e-11 && d2 < 1.0e+100;
-  if (__builtin_expect(__ballot(!ok) != 0ull, 0)) return normalized(a);
+  if (__builtin_expect(MGPU_ANY(!ok), 0)) return normalized(a);
   const double inv = rcp_core(sqrt_core(d2));
   return v3(a.x * inv, a.y * inv, a.z * inv);
 }
@@ -171,7 +191,7 @@ __device__ __forceinline__ bool inverse_dir_w(V3 dir, double &ix, double &iy, do
   iz = rcp_core(dir.z);
   const double lo = 0x1p-400, hi = 0x1p+400;
   const bool ok = fabs(ix) > lo && fabs(ix) < hi && fabs(iy) > lo && fabs(iy) < hi && fabs(iz) > lo && fabs(iz) < hi;
-  if (__builtin_expect(__ballot(!ok) != 0ull, 0)) {
+  if (__builtin_expect(MGPU_ANY(!ok), 0)) {
     ix = 1.0 / dir.x;
     iy = 1.0 / dir.y;
     iz = 1.0 / dir.z;
@@ -183,7 +203,7 @@ __device__ __forceinline__ bool inverse_dir_w(V3 dir, double &ix, double &iy, do
 // executes it: rcp_core when every active lane's |det| is below 2^400, the plain operator for all lanes otherwise
 // (a NaN fails the comparison and lands there too, so that its payload is the division's).
 __device__ __forceinline__ double inv_det_w(double det) {
-  if (__builtin_expect(__ballot(!(fabs(det) < 0x1p+400)) != 0ull, 0)) return 1.0 / det;
+  if (__builtin_expect(MGPU_ANY(!(fabs(det) < 0x1p+400)), 0)) return 1.0 / det;
   return rcp_core(det);
 }
 
@@ -647,7 +667,7 @@ __device__ __forceinline__ int wide_node_step(const WNode *__restrict__ wn, cons
       a0 = make_double2(l0.x, l0.y); a1 = make_double2(l1.x, l1.y); a2 = make_double2(l2.x, l2.y);
       a3 = make_double2(l3.x, l3.y); a4 = make_double2(l4.x, l4.y); a5 = make_double2(l5.x, l5.y);
       m = make_uint4(lm.x, lm.y, lm.z, lm.w);
-      asm volatile("" : "+v"(m.x));
+      MGPU_KEEP1(m.x);
     } else {
       const WNode *r = wn + cur;
       const double2 *q = reinterpret_cast<const double2 *>(r);
@@ -655,7 +675,7 @@ __device__ __forceinline__ int wide_node_step(const WNode *__restrict__ wn, cons
       m = *reinterpret_cast<const uint4 *>(&r->ref0);
     }
     // all seven loads of the record are issued together (the compiler would sink the last behind the box tests)
-    asm volatile("" : "+v"(m.x), "+v"(m.y), "+v"(m.z), "+v"(m.w));
+    MGPU_KEEP4(m.x, m.y, m.z, m.w);
     n_nodes += 2;
     double t0, t1;
     const bool h0 = slab_t<kPlain>(a0, a1, a2, org, ix, iy, iz, sx, sy, sz, bt, t0);
@@ -803,7 +823,7 @@ __device__ __forceinline__ void traverse(const DScene &sc, const Stack<CAP, OVF>
   double ix, iy, iz;
   const bool inv_ok = inverse_dir_w(dir, ix, iy, iz); // 1.0 / dir, no zero guard, as the reference
   // wave-uniform: every active lane's ray may take the min/max form of the box test (slab_hit)
-  const bool all_plain = __ballot(!(sc.boxes_ordered && inv_ok && origin_is_finite(org))) == 0ull;
+  const bool all_plain = !MGPU_ANY(!(sc.boxes_ordered && inv_ok && origin_is_finite(org)));
   h.t = kDblMax;
   h.u = 0.0;
   h.v = 0.0;
@@ -829,7 +849,7 @@ __device__ __forceinline__ void traverse(const DScene &sc, const Stack<CAP, OVF>
       const double2 b2 = *reinterpret_cast<const double2 *>(&nd->bmax[1]); // bmax.y bmax.z
       int4 meta = *reinterpret_cast<const int4 *>(&nd->flag);              // flag axis data0 data1
       // issued with the three loads above (same 64-byte node), not sunk into the hit branch as a second dependent load
-      asm volatile("" : "+v"(meta.x), "+v"(meta.y), "+v"(meta.z), "+v"(meta.w));
+      MGPU_KEEP4(meta.x, meta.y, meta.z, meta.w);
       // IntersectRayAABB, bvh_accel.cc:550-593
       const bool hit = all_plain ? slab_hit<true>(b0, b1, b2, org, ix, iy, iz, sx, sy, sz, h.t)
                                  : slab_hit<false>(b0, b1, b2, org, ix, iy, iz, sx, sy, sz, h.t);
@@ -999,7 +1019,7 @@ __device__ __forceinline__ V3 sample_diffuse_t(V3 n, Rng &rng, const SincosTable
   // <= 1.5e-15 absolute difference).  See DESIGN.md "Numerics" for why this cannot move a pixel.
   cos_theta = x;
   const double s2 = fma(-x, x, 1.0); // >= 2^-53 or exactly 0 (u1 == 0)
-  if (__builtin_expect(__ballot(!(s2 > 0x1p-100)) != 0ull, 0)) sin_theta = sqrt(s2);
+  if (__builtin_expect(MGPU_ANY(!(s2 > 0x1p-100)), 0)) sin_theta = sqrt(s2);
   else sin_theta = sqrt_core(s2);
   if constexpr (TURN) sincos_turn(k2, *azimuth, sin_phi, cos_phi);
   else sincospi(2.0 * u2, &sin_phi, &cos_phi);

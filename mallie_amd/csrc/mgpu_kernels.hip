@@ -53,6 +53,11 @@ __global__ __launch_bounds__(kBlock) void k_trace(DScene sc, const MgpuRay *__re
     // <= CAP * 256 B) by their lanes and streamed out by all 64 lanes.
     uint32_t *stage = &s_stack[wave][0][0];
     const size_t cnt = (n - base < 64) ? (n - base) : 64;
+    // every lane's traversal has left the stacks before the first record is written over them (the lanes reconverge here anyway;
+    // said explicitly -- the wave barrier costs no instruction -- and needed by the tests' wave emulator, whose lanes do not run in lockstep)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int q = 0; q < 4; ++q) {
       if (live && (lane >> 4) == q) {
         MgpuIntersection *is = reinterpret_cast<MgpuIntersection *>(stage + (lane & 15) * kIsectWords);

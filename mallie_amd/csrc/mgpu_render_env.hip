@@ -49,7 +49,7 @@ constexpr int kEnvBlock = 256;
 
 template <int CAP, bool OVF, bool LDS_SCENE, int BLOCK>
 __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_arg) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  MGPU_DYN_SHARED(unsigned char, smem);
   __shared__ EnvParams s_P; // launch parameters live in LDS, not in scalar registers (see k_render_sm)
   __shared__ unsigned long long s_cnt[5];
   __shared__ unsigned char s_owner[BLOCK]; // TRI step with shared leaves: lane of the k-th open leaf, per wave
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
             }
             // keep the fourth load next to the other three (same 64-byte node): the compiler otherwise sinks it into the hit
             // branch as a second dependent trip -- to L1/L2 (BVH in HBM: C4 6.66 -> 6.20 ms) or to LDS (C2 6.56 -> 6.41 ms)
-            asm volatile("" : "+v"(meta.x), "+v"(meta.y), "+v"(meta.z), "+v"(meta.w));
+            MGPU_KEEP4(meta.x, meta.y, meta.z, meta.w);
             const bool hit = slab_hit<kPlain>(b0, b1, b2, org, ix, iy, iz, sx, sy, sz, bt); // IntersectRayAABB
             if (hit) {
               if (meta.x == 0) {

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_F32_HBM_WAVES(CAP)
   if (threadIdx.x == 0) s_P = P_arg;
   __syncthreads();
   const RenderParams &P = s_P;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  MGPU_DYN_SHARED(unsigned char, smem);
   constexpr int kWaves = BLOCK / 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t gid = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_F32_HBM_WAVES(CAP)
   const uint32_t shard_items = (total_items + (uint32_t)kShards - 1) / (uint32_t)kShards;
   uint32_t home_shard = 0;
   uint32_t item_tile = 0, item_pass = 0;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(home_shard));
+  MGPU_XCC_ID(home_shard);
   home_shard &= 7u;
   __shared__ unsigned char s_owner[BLOCK];
   __shared__ unsigned long long wg_cursor;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_F32_HBM_WAVES(CAP)
             q1 = nd[1];
           }
           // the node's last 8 bytes travel with its box (the compiler would fetch them again behind the test)
-          asm volatile("" : "+v"(q1.z), "+v"(q1.w));
+          MGPU_KEEP2(q1.z, q1.w);
           if (slab_f(q0, q1, org, inv, bt)) {
             const uint32_t a = __float_as_uint(q1.z), b = __float_as_uint(q1.w);
             const uint32_t tag = b >> 30, low = b & 0x3FFFFFFFu;

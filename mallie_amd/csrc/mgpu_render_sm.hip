@@ -151,7 +151,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
   if (MGPU_SINCOS_TURN) sincos_table_fill(s_azimuth, threadIdx.x, BLOCK);
   __syncthreads();
   const RenderParams &P = s_P;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  MGPU_DYN_SHARED(unsigned char, smem);
   constexpr int kWaves = BLOCK / 64;
   SE *s_stack = reinterpret_cast<SE *>(smem); // [kWaves][stack_cap][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
   const uint32_t shard_items = (total_items + (uint32_t)kShards - 1) / (uint32_t)kShards;
   uint32_t home_shard = 0;
   uint32_t item_tile = 0, item_pass = 0; // wave-uniform: tile and pass of the current item
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(home_shard)); // which XCD this workgroup runs on (0..7)
+  MGPU_XCC_ID(home_shard); // which XCD this workgroup runs on (0..7)
   home_shard &= 7u;
   // LDS cursor: hi32 = end, lo32 = next, both (shard << 28) | index of the item inside its shard's part
   __shared__ uint32_t s_occ[8]; // occupancy accounting of the workgroup: kOccNodeTrips.. in that order
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
             }
             // keep the fourth load next to the other three (same 64-byte node): the compiler otherwise sinks it into the hit
             // branch as a second dependent trip -- to L1/L2 (BVH in HBM: C4 6.66 -> 6.20 ms) or to LDS (C2 6.56 -> 6.41 ms)
-            asm volatile("" : "+v"(meta.x), "+v"(meta.y), "+v"(meta.z), "+v"(meta.w));
+            MGPU_KEEP4(meta.x, meta.y, meta.z, meta.w);
             const bool hit = slab_hit<kPlain>(b0, b1, b2, org, ix, iy, iz, sx, sy, sz, bt);
             if (hit) {
               if (meta.x == 0) {
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
                 const unsigned long long thr_bits = (unsigned long long)__double_as_longlong(thr0);
                 const bool unit_ok = MGPU_TAIL_TABLE && P.maxPathLength <= 16 && d0 == 0.5 && (thr_bits & 0x000FFFFFFFFFFFFFull) == 0ull &&
                                      thr0 >= 0x1p-900 && thr0 <= 1.0;
-                if (MGPU_TAIL_TABLE && __ballot(!unit_ok) == 0ull) {
+                if (MGPU_TAIL_TABLE && !MGPU_ANY(!unit_ok)) { // (both forms give the same bits: the table when every lane's operands qualify)
                   rad0 = thr0 * P.tail_unit[mul ? 1 : 0][pathLength];
                 } else if (MGPU_TAIL_RECIP && P.maxPathLength <= 16) { // x / L through the rounded reciprocal (mgpu_kernels.hpp, inv_len)
                   for (int L = pathLength;; ++L) {
@@ -1089,7 +1089,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
         const size_t wid = (size_t)blockIdx.x * kWaves + wave;
         if (wid < 16384) {
           unsigned xcc;
-          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+          MGPU_XCC_ID(xcc);
           P.wave_log[4 * wid + 0] = wall_loop0;
           P.wave_log[4 * wid + 1] = wall_clock64();
           P.wave_log[4 * wid + 2] = cyc_dry;

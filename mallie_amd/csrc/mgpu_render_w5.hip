@@ -71,7 +71,7 @@ __global__ __launch_bounds__(BLOCK, MGPU_W5_WAVES) void k_render_w5(DScene sc, R
   sincos_table_fill(s_azimuth, threadIdx.x, BLOCK);
   __syncthreads();
   const RenderParams &P = s_P;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  MGPU_DYN_SHARED(unsigned char, smem);
   constexpr int kWaves = BLOCK / 64;
   typedef __attribute__((address_space(3))) uint32_t lds_u32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(BLOCK, MGPU_W5_WAVES) void k_render_w5(DScene sc, R
   const uint32_t shard_items = (total_items + (uint32_t)kShards - 1) / (uint32_t)kShards;
   uint32_t home_shard = 0;
   uint32_t item_tile = 0, item_pass = 0;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(home_shard));
+  MGPU_XCC_ID(home_shard);
   home_shard &= 7u;
   __shared__ unsigned char s_owner[BLOCK];
   __shared__ unsigned long long wg_cursor;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(BLOCK, MGPU_W5_WAVES) void k_render_w5(DScene sc, R
               if (mul && (size_t)(int)last_mat < (size_t)sc.nm) d0 = sc.mat_diffuse[3 * (size_t)last_mat + 0];
               const unsigned long long thr_bits = (unsigned long long)__double_as_longlong(thr0);
               const bool unit_ok = P.maxPathLength <= 16 && d0 == 0.5 && (thr_bits & 0x000FFFFFFFFFFFFFull) == 0ull && thr0 >= 0x1p-900 && thr0 <= 1.0;
-              if (__ballot(!unit_ok) == 0ull) {
+              if (!MGPU_ANY(!unit_ok)) { // (both forms give the same bits: the table when every lane's operands qualify)
                 rad0 = thr0 * P.tail_unit[mul ? 1 : 0][pathLength];
               } else if (P.maxPathLength <= 16) { // x / L through the rounded reciprocal (mgpu_kernels.hpp, inv_len)
                 for (int L = pathLength;; ++L) {

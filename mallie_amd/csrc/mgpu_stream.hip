@@ -386,7 +386,7 @@ struct RoundParams {
 
 // ---- bases ----------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kSBlock) void k_stream_bases(StreamParams P, RoundParams R) {
-  extern __shared__ uint4 jm[];
+  MGPU_DYN_SHARED(uint4, jm);
   load_jump(jm, P.jump, R.levels);
   const uint4 s0 = *reinterpret_cast<const uint4 *>(P.state);
   for (uint32_t j = blockIdx.x * kSBlock + threadIdx.x; j < R.m; j += gridDim.x * kSBlock) {
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(kSBlock) void k_stream_bases(StreamParams P, RoundP
 // ---- one round: walk the previous round's table, then trace this round's candidates ---------------------------------------------
 template <int CAP>
 __global__ __launch_bounds__(kSBlock) void k_stream_round(DScene sc, StreamParams P, RoundParams R, uint32_t r) {
-  extern __shared__ uint4 jm[];
+  MGPU_DYN_SHARED(uint4, jm);
   __shared__ StreamLds<CAP> lds;
   __shared__ unsigned char s_F[kRoundCand];
   __shared__ uint32_t s_before[kRoundL + 1]; // hits before the round's i-th pixel, relative to the round's start
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(kSBlock) void k_stream_round(DScene sc, StreamParam
 template <int CAP>
 __global__ __launch_bounds__(kSBlock) void k_stream_finish(DScene sc, StreamParams P, RoundParams R, unsigned char *__restrict__ cls, const uint32_t *__restrict__ J,
                                                           uint32_t pass, uint32_t *__restrict__ bad /* [0] certain pixels that disagree, [1] uncertain ones */) {
-  extern __shared__ uint4 jm[];
+  MGPU_DYN_SHARED(uint4, jm);
   __shared__ StreamLds<CAP> lds;
   load_jump(jm, P.jump, R.levels);
   const Stack<CAP, true> stk = bind_stack(lds, sc);
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(kSBlock) void k_stream_finish(DScene sc, StreamPara
 
 // ---- the stream state behind a pass ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_stream_advance(StreamParams P, RoundParams R, const uint32_t *__restrict__ totals) {
-  extern __shared__ uint4 jm[];
+  MGPU_DYN_SHARED(uint4, jm);
   for (int i = threadIdx.x; i < R.levels * 128; i += 64) jm[i] = P.jump[i];
   __syncthreads();
   if (threadIdx.x == 0) {

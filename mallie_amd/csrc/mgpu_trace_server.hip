@@ -61,7 +61,7 @@ __device__ __forceinline__ void traverse_coop(const DScene &sc, const Stack<CAP,
       const double2 b1 = *reinterpret_cast<const double2 *>(&nd->bmin[2]);
       const double2 b2 = *reinterpret_cast<const double2 *>(&nd->bmax[1]);
       int4 meta = *reinterpret_cast<const int4 *>(&nd->flag);
-      asm volatile("" : "+v"(meta.x), "+v"(meta.y), "+v"(meta.z), "+v"(meta.w));
+      MGPU_KEEP4(meta.x, meta.y, meta.z, meta.w);
       const bool hit = all_plain ? slab_hit<true>(b0, b1, b2, org, ix, iy, iz, sx, sy, sz, h.t)
                                  : slab_hit<false>(b0, b1, b2, org, ix, iy, iz, sx, sy, sz, h.t);
       if (hit) {
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64) void k_trace_server(DScene sc, TraceMailbox *mb
                                                      unsigned long long max_polls, uint32_t stage_nodes_bytes,
                                                      uint32_t stage_tris_bytes) {
   __shared__ __attribute__((aligned(16))) uint32_t s_stack[CAP][64];
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_scene[]; // nodes, then triangles, when the scene is small enough
+  MGPU_DYN_SHARED(unsigned char, s_scene); // nodes, then triangles, when the scene is small enough
   const int lane = threadIdx.x;
   const int wave = blockIdx.x;
   const bool owner = lane < kSrvSlotsPerWave;

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
                                                             unsigned long long *__restrict__ stats,
                                                             const uint32_t *__restrict__ select) {
   if (select && *select != kTraceSelectSm) return; // k_trace_probe chose the other kernel for this batch
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  MGPU_DYN_SHARED(unsigned char, smem);
   __shared__ unsigned long long s_cnt[3];
   __shared__ unsigned char s_owner[kTraceBlock]; // TRI step with shared leaves: lane of the k-th open leaf, per wave
   using WS = WStack<kWideStackLds>;

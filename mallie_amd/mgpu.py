@@ -61,6 +61,11 @@ def load_library():
             import torch  # noqa: F401
         except ImportError:
             pass
+    # tests/emu builds the library's sources for the HOST against a wave64 emulator (a CPU / GPU differential for the tests).  It is
+    # test infrastructure, never a fallback: the product refuses to load it unless the caller says it is a test.
+    if "_emu" in os.path.basename(_LIB_PATH) and os.environ.get("MALLIE_ALLOW_EMULATOR", "0") != "1":
+        raise ImportError("%s is the tests' wave emulator build, not the product library; mallie_amd has no CPU path "
+                          "(tests set MALLIE_ALLOW_EMULATOR=1)" % _LIB_PATH)
     if not os.path.exists(_LIB_PATH):
         raise ImportError("%s is missing: build it with `python -m mallie_amd.build` (needs hipcc). mallie_amd has no "
                           "CPU fallback." % _LIB_PATH)

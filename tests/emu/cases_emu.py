@@ -1,0 +1,124 @@
+"""TEST INFRASTRUCTURE: cases that run the library's kernels on the wave64 emulator (tests/emu) against the oracle.  Run by
+tests/test_emu_cpu.py in a child interpreter with MALLIE_MGPU_LIB = tests/emu/libmallie_mgpu_emu.so, MALLIE_ALLOW_EMULATOR=1.
+The whole `-m gpu` suite can be pointed at the emulator the same way (profiles/r5_emulator_suite.txt says which tests pass there)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import mallie_amd as M  # noqa: E402
+import oracle_lib as O  # noqa: E402
+from mallie_amd.scenes import suzanne_grid  # noqa: E402
+
+FIELDS = ("real_rays", "nodes", "tris", "trace_calls")
+
+
+def test_this_is_the_emulator():
+    assert M.lib_path().endswith("libmallie_mgpu_emu.so") and M.device_count() >= 1
+
+
+def _golden_scene(name):
+    g = O.load_golden(name)
+    return M.Scene(g["verts"], g["faces"], g["matIDs"], g["normals"] if g["has_normals"] else None, O.golden_uvs(g), g["nodes"], g["indices"])
+
+
+@pytest.mark.parametrize("kernel", ["sm_lds", "sm", "v1"])
+def test_render_kernels_vs_oracle(kernel, monkeypatch):
+    """k_render_sm with the scene in LDS (leaf hints, staged primary rays), the same walk through the wide records in HBM, and the
+    first ray-synchronous kernel: frames byte-equal to the oracle's, counters equal (primary rays only: exact)."""
+    monkeypatch.setenv("MGPU_RENDER_KERNEL", kernel)
+    sc, osc = _golden_scene("cornell_obj"), O.scene_from_golden("cornell_obj")
+    W, H = 72, 48
+    frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    for (mpl, passes, win) in [(5, 3, None), (1, 2, None), (4, 1, (5, 3, 61, 40))]:
+        img, cnt, st = sc.render(frame, W, H, mpl, passes, osc.plane(), M.RNG_HASH, seed=42, pass_base=3, window=win)
+        oimg, ocnt, ost, _ = osc.render(frame, W, H, mpl, passes, osc.plane(), O.RNG_HASH, seed=42, pass_base=3, window=win)
+        assert img.tobytes() == oimg.tobytes() and np.array_equal(cnt, ocnt), (kernel, mpl, passes, win)
+        if mpl == 1:
+            assert all(st[f] == ost[f] for f in FIELDS), (st, ost)
+        else:
+            assert st["real_rays"] == ost["real_rays"] and st["trace_calls"] == ost["trace_calls"]
+            assert abs(st["nodes"] - ost["nodes"]) <= 2e-3 * ost["nodes"] and abs(st["tris"] - ost["tris"]) <= 2e-3 * ost["tris"]
+
+
+@pytest.mark.parametrize("block", ["640", "320"])
+def test_hand_partitioned_five_wave_kernel(block, monkeypatch):
+    """k_render_w5 (mgpu_render_w5.hip): frames and counters word for word those of k_render_sm's HBM-resident walk, and the
+    oracle's frame."""
+    c = O.load_golden("cornell_obj")
+    verts, faces, mats, normals = suzanne_grid(c["verts"], c["faces"], 3)
+    W, H = 120, 72
+    frame = M.camera_frame((0.0, 40.0, 80.0), (0.0, 0.0, 0.0), width=W, height=H)
+    ref = M.Scene(verts, faces, mats, normals, None)
+    monkeypatch.setenv("MGPU_W5", "1")
+    monkeypatch.setenv("MGPU_W5_BLOCK", block)
+    sc = M.Scene(verts, faces, mats, normals, None)
+    plane = ref.plane()
+    for (mpl, passes, win) in [(5, 3, None), (9, 1, None), (3, 2, (3, 5, 111, 67))]:
+        monkeypatch.setenv("MGPU_W5", "1")
+        img, cnt, st = sc.render(frame, W, H, mpl, passes, plane, M.RNG_HASH, seed=11, pass_base=2, window=win)
+        monkeypatch.setenv("MGPU_W5", "0")
+        rimg, rcnt, rst = ref.render(frame, W, H, mpl, passes, plane, M.RNG_HASH, seed=11, pass_base=2, window=win)
+        assert img.tobytes() == rimg.tobytes() and np.array_equal(cnt, rcnt), (mpl, passes, win)
+        assert all(st[f] == rst[f] for f in FIELDS + ("paths",)), (st, rst)
+    osc = O.OracleScene(verts, faces, mats, normals, None)
+    monkeypatch.setenv("MGPU_W5", "1")
+    img, _, _ = sc.render(frame, W, H, 4, 2, plane, M.RNG_HASH, seed=5)
+    oimg = osc.render(frame, W, H, 4, 2, osc.plane(), O.RNG_HASH, seed=5)[0]
+    assert img.tobytes() == oimg.tobytes()
+
+
+def test_reference_stream_resolution_with_the_analytic_horizon(monkeypatch):
+    """MGPU_RNG_STREAM through the chip-wide resolution (classification incl. the plane's horizon band, rounds, verification)
+    against the one-workgroup walk: tables, stream state and frames word for word; the oracle's frame in the reference's stream."""
+    sc, osc = _golden_scene("cornell_obj"), O.scene_from_golden("cornell_obj")
+    W, H, mpl = 96, 64, 5
+    frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    plane = sc.plane()
+    monkeypatch.setenv("MGPU_STREAM_SERIAL", "1")
+    img0, _, st0, state0, states0 = sc.render_stream(frame, W, H, mpl, 2, plane, want_states=True)
+    monkeypatch.delenv("MGPU_STREAM_SERIAL")
+    img1, _, st1, state1, states1 = sc.render_stream(frame, W, H, mpl, 2, plane, want_states=True)
+    assert np.array_equal(states1, states0) and np.array_equal(state1, state0) and img1.tobytes() == img0.tobytes()
+    ss = sc.stream_stats()
+    assert ss["uncertain_pixels"] >= W  # the horizon row is uncertain from the first call
+    oimg = osc.render(frame, W, H, mpl, 2, osc.plane(), O.RNG_STREAM, stream_state=np.array(O.REFERENCE_SEED, "<u4"))[0]
+    assert img1.tobytes() == oimg.tobytes()
+
+
+@pytest.mark.parametrize("threads", ["0", "1"])
+def test_several_ranks_in_one_process(threads, monkeypatch):
+    """mgpu_frame_* with four ranks sharing the (emulated) device through the copy transport, the launch phase enqueued by the
+    caller's thread or by one thread per member (EnqueuePool): every assembled frame equals the single-launch frame."""
+    monkeypatch.setenv("MGPU_FRAME_TRANSPORT", "copy")
+    monkeypatch.setenv("MGPU_FRAME_ENQUEUE_THREADS", threads)
+    world = 4
+    scenes = [_golden_scene("cornell_obj") for _ in range(world)]
+    W, H, mpl, passes = 80, 53, 4, 2
+    cam = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    plane = scenes[0].plane()
+    fr = M.Frame(scenes, [0] * world, W, H, strip_h=8, frames_in_flight=3)
+    slots = [fr.render(cam, mpl, passes, plane, seed=9, pass_base=k * passes) for k in range(2)]
+    frames = [fr.wait(s, to_host=True) for s in slots]
+    slots = fr.render_batch(cam, mpl, passes, 3, plane, seed=9, pass_base=2 * passes)
+    frames += [fr.wait(s, to_host=True) for s in slots]
+    for k, img in enumerate(frames):
+        ref = scenes[0].render(cam, W, H, mpl, passes, plane, M.RNG_HASH, seed=9, pass_base=k * passes)[0]
+        assert img.tobytes() == ref.tobytes(), (threads, k)
+    fr.close()
+
+
+@pytest.mark.parametrize("kernel", ["v1", "sm"])
+def test_batched_trace_vs_reference_records(kernel, monkeypatch):
+    monkeypatch.setenv("MGPU_TRACE_KERNEL", kernel)
+    sc = _golden_scene("cornell_obj")
+    t = O.load_golden("trace_cornell_obj")
+    out, hit = sc.trace(t["rays"][:600])
+    assert np.array_equal(hit, t["hits"]["hit"][:600].astype("u1"))
+    for name in ("t", "u", "v", "faceID"):
+        m = hit.astype(bool)
+        assert np.array_equal(out[name][m], t["hits"][name][:600][m]), name
