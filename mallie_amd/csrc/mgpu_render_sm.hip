@@ -38,6 +38,12 @@
 #include <climits>
 #include <mutex>
 
+#ifdef MGPU_EMU_STATS
+extern "C" unsigned long long emu_stats[64];
+extern "C" unsigned char *emu_log;
+extern "C" unsigned long long emu_log_n, emu_log_cap;
+#endif
+
 namespace mgpu {
 
 enum : int { ST_NODE = 0, ST_TRI = 1, ST_SHADE = 2, ST_IDLE = 3 };
@@ -487,6 +493,41 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
       }
       const bool occ_sample = occ_sampled();
       const uint32_t occ_t0 = MGPU_OCC ? tri_cur : 0u;
+#ifdef MGPU_EMU_STATS // (emulator builds only: the shape of the TRI steps -- open leaves, tests due, the longest run -- for costing hand-out schemes)
+      if (cT != 0) {
+        const uint32_t len = st == ST_TRI ? tri_end - tri_cur : 0u;
+        uint32_t mx = len, sum = len;
+        for (int x = 1; x < 64; x <<= 1) {
+          mx = max(mx, (uint32_t)__shfl_xor((int)mx, x));
+          sum += (uint32_t)__shfl_xor((int)sum, x);
+        }
+        if (lane == 0) {
+          const uint32_t m = cT <= 16 ? 4u : (cT <= 32 ? 2u : 1u), cap = (uint32_t)MGPU_TRIS_PER_STEP;
+          const uint32_t trips_now = min(cap, (mx + m - 1u) / m);
+          // tests this step performs: every run advances by up to cap * m
+          emu_stats[0] += 1;                       // TRI steps
+          emu_stats[1] += (unsigned long long)cT;  // open leaves
+          emu_stats[2] += sum;                     // tests due in the open leaves
+          emu_stats[3] += trips_now;               // trips of the step as built
+          emu_stats[4] += (sum + 63u) / 64u;       // trips if the (leaf, triangle) pairs were dealt to the lanes one by one, whole runs
+          emu_stats[5] += mx;
+          emu_stats[8 + min((uint32_t)cT, 64u) / 4u] += 1; // steps by open leaves / 4
+        }
+        if (emu_log && emu_log_n + 66 < emu_log_cap) { // per-step record: cT, then every open leaf's run length (lane order), 0-terminated
+          const unsigned long long base = emu_log_n;
+          if (lane == 0) emu_log[base] = (unsigned char)cT;
+          if (st == ST_TRI) emu_log[base + 1 + __popcll(mT & ((1ull << lane) - 1ull))] = (unsigned char)min(len, 255u);
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0) {
+            emu_log[base + 1 + cT] = 0;
+            emu_log_n = base + 2 + cT;
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        // tests done by the step as built
+        if (st == ST_TRI) atomicAdd(&emu_stats[6], (unsigned long long)min(len, (cT <= 32 ? (uint32_t)(MGPU_TRIS_PER_STEP) * (cT <= 16 ? 4u : 2u) : (uint32_t)MGPU_TRIS_PER_STEP)));
+      }
+#endif
 #if MGPU_SHARED_LEAVES
       if (cT != 0 && cT <= 32) { // mgpu_device.hpp, shared_leaves_step: 2, 4 (or 8) lanes per open leaf
         uint32_t my_trips = 0;

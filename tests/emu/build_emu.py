@@ -37,12 +37,45 @@ def build(force=False, extra=()):
         return obj
     with cf.ThreadPoolExecutor(6) as ex:
         objs = list(ex.map(one, srcs))
-    r = subprocess.run([CXX, "-shared", "-pthread", "-o", OUT] + objs + ["-ldl"], capture_output=True, text=True)
+    r = subprocess.run([CXX, "-shared", "-pthread", "-o", OUT] + [e for e in extra if e.startswith("-fsanitize") or e in ("-shared-libasan", "-shared-libsan")] + objs + ["-ldl"], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("emulator link failed:\n" + r.stderr[-4000:])
     return OUT
 
 
+def build_asan():
+    """The same library under AddressSanitizer + UndefinedBehaviorSanitizer (device code included: every kernel's loads and stores are
+    checked against the hipMalloc'ed blocks they belong to -- what compute-sanitizer's memcheck would do).  -> (library, runtime to preload)"""
+    global OUT, OBJ
+    keep = OUT, OBJ
+    OUT, OBJ = os.path.join(HERE, "libmallie_mgpu_emu_asan.so"), os.path.join(HERE, "_obj_asan")
+    try:
+        lib = build(True, ["-fsanitize=address,undefined", "-fno-sanitize=alignment,vptr,function", "-fno-sanitize-recover=undefined", "-shared-libasan", "-fno-omit-frame-pointer"])
+    finally:
+        OUT, OBJ = keep
+    rt = subprocess.run([CXX, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    return lib, rt
+
+
+def build_tsan():
+    """... and under ThreadSanitizer: the host side's threads (enqueue pool, submission queue, render-ahead) with the kernels running
+    underneath as fibers.  -> (library, runtime to preload)"""
+    global OUT, OBJ
+    keep = OUT, OBJ
+    OUT, OBJ = os.path.join(HERE, "libmallie_mgpu_emu_tsan.so"), os.path.join(HERE, "_obj_tsan")
+    try:
+        lib = build(True, ["-fsanitize=thread", "-shared-libsan", "-fno-omit-frame-pointer"])
+    finally:
+        OUT, OBJ = keep
+    rt = subprocess.run([CXX, "-print-file-name=libclang_rt.tsan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    return lib, rt
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
-    print(build("--force" in args, [a for a in args if a != "--force"]))
+    if args[:1] == ["tsan"]:
+        print(*build_tsan())
+    elif args[:1] == ["asan"]:
+        print(*build_asan())
+    else:
+        print(build("--force" in args, [a for a in args if a != "--force"]))

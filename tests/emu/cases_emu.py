@@ -18,7 +18,7 @@ FIELDS = ("real_rays", "nodes", "tris", "trace_calls")
 
 
 def test_this_is_the_emulator():
-    assert M.lib_path().endswith("libmallie_mgpu_emu.so") and M.device_count() >= 1
+    assert "libmallie_mgpu_emu" in os.path.basename(M.lib_path()) and M.device_count() >= 1
 
 
 def _golden_scene(name):

@@ -15,6 +15,32 @@
 #include <mutex>
 #include <vector>
 
+// AddressSanitizer has to be told about stack switches it did not make (python tests/emu/build_emu.py asan)
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define EMU_ASAN 1
+#include <sanitizer/common_interface_defs.h>
+#endif
+#endif
+#ifndef EMU_ASAN
+#define EMU_ASAN 0
+#endif
+// ... and ThreadSanitizer likewise (python tests/emu/build_emu.py tsan): every lane is a fiber of its own to it
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+#define EMU_TSAN 1
+extern "C" {
+void *__tsan_get_current_fiber(void);
+void *__tsan_create_fiber(unsigned flags);
+void __tsan_destroy_fiber(void *fiber);
+void __tsan_switch_to_fiber(void *fiber, unsigned flags);
+}
+#endif
+#endif
+#ifndef EMU_TSAN
+#define EMU_TSAN 0
+#endif
+
 namespace emu {
 
 thread_local Ctx *g_cur = nullptr;
@@ -34,6 +60,8 @@ struct FiberImpl {
   int op = 0, site = 0;
   unsigned long long arg = 0, result = 0;
   int src = 0;
+  void *fake = nullptr; // AddressSanitizer's fake-stack handle of this fiber while it is switched out
+  void *tsan = nullptr; // ThreadSanitizer's fiber
 };
 
 struct Sched {
@@ -42,6 +70,10 @@ struct Sched {
   FiberImpl *running = nullptr;
   const std::function<void()> *entry = nullptr;
   unsigned char *lds = nullptr;
+  void *main_fake = nullptr;          // AddressSanitizer: the scheduler's own handle, and its stack as the fibers see it
+  const void *main_bottom = nullptr;
+  size_t main_size = 0;
+  void *main_tsan = nullptr;
 };
 thread_local Sched *g_sched = nullptr;
 
@@ -73,12 +105,24 @@ emu_switch:
 void yield_to_scheduler() {
   Sched *s = g_sched;
   FiberImpl *f = s->running;
+#if EMU_ASAN
+  __sanitizer_start_switch_fiber(f->state == DONE ? nullptr : &f->fake, s->main_bottom, s->main_size);
+#endif
+#if EMU_TSAN
+  __tsan_switch_to_fiber(s->main_tsan, 0);
+#endif
   emu_switch(&f->sp, s->main_sp);
+#if EMU_ASAN
+  __sanitizer_finish_switch_fiber(f->fake, &g_sched->main_bottom, &g_sched->main_size);
+#endif
 }
 
 extern "C" void emu_fiber_main() {
   Sched *s = g_sched;
   FiberImpl *f = s->running;
+#if EMU_ASAN
+  __sanitizer_finish_switch_fiber(nullptr, &s->main_bottom, &s->main_size);
+#endif
   (*s->entry)();
   f->state = DONE;
   yield_to_scheduler();
@@ -122,7 +166,16 @@ void prepare(FiberImpl &f) {
 void run_fiber(Sched &S, FiberImpl &f) {
   S.running = &f;
   g_cur = &f.ctx;
+#if EMU_ASAN
+  __sanitizer_start_switch_fiber(&S.main_fake, f.stack, kStackBytes);
+#endif
+#if EMU_TSAN
+  __tsan_switch_to_fiber(f.tsan, 0);
+#endif
   emu_switch(&S.main_sp, f.sp);
+#if EMU_ASAN
+  __sanitizer_finish_switch_fiber(S.main_fake, nullptr, nullptr);
+#endif
   S.running = nullptr;
 }
 
@@ -292,6 +345,10 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &la
       }
     }
   }
+#if EMU_TSAN
+  S.main_tsan = __tsan_get_current_fiber();
+  for (FiberImpl &f : S.fibers) f.tsan = __tsan_create_fiber(0);
+#endif
   Sched *outer = g_sched;
   Ctx *outer_cur = g_cur;
   g_sched = &S;
@@ -315,9 +372,14 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &la
   g_sched = outer;
   g_cur = outer_cur;
   for (FiberImpl &f : S.fibers) g_stack_pool.push_back(f.stack);
+#if EMU_TSAN
+  for (FiberImpl &f : S.fibers) __tsan_destroy_fiber(f.tsan);
+#endif
 }
 
 } // namespace emu
+
+extern "C" { unsigned long long emu_stats[64]; unsigned char *emu_log = nullptr; unsigned long long emu_log_n = 0, emu_log_cap = 0; } // scratch counters of -DMGPU_EMU_STATS builds (read by the tests through ctypes)
 
 // ---- runtime API ---------------------------------------------------------------------------------------------------------------------
 struct emuStream { int dummy; };
