@@ -272,6 +272,7 @@ __global__ __launch_bounds__(kSBlock) void k_stream_classify(DScene sc, StreamPa
     // refused -- the pixel is uncertain from the first call on, whatever the sixteen probes below would have said (they found
     // the 0.08-pixel band of the reference's default view one failed verification at a time).  Marking more pixels uncertain is
     // always safe: an uncertain pixel's flag is traced, not assumed.
+#ifndef MGPU_STREAM_NO_HORIZON // (A/B switch: the round-4 classification, probes only)
     if (P.has_plane) {
       const V3 n = v3((double)P.plane[0], (double)P.plane[1], (double)P.plane[2]);
       float lo = __builtin_inff(), hi = -__builtin_inff();
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(kSBlock) void k_stream_classify(DScene sc, StreamPa
         continue;
       }
     }
+#endif
     for (int k = 0; k < 5; ++k) hits += primary_hits<CAP>(sc, stk, P, gx, gy, a[k], b[k], c) ? 1 : 0;
     // ... and kClassifyRandom jitters of the pixel's own: features thinner than a pixel that touch neither a corner nor the centre --
     // seen at once on the reference's default view: the eye sits at the height of the Cornell box's floor, and between the walls'
