@@ -86,6 +86,17 @@ def pmc_for(workload, lib_path):
     return w, "profiles/pmc_current.json (rocprofv3 --pmc, separate passes), %s" % stamp
 
 
+def pmc_stale(workload):
+    """The committed PMC numbers of `workload` WHATEVER library they were collected on, with their tag -- for the bench line of a library
+    no PMC pass has seen yet (reported beside a null `frac`, never as it)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_current.json")) as f:
+            d = json.load(f)
+        return d.get("workloads", {}).get(workload), d.get("tag")
+    except (OSError, ValueError):
+        return None, None
+
+
 def hbm_bytes(p):
     """HBM bytes per frame: 2 x FETCH_SIZE (gfx950 correction of the guide) + WRITE_SIZE, both reported in KiB.  The committed
     calibration passes (profiles/pmc_current.json "calibration": known byte counts in this library's access patterns) confirm
@@ -669,6 +680,15 @@ def main():
                                 "wave_insts_per_ray": round(p["SQ_INSTS_VALU"] / max(st["real_rays"] / n_launch, 1), 2),
                                 "issue_busy": round(p["SQ_ACTIVE_INST_VALU"] * 4.0 / (ksec * CLOCK_HZ * N_SIMD), 3),
                                 "salu_insts_per_frame": int(p["SQ_INSTS_SALU"]) if "SQ_INSTS_SALU" in p else None}
+            if p is None and world == 1 and ksec > 0:
+                # no PMC pass exists for the library loaded now: `achieved` / `frac` stay null.  What the last stamped library's
+                # instruction count would give over THIS run's kernel time is reported under its own name (the count moves by a few %
+                # with the kernel's code; the figure is an indication, not a measurement of this library)
+                sp, stag = pmc_stale("c2")
+                if sp and "SQ_INSTS_VALU" in sp:
+                    roof["unstamped_estimate"] = {"pmc_of": "profiles/pmc_current.json, tag %s: ANOTHER build of the library" % stag,
+                                                  "SQ_INSTS_VALU_of_that_build": sp["SQ_INSTS_VALU"],
+                                                  "frac_if_the_count_were_unchanged": round(sp["SQ_INSTS_VALU"] / ksec / 1e9 / VALU_PEAK_GINST, 4)}
             if traffic and ksec > 0:
                 roof["hbm"] = {"measured_GBps": round(traffic / ksec / 1e9, 1), "frac_of_peak": round(traffic / ksec / 1e9 / HBM_PEAK_GBS, 4),
                                "fetch_bytes": int(2 * p["FETCH_SIZE"] * 1024), "write_bytes": int(p["WRITE_SIZE"] * 1024),
