@@ -20,6 +20,7 @@
 #if __has_feature(address_sanitizer)
 #define EMU_ASAN 1
 #include <sanitizer/common_interface_defs.h>
+#include <sanitizer/asan_interface.h>
 #endif
 #endif
 #ifndef EMU_ASAN
@@ -356,6 +357,12 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &la
     for (unsigned by = 0; by < grid.y; ++by)
       for (unsigned bx = 0; bx < grid.x; ++bx) {
         memset(lds, 0xCD, shmem); // LDS comes up with whatever the last workgroup left: make reliance on that visible
+        // dynamic LDS beyond what the launch asked for does not exist: a canary behind it (and, under AddressSanitizer, poison)
+        const size_t guard = std::min<size_t>(kLdsBytes - shmem, 4096);
+        memset(lds + shmem, 0x5A, guard);
+#if EMU_ASAN
+        __asan_poison_memory_region(lds + shmem, kLdsBytes - shmem);
+#endif
         for (size_t t = 0; t < nthreads; ++t) {
           FiberImpl &f = S.fibers[t];
           f.ctx.thread_idx = Idx{(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y), (unsigned)(t / ((size_t)block.x * block.y))};
@@ -368,6 +375,14 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &la
           prepare(f);
         }
         run_block(S);
+#if EMU_ASAN
+        __asan_unpoison_memory_region(lds + shmem, kLdsBytes - shmem);
+#endif
+        for (size_t i = 0; i < guard; ++i)
+          if (lds[shmem + i] != 0x5A) {
+            fprintf(stderr, "emu: a kernel wrote dynamic LDS byte %zu of a launch that asked for %zu bytes (block %zu threads)\n", shmem + i, shmem, nthreads);
+            abort();
+          }
       }
   g_sched = outer;
   g_cur = outer_cur;
