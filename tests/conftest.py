@@ -38,3 +38,48 @@ def pytest_terminal_summary(terminalreporter):
             "strict: anything but byte-equal fails" if strict_parity() else "MALLIE_STRICT_PARITY=0",
             PARITY["byte_equal"], PARITY["within_tolerance"],
             "".join("\n  " + n for n in PARITY["notes"])))
+
+
+# ---- the parity suite on the tests' wave emulator (tests/emu; MALLIE_MGPU_LIB = .../libmallie_mgpu_emu*.so, MALLIE_ALLOW_EMULATOR=1) ----
+# There "device memory" is host memory and a launch has run when the call returns: torch's CPU tensors serve as the device buffers the
+# tests hand to the C ABI.  The substitutions below exist in that mode only; on a GPU box nothing here runs.
+def _on_emulator():
+    return "_emu" in os.path.basename(os.environ.get("MALLIE_MGPU_LIB", "")) and os.environ.get("MALLIE_ALLOW_EMULATOR") == "1"
+
+
+@pytest.fixture(autouse=True)
+def _emulator_device_buffers(monkeypatch):
+    if not _on_emulator():
+        yield
+        return
+    import torch
+
+    def host(fn):
+        def wrapped(*a, **k):
+            if "device" in k and k["device"] is not None and str(k["device"]).startswith("cuda"):
+                k["device"] = "cpu"
+            return fn(*a, **k)
+        return wrapped
+    for name in ("empty", "full", "zeros", "ones", "tensor", "empty_like", "zeros_like", "full_like"):
+        monkeypatch.setattr(torch, name, host(getattr(torch, name)))
+
+    class _Stream:
+        cuda_stream = 0
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def synchronize(self):
+            pass
+
+        def wait_stream(self, other):
+            pass
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _Stream())
+    monkeypatch.setattr(torch.cuda, "Stream", lambda *a, **k: _Stream())
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: s)
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    yield

@@ -7,6 +7,7 @@ tag=${1:-r5final}; out=gpurun_out/$tag; mkdir -p $out
 echo "== 1. GPU suite"; timeout 900 python -m pytest tests -m gpu -q > $out/tests.txt 2>&1; echo "rc=$?"; grep -E "passed|failed|parity" $out/tests.txt | tail -3
 echo "== 2. k_render_w5 beside k_render_sm"; timeout 900 bash tools/w5_ab.sh c4 c3 c5 > $out/w5_ab.txt 2>&1; cat $out/w5_ab.txt | cut -c1-220
 MGPU_W5_BLOCK=320 timeout 600 bash tools/w5_ab.sh c4 c3 > $out/w5_ab_320.txt 2>&1; grep "MGPU_W5=1" $out/w5_ab_320.txt | cut -c1-220
+for lib in mallie_amd/ab/w5_*.so; do for c in c4 c3; do echo "$(basename $lib .so) $c: $(MGPU_W5=1 MALLIE_MGPU_LIB=$lib timeout 300 python tools/perf_cfg.py $c 6 2>&1 | tail -1 | grep -o "median of the last [0-9]*: [0-9.]*")"; done; done > $out/w5_variants.txt 2>&1; cat $out/w5_variants.txt
 echo "== 3. eight ranks in one process: enqueue cost with and without a thread per member"
 for th in 0 1; do MGPU_FRAME_ENQUEUE_THREADS=$th timeout 600 bash tools/perf_multi_one_gpu.sh $tag/multi_th$th > $out/multi_threads_$th.txt 2>&1; grep "ranks 8" $out/multi_threads_$th.txt | cut -c1-260; done
 echo "== 4. the reference's stream: does it settle"; timeout 300 python tools/perf_stream.py > $out/stream.txt 2>&1; tail -6 $out/stream.txt | cut -c1-220
