@@ -186,6 +186,16 @@ struct EnqueuePool {
   explicit EnqueuePool(size_t n) {
     for (size_t i = 0; i < n; ++i) {
       Worker *w = new Worker();
+      workers.push_back(w);
+      try {
+        start(w, i);
+      } catch (...) {
+        stop_all();
+        throw;
+      }
+    }
+  }
+  void start(Worker *w, size_t i) {
       w->th = std::thread([w, i] {
         std::unique_lock<std::mutex> lk(w->mu);
         for (;;) {
@@ -202,20 +212,20 @@ struct EnqueuePool {
           w->cv.notify_all();
         }
       });
-      workers.push_back(w);
-    }
   }
-  ~EnqueuePool() {
+  void stop_all() {
     for (Worker *w : workers) {
       {
         std::lock_guard<std::mutex> lk(w->mu);
         w->quit = true;
       }
       w->cv.notify_all();
-      w->th.join();
+      if (w->th.joinable()) w->th.join();
       delete w;
     }
+    workers.clear();
   }
+  ~EnqueuePool() { stop_all(); }
   int run(const std::function<int(size_t)> &job) {
     for (Worker *w : workers) {
       std::lock_guard<std::mutex> lk(w->mu);
@@ -514,7 +524,13 @@ int mgpu_frame_create(MgpuScene *const *scenes, const int *devices, int n, int W
   }
   if (n >= 2) { // (MgpuFrame::pool; opt-in until it has been measured on hardware: MGPU_FRAME_ENQUEUE_THREADS=1)
     const char *e = getenv("MGPU_FRAME_ENQUEUE_THREADS");
-    if (e && atoi(e) != 0) f->pool = new (std::nothrow) EnqueuePool((size_t)n);
+    if (e && atoi(e) != 0) {
+      try {
+        f->pool = new EnqueuePool((size_t)n);
+      } catch (...) { // no threads to be had: the caller's thread enqueues for everybody, as without the switch
+        f->pool = nullptr;
+      }
+    }
   }
   *out = f;
   return MGPU_OK;
