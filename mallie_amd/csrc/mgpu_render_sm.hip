@@ -514,15 +514,14 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
           emu_stats[8 + min((uint32_t)cT, 64u) / 4u] += 1; // steps by open leaves / 4
         }
         if (emu_log && emu_log_n + 66 < emu_log_cap) { // per-step record: cT, then every open leaf's run length (lane order), 0-terminated
-          const unsigned long long base = emu_log_n;
-          if (lane == 0) emu_log[base] = (unsigned char)cT;
-          if (st == ST_TRI) emu_log[base + 1 + __popcll(mT & ((1ull << lane) - 1ull))] = (unsigned char)min(len, 255u);
-          __builtin_amdgcn_wave_barrier();
+          unsigned long long base = 0;
+          if (lane == 0) base = atomicAdd(&emu_log_n, (unsigned long long)(cT + 2)); // (the waves of a workgroup take turns: reserve, then fill)
+          base = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(base >> 32), 0) << 32) | (unsigned long long)(uint32_t)__shfl((int)(uint32_t)base, 0);
           if (lane == 0) {
+            emu_log[base] = (unsigned char)cT;
             emu_log[base + 1 + cT] = 0;
-            emu_log_n = base + 2 + cT;
           }
-          __builtin_amdgcn_wave_barrier();
+          if (st == ST_TRI) emu_log[base + 1 + __popcll(mT & ((1ull << lane) - 1ull))] = (unsigned char)min(len, 255u);
         }
         // tests done by the step as built
         if (st == ST_TRI) atomicAdd(&emu_stats[6], (unsigned long long)min(len, (cT <= 32 ? (uint32_t)(MGPU_TRIS_PER_STEP) * (cT <= 16 ? 4u : 2u) : (uint32_t)MGPU_TRIS_PER_STEP)));

@@ -50,6 +50,7 @@ namespace {
 
 constexpr size_t kStackBytes = 256 * 1024;
 constexpr size_t kLdsBytes = 160 * 1024;
+constexpr int kTurn = 24; // cross-lane operations a wave gets per turn (about one step of the wave-scheduled kernels)
 
 enum State : int { RUNNABLE = 0, AT_WAVE_OP, AT_SYNC, ASLEEP, DONE };
 
@@ -180,11 +181,14 @@ void run_fiber(Sched &S, FiberImpl &f) {
   S.running = nullptr;
 }
 
-// Runs wave w until every live lane is at a workgroup barrier, asleep or done.  Returns true if anything ran.
-bool run_wave(Sched &S, size_t w) {
+// Runs wave w until every live lane is at a workgroup barrier, asleep or done -- or until it has been through `budget` cross-lane
+// operations: the waves of a workgroup take turns (a persistent wave that never meets a barrier would otherwise do the whole launch's
+// work alone while its neighbours never leave the prologue).  Returns true if anything ran.
+bool run_wave(Sched &S, size_t w, int budget) {
   const size_t n = S.fibers.size(), l0 = w * 64, l1 = std::min(n, l0 + 64);
   bool progressed = false;
-  for (;;) {
+  for (int ops = 0;;) {
+    if (ops >= budget) return true;
     bool ran = false;
     for (size_t l = l0; l < l1; ++l)
       if (S.fibers[l].state == RUNNABLE) {
@@ -237,6 +241,7 @@ bool run_wave(Sched &S, size_t w) {
       for (size_t l = l0; l < l1; ++l)
         if (S.fibers[l].state == AT_WAVE_OP) S.fibers[l].state = RUNNABLE;
       progressed = true;
+      ++ops;
       continue;
     }
     if (at_op != 0 && (at_sync != 0 || asleep != 0))
@@ -256,7 +261,7 @@ void run_block(Sched &S) {
   const size_t n = S.fibers.size(), waves = (n + 63) / 64;
   for (;;) {
     bool any = false;
-    for (size_t w = 0; w < waves; ++w) any |= run_wave(S, w);
+    for (size_t w = 0; w < waves; ++w) any |= run_wave(S, w, kTurn);
     size_t live = 0, at_sync = 0;
     for (const FiberImpl &f : S.fibers) {
       if (f.state == DONE) continue;
