@@ -192,6 +192,7 @@ struct MgpuScene {
   uint32_t srv_seq[kSrvSlots] = {};   // request numbers, written by the slot's owner
   std::atomic<unsigned long long> srv_launches{0}, srv_calls{0}, srv_ticks{0}; // ticks: device time of the served calls, 10 ns units
   unsigned long long srv_idle_us = 1000, srv_life_us = 100000; // MGPU_TRACE_SERVER_IDLE_US / _LIFE_US
+  double srv_timeout_ms = 10000.0; // MGPU_TRACE_SERVER_TIMEOUT_MS: how long a caller waits for its record before the call fails
   bool tile_order_on = true;   // MGPU_TILE_ORDER (read once, when the scene is created)
   unsigned tile_order_every = 4; // MGPU_TILE_ORDER_EVERY
   int tile_order_z = INT_MIN;    // MGPU_TILE_ORDER_Z: forces the hand-out order of HBM-resident scenes (render_frames_impl); INT_MIN: by launch size
@@ -749,8 +750,8 @@ int trace_served(MgpuScene *s, const MgpuRay *ray, MgpuIntersection *out, uint8_
       if (rc) break;
     }
     cpu_relax();
-    if ((spins & 0xFFFu) == 0xFFFu && now_ms() - t0 > 10000.0) {
-      rc = fail(MGPU_ERR_HIP, "trace server did not answer within 10 s");
+    if ((spins & 0xFFFu) == 0xFFFu && now_ms() - t0 > s->srv_timeout_ms) {
+      rc = fail(MGPU_ERR_HIP, "trace server did not answer within %.0f s", s->srv_timeout_ms * 1e-3);
       break;
     }
   }
@@ -981,6 +982,7 @@ int mgpu_scene_create(const double *verts, size_t nv, const uint32_t *faces, siz
   if (const char *e = getenv("MGPU_TRACE_SERVER")) s->srv_on = atoi(e) != 0;
   if (const char *e = getenv("MGPU_TRACE_SERVER_LDS")) s->srv_stage = atoi(e) != 0;
   if (const char *e = getenv("MGPU_TRACE_SERVER_IDLE_US")) s->srv_idle_us = (unsigned long long)(atoll(e) < 1 ? 1 : atoll(e));
+  if (const char *e = getenv("MGPU_TRACE_SERVER_TIMEOUT_MS")) s->srv_timeout_ms = atof(e) < 1.0 ? 1.0 : atof(e);
   if (const char *e = getenv("MGPU_TRACE_SERVER_LIFE_US")) s->srv_life_us = (unsigned long long)(atoll(e) < 100 ? 100 : atoll(e));
   if (const char *e = getenv("MGPU_TILE_ORDER")) s->tile_order_on = atoi(e) != 0;
   if (const char *e = getenv("MGPU_TILE_ORDER_Z")) s->tile_order_z = atoi(e);

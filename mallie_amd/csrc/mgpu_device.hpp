@@ -26,6 +26,9 @@
 // Does ANY lane executing this -- possibly divergent -- code satisfy p?  Only for choices between two forms that give every lane
 // the same bits (a shorter instruction sequence when all lanes qualify); the emulator lets every lane answer for itself.
 #define MGPU_ANY(p) (__ballot(p) != 0ull)
+// A word every lane of the wave loads from the same address in one instruction -- one value for the wave, whoever writes it meanwhile.
+// (The emulator's lanes load one after the other: it takes the first lane's.)
+#define MGPU_WAVE_LOAD(x) (x)
 #else
 #define MGPU_KEEP1(a) ((void)0)
 #define MGPU_KEEP2(a, b) ((void)0)
@@ -33,6 +36,7 @@
 #define MGPU_XCC_ID(v) ((v) = emu::g_cur->block_idx.x)
 #define MGPU_DYN_SHARED(T, name) T *name = reinterpret_cast<T *>(emu::g_cur->dyn_shared)
 #define MGPU_ANY(p) (p)
+#define MGPU_WAVE_LOAD(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #endif
 
 #include "mgpu_sincos.hpp"

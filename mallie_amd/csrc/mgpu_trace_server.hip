@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64) void k_trace_server(DScene sc, TraceMailbox *mb
   uint32_t served = owner ? sys_load(&mb->ack[slot]) : 0u;
   const unsigned long long t_start = wall_clock64();
   for (unsigned long long poll = 0; poll < max_polls; ++poll) {
-    if (__hip_atomic_load(&ctl->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    if (MGPU_WAVE_LOAD(__hip_atomic_load(&ctl->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break; // (the wave leaves together)
     // one poll: lanes 0..15 read their slots' request numbers (one 64-byte line of host memory), lane 16 the stop word
     // (ONE load instruction for both: two were two PCIe round trips per poll)
     uint32_t r = served;

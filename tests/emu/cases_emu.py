@@ -122,3 +122,40 @@ def test_batched_trace_vs_reference_records(kernel, monkeypatch):
     for name in ("t", "u", "v", "faceID"):
         m = hit.astype(bool)
         assert np.array_equal(out[name][m], t["hits"][name][:600][m]), name
+
+
+def test_one_ray_calls_through_the_resident_server():
+    """k_trace_server -- sixteen resident single-wave workgroups polling a mailbox in mapped host memory -- runs on the emulator as a
+    RESIDENT kernel: all workgroups alive, on a thread of its own, while the callers' threads post rays and spin on the
+    acknowledgements (mgpu_api.hip, trace_served).  Records of one-ray calls from one and from four threads equal the batched
+    kernel's and the reference's goldens."""
+    import threading
+    sc = _golden_scene("cornell_obj")
+    t = O.load_golden("trace_cornell_obj")
+    rays = t["rays"][:160]
+    ref, ref_hit = sc.trace(rays)
+    out, hit = sc.trace_calls(rays[:40], per_call=1)
+    assert np.array_equal(hit, ref_hit[:40]) and out.tobytes() == ref[:40].tobytes()
+    st = sc.trace_server_stats()
+    assert st["calls"] == 40 and st["launches"] >= 1
+    res = [None] * 4
+
+    def work(k):
+        res[k] = sc.trace_calls(rays[k::4], per_call=1)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for k in range(4):
+        assert np.array_equal(res[k][1], ref_hit[k::4]) and res[k][0].tobytes() == ref[k::4].tobytes(), k
+    m = ref_hit.astype(bool)
+    assert np.array_equal(ref["t"][m], t["hits"]["t"][:160][m]) and np.array_equal(ref["faceID"][m], t["hits"]["faceID"][:160][m])
+    # a render call retires the live launch first
+    W, H = 32, 24
+    frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    img = sc.render(frame, W, H, 3, 1, sc.plane(), M.RNG_HASH, seed=3)[0]
+    assert not sc.trace_server_stats()["alive"]
+    oimg = O.scene_from_golden("cornell_obj").render(frame, W, H, 3, 1, sc.plane(), O.RNG_HASH, seed=3)[0]
+    assert img.tobytes() == oimg.tobytes()
+    sc.close()

@@ -13,6 +13,8 @@
 #include <chrono>
 #include <cstdio>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 // AddressSanitizer has to be told about stack switches it did not make (python tests/emu/build_emu.py asan)
@@ -257,30 +259,33 @@ bool run_wave(Sched &S, size_t w, int budget) {
   }
 }
 
-void run_block(Sched &S) {
+// One turn of a workgroup: every wave gets its turn, then a completed barrier is released.  Returns false when nothing could run.
+enum TurnResult : int { TURN_DONE = 0, TURN_PROGRESS, TURN_STUCK };
+TurnResult block_turn(Sched &S) {
   const size_t n = S.fibers.size(), waves = (n + 63) / 64;
+  bool any = false;
+  for (size_t w = 0; w < waves; ++w) any |= run_wave(S, w, kTurn);
+  size_t live = 0, at_sync = 0;
+  for (const FiberImpl &f : S.fibers) {
+    if (f.state == DONE) continue;
+    ++live;
+    if (f.state == AT_SYNC) ++at_sync;
+  }
+  if (live == 0) return TURN_DONE;
+  if (at_sync == live) {
+    for (FiberImpl &f : S.fibers)
+      if (f.state == AT_SYNC) f.state = RUNNABLE; // (different __syncthreads sites in one barrier are legal on the hardware)
+    return TURN_PROGRESS;
+  }
+  if (at_sync != 0 && !any) die(S, "__syncthreads: some lanes wait at the barrier while the others have left the kernel or cannot reach it");
+  return any ? TURN_PROGRESS : TURN_STUCK;
+}
+
+void run_block(Sched &S) {
   for (;;) {
-    bool any = false;
-    for (size_t w = 0; w < waves; ++w) any |= run_wave(S, w, kTurn);
-    size_t live = 0, at_sync = 0;
-    for (const FiberImpl &f : S.fibers) {
-      if (f.state == DONE) continue;
-      ++live;
-      if (f.state == AT_SYNC) ++at_sync;
-    }
-    if (live == 0) return;
-    if (at_sync == live) {
-      int site = -1;
-      for (FiberImpl &f : S.fibers)
-        if (f.state == AT_SYNC) {
-          if (site < 0) site = f.site;
-          // (different __syncthreads sites in one barrier are legal on the hardware; noted only because they are usually a bug)
-          f.state = RUNNABLE;
-        }
-      continue;
-    }
-    if (at_sync != 0 && !any) die(S, "__syncthreads: some lanes wait at the barrier while the others have left the kernel or cannot reach it");
-    if (!any) die(S, "the workgroup made no progress");
+    const TurnResult r = block_turn(S);
+    if (r == TURN_DONE) return;
+    if (r == TURN_STUCK) die(S, "the workgroup made no progress");
   }
 }
 
@@ -319,26 +324,59 @@ unsigned long long wave_first(unsigned long long v, int site) {
 void wave_barrier(int site) { block_at(OP_WAVE_BARRIER, site, AT_WAVE_OP); }
 void block_sync(int site) { block_at(OP_SYNC, site, AT_SYNC); }
 void wave_sleep() { block_at(OP_SLEEP, 0, ASLEEP); }
-unsigned long long clock_ticks() {
-  static unsigned long long t = 0;
-  return t += 97; // a clock that moves (the kernels sample its low bits)
+unsigned long long clock_ticks() { // 100 MHz, as the device's wall clock
+  return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10ull;
 }
 
-void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &lane_entry) {
-  std::lock_guard<std::mutex> lock(g_launch_mutex);
-  const size_t nthreads = (size_t)block.x * block.y * block.z;
-  if (nthreads == 0 || nthreads > 1024 || shmem > kLdsBytes) {
-    fprintf(stderr, "emu: bad launch (block %zu threads, %zu bytes of dynamic LDS)\n", nthreads, shmem);
-    abort();
-  }
-  static const bool trace = getenv("MGPU_EMU_TRACE") != nullptr;
-  if (trace) fprintf(stderr, "emu: launch grid %u x %u x %u, block %zu, dynamic LDS %zu\n", grid.x, grid.y, grid.z, nthreads, shmem);
+// static LDS lives in one linker section (hip_runtime.h: __shared__); resident kernels keep one image of it per workgroup
+extern "C" char __start_emu_lds[], __stop_emu_lds[];
+// which static belongs to which kernel (generated by build_emu.py's second link pass; absent in the first)
+extern "C" {
+struct EmuLdsSym { const char *name; unsigned long off, size; };
+extern const EmuLdsSym emu_lds_table[] __attribute__((weak));
+}
+
+namespace {
+struct Block {
   Sched S;
-  S.entry = &lane_entry;
-  S.fibers.resize(nthreads);
-  static unsigned char *lds = nullptr;
-  if (!lds) lds = (unsigned char *)aligned_alloc(256, kLdsBytes);
-  S.lds = lds;
+  unsigned char *lds = nullptr;
+  std::vector<char> statics; // this workgroup's image of the resident kernel's static LDS (the ranges below, back to back)
+  bool done = false;
+};
+struct Range { size_t off, size; };
+// the static LDS variables of the kernel called `name` ("k_trace_server<CAP>" -> every k_trace_server<..>(...)::variable), merged
+std::vector<Range> statics_of(const char *name) {
+  std::vector<Range> r;
+  std::string key(name);
+  key = key.substr(0, key.find('<'));
+  if (&emu_lds_table[0] != nullptr && !key.empty())
+    for (const EmuLdsSym *e = emu_lds_table; e->name; ++e) {
+      const std::string n(e->name);
+      const size_t at = n.find(key);
+      if (at != std::string::npos && (n[at + key.size()] == '<' || n[at + key.size()] == '(') && (at == 0 || n[at - 1] == ':' || n[at - 1] == ' '))
+        r.push_back(Range{e->off, e->size});
+    }
+  if (r.empty()) r.push_back(Range{0, (size_t)(__stop_emu_lds - __start_emu_lds)}); // no table: the whole section
+  return r;
+}
+void copy_in(const std::vector<Range> &rs, const std::vector<char> &img) {
+  size_t at = 0;
+  for (const Range &r : rs) {
+    memcpy(__start_emu_lds + r.off, img.data() + at, r.size);
+    at += r.size;
+  }
+}
+void copy_out(const std::vector<Range> &rs, std::vector<char> &img) {
+  size_t at = 0;
+  for (const Range &r : rs) {
+    memcpy(img.data() + at, __start_emu_lds + r.off, r.size);
+    at += r.size;
+  }
+}
+std::mutex g_resident_mutex;
+std::vector<std::thread> g_resident; // guarded by g_resident_mutex
+
+void take_stacks(Sched &S) {
   for (FiberImpl &f : S.fibers) {
     if (!g_stack_pool.empty()) {
       f.stack = g_stack_pool.back();
@@ -350,10 +388,51 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &la
         abort();
       }
     }
+#if EMU_TSAN
+    f.tsan = __tsan_create_fiber(0);
+#endif
   }
+}
+void give_stacks(Sched &S) {
+  for (FiberImpl &f : S.fibers) {
+    g_stack_pool.push_back(f.stack);
+#if EMU_TSAN
+    __tsan_destroy_fiber(f.tsan);
+#endif
+  }
+}
+void arm(Sched &S, unsigned bx, unsigned by, unsigned bz, dim3 grid, dim3 block, unsigned char *lds) {
+  const size_t nthreads = S.fibers.size();
+  for (size_t t = 0; t < nthreads; ++t) {
+    FiberImpl &f = S.fibers[t];
+    f.ctx.thread_idx = Idx{(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y), (unsigned)(t / ((size_t)block.x * block.y))};
+    f.ctx.block_idx = Idx{bx, by, bz};
+    f.ctx.block_dim = Idx{block.x, block.y, block.z};
+    f.ctx.grid_dim = Idx{grid.x, grid.y, grid.z};
+    f.ctx.dyn_shared = lds;
+    f.ctx.lane = (int)(t & 63);
+    f.state = RUNNABLE;
+    prepare(f);
+  }
+}
+bool is_resident(const char *name) {
+  const char *e = getenv("MGPU_EMU_RESIDENT");
+  const std::string pat = e ? e : "k_trace_server";
+  return !pat.empty() && std::string(name).find(pat) != std::string::npos;
+}
+
+// every workgroup to completion, one after another, on the calling thread
+void run_serial(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &lane_entry) {
+  const size_t nthreads = (size_t)block.x * block.y * block.z;
+  Sched S;
+  S.entry = &lane_entry;
+  S.fibers.resize(nthreads);
+  static unsigned char *lds = nullptr;
+  if (!lds) lds = (unsigned char *)aligned_alloc(256, kLdsBytes);
+  S.lds = lds;
+  take_stacks(S);
 #if EMU_TSAN
   S.main_tsan = __tsan_get_current_fiber();
-  for (FiberImpl &f : S.fibers) f.tsan = __tsan_create_fiber(0);
 #endif
   Sched *outer = g_sched;
   Ctx *outer_cur = g_cur;
@@ -368,17 +447,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &la
 #if EMU_ASAN
         __asan_poison_memory_region(lds + shmem, kLdsBytes - shmem);
 #endif
-        for (size_t t = 0; t < nthreads; ++t) {
-          FiberImpl &f = S.fibers[t];
-          f.ctx.thread_idx = Idx{(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y), (unsigned)(t / ((size_t)block.x * block.y))};
-          f.ctx.block_idx = Idx{bx, by, bz};
-          f.ctx.block_dim = Idx{block.x, block.y, block.z};
-          f.ctx.grid_dim = Idx{grid.x, grid.y, grid.z};
-          f.ctx.dyn_shared = lds;
-          f.ctx.lane = (int)(t & 63);
-          f.state = RUNNABLE;
-          prepare(f);
-        }
+        arm(S, bx, by, bz, grid, block, lds);
         run_block(S);
 #if EMU_ASAN
         __asan_unpoison_memory_region(lds + shmem, kLdsBytes - shmem);
@@ -391,10 +460,91 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &la
       }
   g_sched = outer;
   g_cur = outer_cur;
-  for (FiberImpl &f : S.fibers) g_stack_pool.push_back(f.stack);
+  give_stacks(S);
+}
+
+// all workgroups alive, taking turns; static LDS swapped with the workgroup
+void run_resident(const char *name, dim3 grid, dim3 block, size_t shmem, const std::function<void()> &lane_entry) {
+  const size_t nthreads = (size_t)block.x * block.y * block.z, nblocks = (size_t)grid.x * grid.y * grid.z;
+  const std::vector<Range> ranges = statics_of(name);
+  size_t nstat = 0;
+  for (const Range &r : ranges) nstat += r.size;
+  std::vector<Block> blocks(nblocks);
+  size_t i = 0;
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx, ++i) {
+        Block &b = blocks[i];
+        b.S.entry = &lane_entry;
+        b.S.fibers.resize(nthreads);
+        b.lds = (unsigned char *)aligned_alloc(256, (shmem + 255 + 4096) & ~(size_t)255);
+        memset(b.lds, 0xCD, shmem);
+        take_stacks(b.S);
 #if EMU_TSAN
-  for (FiberImpl &f : S.fibers) __tsan_destroy_fiber(f.tsan);
+        b.S.main_tsan = __tsan_get_current_fiber();
 #endif
+        arm(b.S, bx, by, bz, grid, block, b.lds);
+        b.statics.resize(nstat);
+        copy_out(ranges, b.statics);
+      }
+  Sched *outer = g_sched;
+  Ctx *outer_cur = g_cur;
+  unsigned long long rounds = 0;
+  for (;;) {
+    ++rounds;
+    bool live = false, progress = false;
+    for (Block &b : blocks) {
+      if (b.done) continue;
+      copy_in(ranges, b.statics);
+      g_sched = &b.S;
+      const TurnResult r = block_turn(b.S);
+      copy_out(ranges, b.statics);
+      if (r == TURN_DONE) b.done = true;
+      else live = true;
+      if (r != TURN_STUCK) progress = true;
+    }
+    if (!live) break;
+    if (!progress) die(blocks[0].S, "a resident kernel made no progress in any workgroup");
+  }
+  g_sched = outer;
+  g_cur = outer_cur;
+  if (getenv("MGPU_EMU_TRACE")) fprintf(stderr, "emu: resident kernel %s left after %llu rounds (%zu bytes of static LDS per workgroup)\n", name, rounds, nstat);
+  for (Block &b : blocks) {
+    give_stacks(b.S);
+    free(b.lds);
+  }
+}
+} // namespace
+
+void launch(const char *name, dim3 grid, dim3 block, size_t shmem, std::function<void()> lane_entry) {
+  const size_t nthreads = (size_t)block.x * block.y * block.z;
+  if (nthreads == 0 || nthreads > 1024 || shmem > kLdsBytes) {
+    fprintf(stderr, "emu: bad launch of %s (block %zu threads, %zu bytes of dynamic LDS)\n", name, nthreads, shmem);
+    abort();
+  }
+  static const bool trace = getenv("MGPU_EMU_TRACE") != nullptr;
+  const bool resident = is_resident(name);
+  if (trace) fprintf(stderr, "emu: launch %s grid %u x %u x %u, block %zu, dynamic LDS %zu%s\n", name, grid.x, grid.y, grid.z, nthreads, shmem, resident ? " (resident)" : "");
+  if (!resident) {
+    std::lock_guard<std::mutex> lock(g_launch_mutex);
+    run_serial(grid, block, shmem, lane_entry);
+    return;
+  }
+  std::lock_guard<std::mutex> rl(g_resident_mutex);
+  const std::string kname(name);
+  g_resident.emplace_back([=]() {
+    std::lock_guard<std::mutex> lock(g_launch_mutex); // one kernel at a time: the static LDS section is the process's
+    run_resident(kname.c_str(), grid, block, shmem, lane_entry);
+  });
+}
+
+void wait_resident() {
+  std::vector<std::thread> mine;
+  {
+    std::lock_guard<std::mutex> rl(g_resident_mutex);
+    mine.swap(g_resident);
+  }
+  for (std::thread &t : mine) t.join();
 }
 
 } // namespace emu
@@ -451,10 +601,10 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
   p->sharedMemPerBlock = 160 * 1024;
   return hipSuccess;
 }
-hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipDeviceSynchronize() { emu::wait_resident(); return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new emuStream{0}; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { emu::wait_resident(); return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t *e) { *e = new emuEvent{std::chrono::steady_clock::now(), false}; return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }

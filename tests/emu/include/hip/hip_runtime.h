@@ -31,7 +31,7 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
-#define __shared__ static
+#define __shared__ static __attribute__((section("emu_lds")))
 #define address_space(x) // __attribute__((address_space(3))) -> __attribute__(())
 
 // ---- vector types ---------------------------------------------------------------------------------------------------------------
@@ -69,7 +69,11 @@ void wave_barrier(int site);
 void block_sync(int site);
 void wave_sleep();
 unsigned long long clock_ticks();
-void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &lane_entry);
+// name: the launch site's kernel expression.  Kernels named in MGPU_EMU_RESIDENT (default: k_trace_server) are RESIDENT kernels: all
+// their workgroups are alive at once (taking turns) and the launch returns at once, the kernel running on a thread of its own until
+// it leaves -- the host talks to them through mapped memory while they run.  Everything else runs to completion inside the call.
+void launch(const char *name, dim3 grid, dim3 block, size_t shmem, std::function<void()> lane_entry);
+void wait_resident(); // joins resident kernels that have left or are leaving (stream / device synchronisation)
 } // namespace emu
 
 #define threadIdx (emu::g_cur->thread_idx)
@@ -233,4 +237,4 @@ hipError_t hipFuncSetAttribute(const void *f, hipFuncAttribute a, int v);
 
 // the kernel's name is not allowed to contain a top-level comma (the library's launch sites bind template-ids to a variable first)
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
-  emu::launch(dim3(grid), dim3(block), (size_t)(shmem), [&]() { kern(__VA_ARGS__); })
+  emu::launch(#kern, dim3(grid), dim3(block), (size_t)(shmem), [=]() mutable { kern(__VA_ARGS__); })
