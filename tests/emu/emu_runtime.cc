@@ -192,11 +192,29 @@ bool run_wave(Sched &S, size_t w, int budget) {
   for (int ops = 0;;) {
     if (ops >= budget) return true;
     bool ran = false;
-    for (size_t l = l0; l < l1; ++l)
-      if (S.fibers[l].state == RUNNABLE) {
-        run_fiber(S, S.fibers[l]);
+    // The order in which a wave's lanes run between two cross-lane operations is the emulator's choice -- the hardware runs them in
+    // lockstep, and code that is correct there for any reason other than an explicit wave barrier depends on it.  MGPU_EMU_LANE_ORDER =
+    // reverse | random makes such dependences visible (the k_trace finding of round 5); the default is lane 0 first.
+    static const int order = [] {
+      const char *e = getenv("MGPU_EMU_LANE_ORDER");
+      return !e ? 0 : (!strcmp(e, "reverse") ? 1 : (!strcmp(e, "random") ? 2 : 0));
+    }();
+    static thread_local unsigned long long lcg = 0x9E3779B97F4A7C15ull;
+    const size_t cnt = l1 - l0;
+    size_t rot = 0, stride = 1;
+    if (order == 2) {
+      lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+      rot = (size_t)(lcg >> 33) % cnt;
+      stride = (cnt == 64) ? ((size_t)((lcg >> 20) & 31u) * 2 + 1) : 1; // odd: a permutation of 64
+    }
+    for (size_t k = 0; k < cnt; ++k) {
+      const size_t i = order == 1 ? cnt - 1 - k : (order == 2 ? (rot + k * stride) % cnt : k);
+      FiberImpl &f = S.fibers[l0 + i];
+      if (f.state == RUNNABLE) {
+        run_fiber(S, f);
         ran = true;
       }
+    }
     progressed |= ran;
     // where does the wave stand?
     int live = 0, at_op = 0, at_sync = 0, asleep = 0;
