@@ -534,7 +534,8 @@ void run_resident(const char *name, dim3 grid, dim3 block, size_t shmem, const s
 }
 } // namespace
 
-void launch(const char *name, dim3 grid, dim3 block, size_t shmem, std::function<void()> lane_entry) {
+void launch(const char *name, dim3 grid, dim3 block, size_t shmem, const std::function<void()> &lane_entry,
+            const std::function<std::function<void()>()> &owning_copy) {
   const size_t nthreads = (size_t)block.x * block.y * block.z;
   if (nthreads == 0 || nthreads > 1024 || shmem > kLdsBytes) {
     fprintf(stderr, "emu: bad launch of %s (block %zu threads, %zu bytes of dynamic LDS)\n", name, nthreads, shmem);
@@ -550,9 +551,10 @@ void launch(const char *name, dim3 grid, dim3 block, size_t shmem, std::function
   }
   std::lock_guard<std::mutex> rl(g_resident_mutex);
   const std::string kname(name);
+  const std::function<void()> owned = owning_copy();
   g_resident.emplace_back([=]() {
     std::lock_guard<std::mutex> lock(g_launch_mutex); // one kernel at a time: the static LDS section is the process's
-    run_resident(kname.c_str(), grid, block, shmem, lane_entry);
+    run_resident(kname.c_str(), grid, block, shmem, owned);
   });
 }
 

@@ -72,7 +72,10 @@ unsigned long long clock_ticks();
 // name: the launch site's kernel expression.  Kernels named in MGPU_EMU_RESIDENT (default: k_trace_server) are RESIDENT kernels: all
 // their workgroups are alive at once (taking turns) and the launch returns at once, the kernel running on a thread of its own until
 // it leaves -- the host talks to them through mapped memory while they run.  Everything else runs to completion inside the call.
-void launch(const char *name, dim3 grid, dim3 block, size_t shmem, std::function<void()> lane_entry);
+// lane_entry refers to the launch site's arguments (valid until the call returns); owning_copy() makes an entry that owns copies of
+// them -- asked for only by resident kernels, which outlive the call (their arguments are plain data).
+void launch(const char *name, dim3 grid, dim3 block, size_t shmem, const std::function<void()> &lane_entry,
+            const std::function<std::function<void()>()> &owning_copy);
 void wait_resident(); // joins resident kernels that have left or are leaving (stream / device synchronisation)
 } // namespace emu
 
@@ -237,4 +240,5 @@ hipError_t hipFuncSetAttribute(const void *f, hipFuncAttribute a, int v);
 
 // the kernel's name is not allowed to contain a top-level comma (the library's launch sites bind template-ids to a variable first)
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
-  emu::launch(#kern, dim3(grid), dim3(block), (size_t)(shmem), [=]() mutable { kern(__VA_ARGS__); })
+  emu::launch(#kern, dim3(grid), dim3(block), (size_t)(shmem), [&]() { kern(__VA_ARGS__); }, \
+              [&]() { return std::function<void()>([=]() mutable { kern(__VA_ARGS__); }); })
