@@ -159,3 +159,34 @@ def test_one_ray_calls_through_the_resident_server():
     oimg = O.scene_from_golden("cornell_obj").render(frame, W, H, 3, 1, sc.plane(), O.RNG_HASH, seed=3)[0]
     assert img.tobytes() == oimg.tobytes()
     sc.close()
+
+
+def test_five_wave_kernel_on_a_deep_tree(monkeypatch):
+    """k_render_w5 keeps five far-child entries per lane in LDS; deeper ones go to the lane's column in HBM.  A chain of shells of
+    geometrically growing size seen from inside gives a tree of depth 256 (minLeafPrimitives 1) whose walks hold far more: frames and
+    counters equal k_render_sm's (eight entries in LDS) and the oracle's."""
+    monkeypatch.setenv("MGPU_RENDER_KERNEL", "sm")
+    rng = np.random.default_rng(7)
+    V, F = [], []
+    for k in range(70):
+        s = 1.25 ** k
+        c = np.array([s, 0.15 * s * rng.normal(), 0.15 * s * rng.normal()])
+        for _ in range(2):
+            a = c + 0.25 * s * np.array([0.0, rng.normal(), rng.normal()])
+            V += [a, a + 0.2 * s * np.array([0.02, 1.0, 0.1]), a + 0.2 * s * np.array([-0.02, 0.1, 1.0])]
+            F.append([len(V) - 3, len(V) - 2, len(V) - 1])
+    verts, faces = np.array(V), np.array(F, "u4")
+    nodes, idx, st = M.bvh_build(verts, faces, minLeaf=1)
+    assert st["maxTreeDepth"] > 40
+    ref = M.Scene(verts, faces, None, None, None, nodes, idx)
+    W, H = 96, 64
+    frame = M.camera_frame((-2.0, 0.0, 0.0), (10.0, 0.0, 0.0), width=W, height=H)
+    rimg, rcnt, rst = ref.render(frame, W, H, 6, 2, None, M.RNG_HASH, seed=3)
+    monkeypatch.setenv("MGPU_W5", "1")
+    sc = M.Scene(verts, faces, None, None, None, nodes, idx)
+    img, cnt, s5 = sc.render(frame, W, H, 6, 2, None, M.RNG_HASH, seed=3)
+    assert img.tobytes() == rimg.tobytes() and all(s5[f] == rst[f] for f in FIELDS + ("paths",)), (s5, rst)
+    assert s5["nodes"] > 5 * s5["real_rays"]
+    osc = O.OracleScene(verts, faces, None, None, None, nodes, idx)
+    oimg, _, ost, _ = osc.render(frame, W, H, 6, 2, None, O.RNG_HASH, seed=3)
+    assert img.tobytes() == oimg.tobytes() and ost["nodes"] == s5["nodes"] and ost["tris"] == s5["tris"]
