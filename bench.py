@@ -65,30 +65,83 @@ def so_sha256(path):
     return h.hexdigest()
 
 
+_SELF_PMC = {"entries": {}, "log": [], "t0": None, "enabled": True}
+# wall-clock budget of the counter passes bench.py runs itself (all workloads together); the headline workload goes first
+SELF_PMC_BUDGET_S = float(os.environ.get("MALLIE_BENCH_SELF_PMC_BUDGET", "420"))
+
+
+def self_pmc(workload):
+    """No committed PMC pass has seen the library loaded now: collect the passes here (tools/pmc_collect.py -- rocprofv3 in processes
+    of their own, AFTER the timed region, counters never together with tracing), once per workload and run.  Returns (entry or
+    None, reason).  MALLIE_BENCH_SELF_PMC=0 switches it off."""
+    if os.environ.get("MALLIE_BENCH_SELF_PMC", "1") == "0" or not _SELF_PMC["enabled"]:
+        return None, "self-collection switched off (MALLIE_BENCH_SELF_PMC=0, --no-extras or N > 1)"
+    if workload in _SELF_PMC["entries"]:
+        return _SELF_PMC["entries"][workload]
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_collect
+    if pmc_collect.rocprof() is None:
+        res = (None, "no rocprofv3 on this box")
+    else:
+        if _SELF_PMC["t0"] is None:
+            _SELF_PMC["t0"] = time.monotonic()
+        out_dir = os.path.join(ROOT, "gpurun_out", "self_pmc")
+        head = workload == "c2"
+        # the headline workload: every pass + a kernel trace; the HBM-resident extras: traffic first, the SQ pass while the budget lasts
+        e = pmc_collect.collect(workload, out_dir, frames=3 if workload != "c5" else 1, passes=("sq", "fetch", "write", "sq2") if head else ("fetch", "write", "sq", "sq2"),
+                                trace=head, trace_frames=10, timeout=240, deadline=_SELF_PMC["t0"] + SELF_PMC_BUDGET_S, log=_SELF_PMC["log"])
+        if e:
+            res = (e, "collected by THIS run after its timed region (tools/pmc_collect.py: rocprofv3 --pmc, one process per pass, over "
+                      "tools/pmc_workload.py %s; raw CSVs under gpurun_out/self_pmc/): %s" % (workload, "; ".join(l for l in _SELF_PMC["log"] if l.startswith(workload))))
+        else:
+            res = (None, "rocprofv3 passes left nothing to read: %s" % "; ".join(_SELF_PMC["log"][-4:]))
+    _SELF_PMC["entries"][workload] = res
+    return res
+
+
+def self_pmc_dump(lib_path):
+    """What the self-collected passes gave, in profiles/pmc_current.json's format, under gpurun_out/self_pmc/ (it travels back from the GPU box)."""
+    got = {w: e for w, (e, _) in _SELF_PMC["entries"].items() if e}
+    if not got:
+        return
+    from mallie_amd import build as _b
+    try:
+        with open(os.path.join(ROOT, "gpurun_out", "self_pmc", "pmc_current.json"), "w") as f:
+            json.dump({"so_sha256": so_sha256(lib_path), "source_sha256": _b.source_digest(), "tag": "self_pmc", "workloads": got,
+                       "log": _SELF_PMC["log"]}, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
 def pmc_for(workload, lib_path):
-    """Per-FRAME PMC numbers of the dominant kernel (summed over its launches of one frame) on `workload` from profiles/pmc_current.json (profiles/collect_pmc.sh +
-    profiles/summarize_pmc.py) -- only if they were collected on the library loaded now.  Returns (dict or None, reason)."""
+    """Per-FRAME PMC numbers of the dominant kernel (summed over its launches of one frame) on `workload`: from profiles/pmc_current.json
+    (profiles/collect_pmc.sh + profiles/summarize_pmc.py) when those passes ran on the library loaded now, else collected by this run
+    itself (self_pmc).  Returns (dict or None, reason)."""
+    why_not = "no profiles/pmc_current.json"
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_current.json")) as f:
             d = json.load(f)
     except (OSError, ValueError):
-        return None, "no profiles/pmc_current.json"
-    from mallie_amd import build as _b
-    if d.get("so_sha256") == so_sha256(lib_path):
-        stamp = "library sha256 %s" % d["so_sha256"][:16]
-    elif d.get("source_sha256") and d.get("source_sha256") == _b.source_digest() and not _b.is_stale():
-        stamp = "source digest %s (same sources and flags, library rebuilt elsewhere)" % d["source_sha256"][:16]
-    else:
-        return None, "profiles/pmc_current.json was collected on another build of the library (sha256 of library and sources differ)"
-    w = d.get("workloads", {}).get(workload)
-    if not w:
-        return None, "profiles/pmc_current.json has no entry for %s" % workload
-    return w, "profiles/pmc_current.json (rocprofv3 --pmc, separate passes), %s" % stamp
+        d = None
+    if d is not None:
+        from mallie_amd import build as _b
+        stamp = None
+        if d.get("so_sha256") == so_sha256(lib_path):
+            stamp = "library sha256 %s" % d["so_sha256"][:16]
+        elif d.get("source_sha256") and d.get("source_sha256") == _b.source_digest() and not _b.is_stale():
+            stamp = "source digest %s (same sources and flags, library rebuilt elsewhere)" % d["source_sha256"][:16]
+        w = d.get("workloads", {}).get(workload) if stamp else None
+        if w:
+            return w, "profiles/pmc_current.json (rocprofv3 --pmc, separate passes), %s" % stamp
+        why_not = ("profiles/pmc_current.json has no entry for %s" % workload) if stamp else \
+            "profiles/pmc_current.json was collected on another build of the library (sha256 of library and sources differ)"
+    e, why = self_pmc(workload)
+    return e, (why if e else "%s; %s" % (why_not, why))
 
 
 def pmc_stale(workload):
     """The committed PMC numbers of `workload` WHATEVER library they were collected on, with their tag -- for the bench line of a library
-    no PMC pass has seen yet (reported beside a null `frac`, never as it)."""
+    no PMC pass could see (no rocprofv3 on the box): reported beside a null `frac`, never as it."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_current.json")) as f:
             d = json.load(f)
@@ -635,6 +688,9 @@ def main():
 
     if rank == 0:
         lib_path = M.lib_path()
+        # counter passes of its own (when the committed ones are of another build): single GPU, full runs only -- never under
+        # --no-extras, which is how profiles/collect_pmc.sh runs this script UNDER rocprofv3
+        _SELF_PMC["enabled"] = world == 1 and not args.no_extras
         ms_per_step = 1e3 * elapsed / args.steps
         value = rays / elapsed / 1e6
         # the dominant kernel (k_render_sm) on rank 0: algorithmic bytes of one launch / its mean duration
@@ -654,17 +710,18 @@ def main():
             p, why = pmc_for("c2", lib_path) if world == 1 else (None, "PMC passes are single-GPU")
             traffic = hbm_bytes(p)
             alg_gbs = alg_bytes_launch / ksec / 1e9 if ksec > 0 else 0.0
-            ginst_run = p["SQ_INSTS_VALU"] / ksec / 1e9 if p and "SQ_INSTS_VALU" in p and ksec > 0 else None
-            # `achieved` / `frac` over the kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of the SAME
-            # library (profiles/<tag>_summary.txt; pmc_current.json carries it as traced_kernel_avg_ms) -- the reproducible figure; the
-            # traced run is a few % slower than this one (its read-backs become blit kernels) -- and the figure over THIS run's own
-            # HIP-event kernel time beside it
+            # `achieved` / `frac`: the kernel's executed VALU wave-instructions per launch (counter pass) over THIS run's mean launch
+            # duration (HIP events on the launch stream, timed region).  The same count over the kernel's average in the
+            # rocprofv3 --kernel-trace --stats pass of the SAME library (committed under profiles/, or collected by this run) is kept
+            # beside it as `frac_traced_profile`: the two durations must agree (a traced run is a few % slower).
+            ginst = p["SQ_INSTS_VALU"] / ksec / 1e9 if p and "SQ_INSTS_VALU" in p and ksec > 0 else None
             traced_ms = p.get("traced_kernel_avg_ms") if p else None
-            ginst = p["SQ_INSTS_VALU"] / (traced_ms * 1e-3) / 1e9 if ginst_run and traced_ms else ginst_run
+            ginst_traced = p["SQ_INSTS_VALU"] / (traced_ms * 1e-3) / 1e9 if ginst and traced_ms else None
             roof = {"bound": "valu", "unit": "Ginst/s", "peak": round(VALU_PEAK_GINST, 1),
                     "achieved": round(ginst, 1) if ginst else None, "frac": round(ginst / VALU_PEAK_GINST, 4) if ginst else None,
-                    "frac_over": ("kernel average of the traced bench run in profiles/ (%.3f ms)" % traced_ms) if traced_ms and ginst_run else "this run's HIP-event kernel time",
-                    "frac_this_run": round(ginst_run / VALU_PEAK_GINST, 4) if ginst_run else None,
+                    "frac_over": "this run's HIP-event kernel time (%.3f ms per launch, %d launches timed)" % (kernel_avg_ms, launch_counts[0]),
+                    "frac_traced_profile": round(ginst_traced / VALU_PEAK_GINST, 4) if ginst_traced else None,
+                    "traced_kernel_avg_ms": round(traced_ms, 3) if traced_ms else None,
                     "traffic": traffic, "kernel": "k_render_sm", "kernel_avg_ms": round(kernel_avg_ms, 3), "pmc_source": why,
                     "valu": None, "hbm": None,
                     "algorithmic_vs_hbm": {"bytes_per_launch": int(alg_bytes_launch), "GBps": round(alg_gbs, 1),
@@ -681,7 +738,7 @@ def main():
                                 "issue_busy": round(p["SQ_ACTIVE_INST_VALU"] * 4.0 / (ksec * CLOCK_HZ * N_SIMD), 3),
                                 "salu_insts_per_frame": int(p["SQ_INSTS_SALU"]) if "SQ_INSTS_SALU" in p else None}
             if p is None and world == 1 and ksec > 0:
-                # no PMC pass exists for the library loaded now: `achieved` / `frac` stay null.  What the last stamped library's
+                # no PMC pass exists for the library loaded now and none could be collected here: `achieved` / `frac` stay null.  What the last stamped library's
                 # instruction count would give over THIS run's kernel time is reported under its own name (the count moves by a few %
                 # with the kernel's code; the figure is an indication, not a measurement of this library)
                 sp, stag = pmc_stale("c2")
@@ -706,10 +763,11 @@ def main():
                              % (12e-6 * W * H, " and exchange" if world > 1 else "", host_frames_taken, args.steps)) if readback else "none: frames stay in HBM",
                 "rays_per_frame": int(rays / args.steps), "trace_calls_per_frame": int(trace_calls / args.steps),
                 "nodes_per_ray": round(nodes / rays, 3), "tris_per_ray": round(tris / rays, 3),
-                "work_counters": ("nodes / tris per ray = the reference's node pops and TriangleIsect calls (equal to the oracle's counters); with the "
-                                  "scene in LDS the leaf hints drop tests the ray provably cannot pass and book them as made (how many: "
-                                  "tools/perf_hint_classes.py on a diagnostic build, DESIGN.md 4.1)") if key == "c2" else
-                                 "nodes / tris per ray = the reference's node pops and TriangleIsect calls (equal to the oracle's counters)",
+                "work_counters": ("nodes / tris per ray = the reference's node pops and TriangleIsect calls: exactly the oracle's counters for primary "
+                                  "rays and batched traces, within 0.2 % of them for bounce rays (the tests' bound, tests/test_gpu_parity.py assert_same_work: "
+                                  "bounce directions carry the <= 1 ulp difference between the device's and glibc's acos / sin / cos)"
+                                  + ("; with the scene in LDS the leaf hints drop tests the ray provably cannot pass and book them as made (how many: "
+                                     "tools/perf_hint_classes.py on a diagnostic build, DESIGN.md 4.1)" if key == "c2" else "")),
                 "mtrace_calls_per_s": round(trace_calls / elapsed / 1e6, 2),
                 # what the multi-GPU machinery says about itself: communicator size read back from RCCL (ncclCommCount), the
                 # exchange step's device time per frame (HIP events on rank 0's communicator stream) and mean kernel time per
@@ -851,6 +909,7 @@ def main():
     # come out at process exit, AFTER the result: flush it first, on every rank, so that the JSON line is the last line
     flush_c_stdio()
     if out is not None:
+        self_pmc_dump(M.lib_path())
         print(json.dumps(out), flush=True)
 
 

@@ -15,7 +15,7 @@ LIB_OCC = os.path.join(HERE, "libmallie_mgpu_occ.so")
 LIB_LITERAL = os.path.join(HERE, "libmallie_mgpu_literal.so")
 SOURCES = ["mgpu_kernels.hip", "mgpu_render_sm.hip", "mgpu_render_w5.hip", "mgpu_trace_sm.hip", "mgpu_trace_server.hip", "mgpu_render_env.hip", "mgpu_bvh_build.hip", "mgpu_api.hip", "mgpu_frame.hip", "mgpu_stream.hip", "mgpu_render_f32.hip", "host/bvh_build.cc", "host/camera.cc", "host/scene_render.cc",
            "host/mesh_io.cc"]
-HEADERS = ["mgpu_device.hpp", "mgpu_kernels.hpp", "mgpu_sincos.hpp", "host/mesh_io.hpp", os.path.join("..", "..", "include", "mgpu.h"), os.path.join("..", "..", "include", "mgpu_internal.h"),
+HEADERS = ["mgpu_device.hpp", "mgpu_kernels.hpp", "mgpu_sincos.hpp", "mgpu_enqueue_pool.hpp", "host/mesh_io.hpp", os.path.join("..", "..", "include", "mgpu.h"), os.path.join("..", "..", "include", "mgpu_internal.h"),
            os.path.join("..", "..", "include", "mallie", "mallie_api.hpp")]
 # -ffp-contract=off: the parity contract (no FMA contraction on device or host), see csrc/mgpu_device.hpp
 # -ffile-prefix-map: __FILE__ (error messages) does not carry the checkout's path.  The binary still depends on that path

@@ -87,7 +87,7 @@ struct RenderSlot {
   void *p_overflow = nullptr;       // HBM stack overflow columns (deep trees only)
   size_t overflow_lanes = 0;
   void *p_woverflow = nullptr;      // the same for the wide traversal's far-child stack (16-byte entries)
-  size_t woverflow_lanes = 0;
+  size_t woverflow_entries = 0;     // its capacity in entries (lanes x entries per lane of the launch that sized it)
 };
 
 struct MgpuScene {
@@ -414,17 +414,20 @@ int slot_woverflow(MgpuScene *s, RenderSlot &r, size_t lanes, DScene &d, int lds
   d.wstack_overflow = nullptr;
   d.woverflow_cap = 0;
   if (extra <= 0) return MGPU_OK;
-  if (lanes > r.woverflow_lanes) {
+  // `extra` differs between the kernels that share a slot (k_render_w5 keeps fewer entries in LDS than k_render_sm): the buffer is
+  // sized, and its size remembered, in ENTRIES -- a column pitch of this launch times its lanes must fit, whatever launch allocated it
+  const size_t need = lanes * (size_t)extra;
+  if (need > r.woverflow_entries) {
     if (r.p_woverflow) {
       HIP_TRY(hipDeviceSynchronize());
       HIP_TRY(hipFree(r.p_woverflow));
-      s->device_bytes -= r.woverflow_lanes * (size_t)extra * sizeof(uint4);
+      s->device_bytes -= r.woverflow_entries * sizeof(uint4);
       r.p_woverflow = nullptr;
-      r.woverflow_lanes = 0;
+      r.woverflow_entries = 0;
     }
-    int rc = dev_alloc(s, &r.p_woverflow, lanes * (size_t)extra * sizeof(uint4));
+    int rc = dev_alloc(s, &r.p_woverflow, need * sizeof(uint4));
     if (rc) return rc;
-    r.woverflow_lanes = lanes;
+    r.woverflow_entries = need;
   }
   d.wstack_overflow = (uint4 *)r.p_woverflow;
   d.woverflow_cap = (uint32_t)extra;

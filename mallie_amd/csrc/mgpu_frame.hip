@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/mgpu.h"
+#include "mgpu_enqueue_pool.hpp"
 
 // The handful of RCCL declarations this file needs, written out so that the library builds where the RCCL headers are not
 // installed (single-GPU users never load RCCL at all): rccl.h, `ncclUniqueId` / `ncclResult_t` / `ncclDataType_t`.
@@ -167,83 +168,6 @@ struct MgpuFrame {
   // MGPU_FRAME_ENQUEUE_THREADS=1 (opt-in).  The exchange phase stays on the caller's thread: it
   // is one RCCL group / one chain of copies on rank 0's stream.
   struct EnqueuePool *pool = nullptr;
-};
-
-// One worker thread per member of a frame object that drives several GPUs from one process (MgpuFrame::pool).  run() hands every
-// worker the same job (called with the worker's member index) and returns when all of them have finished: the largest return code,
-// and that worker's error text in the caller's thread-local message buffer.
-struct EnqueuePool {
-  struct Worker {
-    std::thread th;
-    std::mutex mu;
-    std::condition_variable cv;
-    const std::function<int(size_t)> *job = nullptr; // posted by run(), cleared by the worker
-    bool quit = false, done = true;
-    int rc = MGPU_OK;
-    char err[512] = "";
-  };
-  std::vector<Worker *> workers;
-  explicit EnqueuePool(size_t n) {
-    for (size_t i = 0; i < n; ++i) {
-      Worker *w = new Worker();
-      workers.push_back(w);
-      try {
-        start(w, i);
-      } catch (...) {
-        stop_all();
-        throw;
-      }
-    }
-  }
-  void start(Worker *w, size_t i) {
-      w->th = std::thread([w, i] {
-        std::unique_lock<std::mutex> lk(w->mu);
-        for (;;) {
-          w->cv.wait(lk, [w] { return w->quit || w->job != nullptr; });
-          if (w->quit) return;
-          const std::function<int(size_t)> *job = w->job;
-          lk.unlock();
-          const int rc = (*job)(i);
-          lk.lock();
-          w->rc = rc;
-          if (rc) snprintf(w->err, sizeof(w->err), "%s", g_ferr); // this thread's message, for the caller's thread
-          w->job = nullptr;
-          w->done = true;
-          w->cv.notify_all();
-        }
-      });
-  }
-  void stop_all() {
-    for (Worker *w : workers) {
-      {
-        std::lock_guard<std::mutex> lk(w->mu);
-        w->quit = true;
-      }
-      w->cv.notify_all();
-      if (w->th.joinable()) w->th.join();
-      delete w;
-    }
-    workers.clear();
-  }
-  ~EnqueuePool() { stop_all(); }
-  int run(const std::function<int(size_t)> &job) {
-    for (Worker *w : workers) {
-      std::lock_guard<std::mutex> lk(w->mu);
-      w->job = &job;
-      w->done = false;
-      w->cv.notify_all();
-    }
-    int rc = MGPU_OK;
-    for (Worker *w : workers) {
-      std::unique_lock<std::mutex> lk(w->mu);
-      w->cv.wait(lk, [w] { return w->done; });
-      if (w->rc && !rc) {
-        rc = w->rc;
-        snprintf(g_ferr, sizeof(g_ferr), "%s", w->err);
-      }
-    }
-    return rc;
-  }
 };
 
 namespace {
@@ -522,11 +446,17 @@ int mgpu_frame_create(MgpuScene *const *scenes, const int *devices, int n, int W
     mgpu_frame_destroy(f);
     return rc;
   }
-  if (n >= 2) { // (MgpuFrame::pool; opt-in until it has been measured on hardware: MGPU_FRAME_ENQUEUE_THREADS=1)
+  // (MgpuFrame::pool; opt-in until it has been measured on hardware: MGPU_FRAME_ENQUEUE_THREADS=1.)  Members that share ONE scene
+  // object -- possible under MGPU_FRAME_TRANSPORT=copy, where ranks may share a device -- share its render slots, which the launch
+  // phase rewrites without a lock: such a frame keeps the serial loop.
+  bool scenes_distinct = true;
+  for (int r = 0; r < n; ++r)
+    for (int q = 0; q < r; ++q) scenes_distinct = scenes_distinct && scenes[q] != scenes[r];
+  if (n >= 2 && scenes_distinct) {
     const char *e = getenv("MGPU_FRAME_ENQUEUE_THREADS");
     if (e && atoi(e) != 0) {
       try {
-        f->pool = new EnqueuePool((size_t)n);
+        f->pool = new EnqueuePool((size_t)n, [] { return g_ferr; });
       } catch (...) { // no threads to be had: the caller's thread enqueues for everybody, as without the switch
         f->pool = nullptr;
       }

@@ -4,6 +4,7 @@ agree bit-for-bit with the reference goldens and with the oracle, and compute ca
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -260,3 +261,67 @@ def test_tail_table_scales_with_a_power_of_two_throughput():
                     assert tail(thr, L0, mpl, mul) == thr * unit, (mpl, L0, mul, k)
     # and a throughput that is NOT a power of two does not scale like that in general (the kernel then runs the loop)
     assert any(tail(0.3 * math.ldexp(1.0, -k), 2, 16, True) != 0.3 * math.ldexp(1.0, -k) * tail(1.0, 2, 16, True) for k in range(8))
+
+
+def test_bench_collects_its_own_counter_passes_when_the_committed_ones_are_of_another_build(tmp_path, monkeypatch):
+    """bench.py's roofline must not depend on profiles/pmc_current.json carrying the loaded library's stamp: with a
+    stamp of another build it runs rocprofv3 passes itself.  Here a stand-in `rocprofv3` on PATH writes the CSVs a real pass leaves
+    behind (no GPU in this container); the entry bench.py builds from them must be per frame and carry the traced kernel average."""
+    import importlib
+    fake = tmp_path / "bin" / "rocprofv3"
+    fake.parent.mkdir()
+    fake.write_text('''#!/usr/bin/env python3
+import os, sys
+a = sys.argv[1:]
+d = a[a.index("-d") + 1]; os.makedirs(d, exist_ok=True)
+frames = int(a[-1])
+K = '"void mgpu::k_render_sm<unsigned char, true, 1024, true, true>(mgpu::DScene, mgpu::RenderParams)"'
+if "--pmc" in a:
+    ctrs = a[a.index("--pmc") + 1:a.index("--kernel-include-regex")]
+    with open(os.path.join(d, "p_counter_collection.csv"), "w") as f:
+        f.write('"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size","Kernel_Id","Kernel_Name","Workgroup_Size","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Counter_Name","Counter_Value","Start_Timestamp","End_Timestamp"\\n')
+        for disp in range(frames):
+            for c in ctrs:
+                f.write('%d,%d,"Agent 2",1,1,1,262144,36,%s,1024,3072,8,64,0,112,"%s",%f,0,1\\n' % (disp, disp, K, c, 1000.0 + len(c)))
+else:
+    with open(os.path.join(d, "p_kernel_stats.csv"), "w") as f:
+        f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\\n')
+        f.write('%s,%d,%d,5000000.0,99.0,1,2,0.0\\n' % (K, frames, 5000000 * frames))
+''')
+    fake.chmod(0o755)
+    monkeypatch.setenv("PATH", str(fake.parent) + os.pathsep + os.environ["PATH"])
+    monkeypatch.delenv("MALLIE_BENCH_SELF_PMC", raising=False)
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))  # no profiles/pmc_current.json there; the passes' CSVs land under tmp_path/gpurun_out
+    (tmp_path / "tools").mkdir()
+    import shutil
+    shutil.copy(os.path.join(ROOT, "tools", "pmc_collect.py"), tmp_path / "tools" / "pmc_collect.py")
+    monkeypatch.setitem(bench._SELF_PMC, "entries", {})
+    monkeypatch.setitem(bench._SELF_PMC, "t0", None)
+    monkeypatch.setitem(bench._SELF_PMC, "enabled", True)
+    lib = os.path.join(ROOT, "mallie_amd", "libmallie_mgpu.so")
+    e, why = bench.pmc_for("c2", lib)
+    assert e is not None and "collected by THIS run" in why, why
+    assert e["SQ_INSTS_VALU"] == 1000.0 + len("SQ_INSTS_VALU") and e["launches_per_frame"] == 1.0  # per frame, not per pass
+    assert e["FETCH_SIZE"] == 1010.0 and e["WRITE_SIZE"] == 1010.0 and abs(e["traced_kernel_avg_ms"] - 5.0) < 1e-9
+    assert bench.hbm_bytes(e) == int(2 * 1010 * 1024 + 1010 * 1024)
+    e4, _ = bench.pmc_for("c5", lib)  # an HBM-resident extra: one frame per pass
+    assert e4["FETCH_SIZE"] == 1010.0 and "traced_kernel_avg_ms" not in e4
+    # switched off (how collect_pmc.sh runs bench.py under rocprofv3): nothing is spawned, the reason says so
+    monkeypatch.setitem(bench._SELF_PMC, "entries", {})
+    monkeypatch.setitem(bench._SELF_PMC, "enabled", False)
+    e, why = bench.pmc_for("c2", lib)
+    assert e is None and "switched off" in why
+
+
+def test_enqueue_pool_hands_every_member_its_job_once_plain_and_under_tsan(tmp_path):
+    """mallie_amd/csrc/mgpu_enqueue_pool.hpp (the multi-GPU frame object's launch-phase workers): tests/cpp/pool_driver.cc runs 3 spin
+    windows x 3000 calls x 8 members -- parked and spinning workers, failing members -- built plain and with ThreadSanitizer."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "cpp", "pool_driver.cc")
+    for name, flags in (("pool_plain", ["-O2"]), ("pool_tsan", ["-O1", "-g", "-fsanitize=thread"])):
+        exe = str(tmp_path / name)
+        subprocess.run(["g++", "-std=c++17", "-pthread"] + flags + [src, "-o", exe], check=True, capture_output=True)
+        r = subprocess.run([exe, "stress"], capture_output=True, text=True, timeout=600, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+        assert r.returncode == 0 and "pool stress ok" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr[-3000:]
