@@ -67,7 +67,7 @@ def so_sha256(path):
 
 _SELF_PMC = {"entries": {}, "log": [], "t0": None, "enabled": True}
 # wall-clock budget of the counter passes bench.py runs itself (all workloads together); the headline workload goes first
-SELF_PMC_BUDGET_S = float(os.environ.get("MALLIE_BENCH_SELF_PMC_BUDGET", "420"))
+SELF_PMC_BUDGET_S = float(os.environ.get("MALLIE_BENCH_SELF_PMC_BUDGET", "360"))
 
 
 def self_pmc(workload):
@@ -89,7 +89,7 @@ def self_pmc(workload):
         head = workload == "c2"
         # the headline workload: every pass + a kernel trace; the HBM-resident extras: traffic first, the SQ pass while the budget lasts
         e = pmc_collect.collect(workload, out_dir, frames=3 if workload != "c5" else 1, passes=("sq", "fetch", "write", "sq2") if head else ("fetch", "write", "sq", "sq2"),
-                                trace=head, trace_frames=10, timeout=240, deadline=_SELF_PMC["t0"] + SELF_PMC_BUDGET_S, log=_SELF_PMC["log"])
+                                trace=head, trace_frames=10, timeout=180, deadline=_SELF_PMC["t0"] + SELF_PMC_BUDGET_S, log=_SELF_PMC["log"])
         if e:
             res = (e, "collected by THIS run after its timed region (tools/pmc_collect.py: rocprofv3 --pmc, one process per pass, over "
                       "tools/pmc_workload.py %s; raw CSVs under gpurun_out/self_pmc/): %s" % (workload, "; ".join(l for l in _SELF_PMC["log"] if l.startswith(workload))))

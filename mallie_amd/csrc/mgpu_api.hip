@@ -1480,6 +1480,10 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
     P.hint_q2 = Q * Q;
     P.hint_q = Q * (1.0 + 0x1p-20);
     if (!std::isfinite(P.hint_q2) || !std::isfinite(s->hint_rho + P.hint_q)) P.lds_hint_cap = 0u;
+    // the consultation runs in float (leaf_hint_apply): every origin that may consult lies within Q of c, so |origin| <= |c| + Q must
+    // stay below 2^26 for its slab products to be finite (the boxes' side of that bound is leaf_hint_make's)
+    const double cbig = std::max(std::fabs(P.hint_c[0]), std::max(std::fabs(P.hint_c[1]), std::fabs(P.hint_c[2])));
+    if (!(cbig + P.hint_q < 0x1p26)) P.lds_hint_cap = 0u;
   }
   if (treelet) P.lds_nodes_bytes = (uint32_t)(sizeof(WNode) * s->d.treelet_n); // what the HBM-resident kernel stages into LDS
   if (w5) {

@@ -485,6 +485,10 @@ __device__ __forceinline__ bool leaf_hint_make(TriFn tri, uint32_t n, double wor
     for (int a = 0; a < 3; ++a) {
       rec[6 * part + a] = __double2float_rd(lo[a] - pad);
       rec[6 * part + 3 + a] = __double2float_ru(hi[a] + pad);
+      // leaf_hint_apply multiplies (box coordinate - origin) by 1 / d in FLOAT: with |1 / d| < 2^100 and an origin below 2^26 (the host
+      // gives a launch hints only when |c| + Q is: mgpu_api.hip) a coordinate below 2^26 keeps every product finite.  A padded box that
+      // reaches farther gets no record (an infinite product could turn a hit half into a missed one).
+      if (!(fabsf(rec[6 * part + a]) < 0x1p26f && fabsf(rec[6 * part + 3 + a]) < 0x1p26f)) return false;
     }
     rec[12 + 4 * part + 0] = nb[0];
     rec[12 + 4 * part + 1] = nb[1];
@@ -500,7 +504,9 @@ __device__ __forceinline__ bool leaf_hint_make(TriFn tri, uint32_t n, double wor
 // Evaluated in FLOAT (the boxes are floats; the ray's origin, inverse direction and direction are rounded to nearest, the best t
 // upwards): every float slab product is the exact one of a plane shifted by <= 2^-24 |org| and is off by <= 3.1 x 2^-24 of itself,
 // which the 2^-20 (|c| + 2 reach + |coordinate|) that leaf_hint_make adds to every pad turns into slack on the right side of all three
-// clauses; |1 / d| < 2^100 (part of the ray's permission) keeps the products finite.  Half the issue slots of the double form.
+// clauses; |1 / d| < 2^100 (part of the ray's permission), box coordinates below 2^26 (leaf_hint_make refuses any other record) and
+// origins below 2^26 (|c| + Q is, or the launch has no hints: mgpu_api.hip) keep every product below 2^127, i.e. finite.  Half the issue
+// slots of the double form.
 // (The cone clauses are evaluated for every consulting lane, not only behind a missed box: six float FMAs against a second,
 // dependent trip to LDS in the middle of the step.)
 __device__ __forceinline__ bool slab_hit_f32(float lx, float ly, float lz, float hx, float hy, float hz, float ox, float oy, float oz, float ix,

@@ -468,6 +468,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
               const uint32_t m = __float_as_uint(hp[20]);
               const uint32_t dropped = leaf_hint_apply(f0, f1, f2, cA, cB, m, org, dir, ix, iy, iz, bt, tri_cur, tri_end);
               n_tris += dropped; // the tests the reference makes on the dropped part
+#ifdef MGPU_EMU_STATS // (emulator builds only: how many consultations, how many tests they drop, how many leaves go whole)
+              atomicAdd(&emu_stats[40], 1ull);
+              atomicAdd(&emu_stats[41], (unsigned long long)dropped);
+              if (tri_cur == tri_end) atomicAdd(&emu_stats[42], 1ull);
+              atomicAdd(&emu_stats[43], (unsigned long long)(pathLength == 1 ? 1 : 0));
+              if (pathLength == 1) atomicAdd(&emu_stats[44], (unsigned long long)dropped);
+#endif
 #ifdef MGPU_UTIL
               u_hint_fresh++;
               u_hint_dropped += dropped;

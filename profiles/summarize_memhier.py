@@ -42,8 +42,13 @@ for w, e in sorted(out["workloads"].items()):
         d["l2_hit_rate"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
     if g("TCC_EA0_RDREQ_sum") and g("TCC_EA0_RDREQ_DRAM_sum") is not None:
         d["fabric_reads_to_dram_share"] = g("TCC_EA0_RDREQ_DRAM_sum") / g("TCC_EA0_RDREQ_sum")
-        if g("TCC_EA0_RDREQ_32B_sum") is not None:  # requests are 32 or 64 bytes
-            d["fabric_read_bytes"] = 32.0 * g("TCC_EA0_RDREQ_32B_sum") + 64.0 * (g("TCC_EA0_RDREQ_sum") - g("TCC_EA0_RDREQ_32B_sum"))
+        if g("TCC_EA0_RDREQ_32B_sum") is not None:
+            # The counter tallies a request at 32 or 64 bytes; on gfx950 the requests of wide reads are 128 bytes tallied at 64
+            # (/opt/skills/guides/MI355X_MICROARCH.md, HBM: FETCH_SIZE = TCC_EA0_RDREQ x 64 B reports HALF the bytes; this repo's own
+            # calibration, profiles/pmc_current.json "calibration": x 1.9997 on 1 GiB of 16-byte reads).  `fabric_read_bytes` carries that
+            # factor 2 -- the same quantity as bench.py's 2 x FETCH_SIZE --, the uncorrected tally is kept beside it.
+            d["fabric_read_bytes_as_tallied"] = 32.0 * g("TCC_EA0_RDREQ_32B_sum") + 64.0 * (g("TCC_EA0_RDREQ_sum") - g("TCC_EA0_RDREQ_32B_sum"))
+            d["fabric_read_bytes"] = 2.0 * d["fabric_read_bytes_as_tallied"]
     if g("SQ_WAVE_CYCLES") and g("SQ_WAIT_ANY") is not None:
         d["wave_cycles_waiting"] = g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")
     if g("SQ_INSTS_VMEM_RD") and g("TCP_TOTAL_CACHE_ACCESSES_sum"):

@@ -826,6 +826,7 @@ def test_grey_and_three_channel_kernels_agree(monkeypatch):
     assert imgs[0].tobytes() == imgs[1].tobytes() == oimg.tobytes()
 
 
+@pytest.mark.opt_in_experiment
 @pytest.mark.parametrize("block", ["640", "320"])
 def test_hand_partitioned_five_wave_kernel_equals_the_default(block, monkeypatch):
     """k_render_w5 (mgpu_render_w5.hip; opt-in with MGPU_W5=1): the HBM-resident walk with its state divided by hand between
@@ -1447,7 +1448,9 @@ def test_c_abi_frame_readback_runs_under_the_next_frame(world, in_flight, monkey
     fr.close()
 
 
-@pytest.mark.parametrize("world,mode,threads", [(2, "block", "0"), (3, "strips", "0"), (8, "block", "0"), (8, "strips", "0"), (3, "block", "1"), (8, "block", "1")])
+@pytest.mark.parametrize("world,mode,threads", [(2, "block", "0"), (3, "strips", "0"), (8, "block", "0"), (8, "strips", "0"),
+                                                pytest.param(3, "block", "1", marks=pytest.mark.opt_in_experiment),
+                                                pytest.param(8, "block", "1", marks=pytest.mark.opt_in_experiment)])
 def test_c_abi_frame_with_several_ranks_on_one_gpu(world, mode, threads, monkeypatch):
     """The N > 1 machinery of mgpu_frame_* with N = 2, 3, 8 ranks on the ONE GPU of the test box: MGPU_FRAME_TRANSPORT=copy puts a
     device-to-device copy where every ncclSend / ncclRecv pair would be and lets the ranks share a device; everything else is

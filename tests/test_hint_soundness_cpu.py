@@ -121,3 +121,29 @@ def test_adversarial_family_bites_the_round4_pad_and_not_the_round5_rule():
     assert new_drops == 0, new_drops
     print("family: %d rays, %d accepted by the reference, %d of those outside the round-4 box, %d outside the round-5 box" % (
         total, accepted_total, old_drops, new_drops))
+
+
+def test_device_hint_code_itself_drops_nothing_the_reference_accepts(tmp_path):
+    """tests/cpp/hint_fuzz.cc: the DEVICE's leaf_hint_make / leaf_hint_apply (mallie_amd/csrc/mgpu_device.hpp, compiled for the host
+    through the tests' stand-in hip_runtime.h) against a literal TestLeafNode loop written independently of the kernels, on rays aimed
+    at the determinant guard -- not a Python restatement of the rule (which is what the checks above and the round-5 review's own fuzz
+    exercise).  Control first: the same rays against the round-4 pads must FIND accepted-but-dropped tests, or the fuzz proves nothing."""
+    import os
+    import shutil
+    import subprocess
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cxx = next((c for c in ("/opt/rocm/lib/llvm/bin/clang++", shutil.which("clang++"), shutil.which("g++")) if c and os.path.exists(c)), None)
+    if cxx is None:
+        pytest.skip("no host C++ compiler")
+    exe = str(tmp_path / "hint_fuzz")
+    r = subprocess.run([cxx, "-std=c++17", "-O2", "-ffp-contract=off", "-fno-strict-aliasing", "-pthread", "-DMGPU_EMU", "-I", os.path.join(root, "tests", "emu", "include"),
+                        "-w", "-x", "c++", os.path.join(root, "tests", "cpp", "hint_fuzz.cc"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    threads = str(min(8, len(os.sched_getaffinity(0))))
+    ctl = subprocess.run([exe, "4", threads, "round4"], capture_output=True, text=True, timeout=600)
+    assert ctl.returncode == 0 and "accepted-but-dropped 0," not in ctl.stdout, ctl.stdout
+    run = subprocess.run([exe, "16", threads], capture_output=True, text=True, timeout=900)
+    print(ctl.stdout.strip())
+    print(run.stdout.strip())
+    assert run.returncode == 0 and "accepted-but-dropped 0, results differing 0" in run.stdout, run.stdout
