@@ -78,6 +78,15 @@ def self_pmc(workload):
         return None, "self-collection switched off (MALLIE_BENCH_SELF_PMC=0, --no-extras or N > 1)"
     if workload in _SELF_PMC["entries"]:
         return _SELF_PMC["entries"][workload]
+    try:
+        res = _self_pmc_collect(workload)
+    except Exception as e:  # noqa: BLE001 -- a measurement aid must never take the bench line down
+        res = (None, "collecting the counter passes failed: %r" % (e,))
+    _SELF_PMC["entries"][workload] = res
+    return res
+
+
+def _self_pmc_collect(workload):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_collect
     if pmc_collect.rocprof() is None:
@@ -95,21 +104,20 @@ def self_pmc(workload):
                       "tools/pmc_workload.py %s; raw CSVs under gpurun_out/self_pmc/): %s" % (workload, "; ".join(l for l in _SELF_PMC["log"] if l.startswith(workload))))
         else:
             res = (None, "rocprofv3 passes left nothing to read: %s" % "; ".join(_SELF_PMC["log"][-4:]))
-    _SELF_PMC["entries"][workload] = res
     return res
 
 
 def self_pmc_dump(lib_path):
     """What the self-collected passes gave, in profiles/pmc_current.json's format, under gpurun_out/self_pmc/ (it travels back from the GPU box)."""
-    got = {w: e for w, (e, _) in _SELF_PMC["entries"].items() if e}
-    if not got:
-        return
-    from mallie_amd import build as _b
     try:
+        got = {w: e for w, (e, _) in _SELF_PMC["entries"].items() if e}
+        if not got:
+            return
+        from mallie_amd import build as _b
         with open(os.path.join(ROOT, "gpurun_out", "self_pmc", "pmc_current.json"), "w") as f:
             json.dump({"so_sha256": so_sha256(lib_path), "source_sha256": _b.source_digest(), "tag": "self_pmc", "workloads": got,
                        "log": _SELF_PMC["log"]}, f, indent=1, sort_keys=True)
-    except OSError:
+    except Exception:  # noqa: BLE001 -- a record for the builder, nothing the bench line depends on
         pass
 
 

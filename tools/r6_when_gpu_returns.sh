@@ -1,9 +1,9 @@
 #!/bin/bash
-# ON THE GPU BOX: everything round 5 built while GPU access was closed, in order of importance, each step bounded.
-#   gpurun --timeout 3000 -- 'bash tools/r5_when_gpu_returns.sh r5final'
+# ON THE GPU BOX: everything rounds 5 and 6 built while GPU access was closed, in order of importance, each step bounded.
+#   gpurun --timeout 3000 -- 'bash tools/r6_when_gpu_returns.sh r6final'        (short form: ... r6a short)
 # -> gpurun_out/<tag>/{tests.txt, w5_ab.txt, multi_threads_*.txt, stream.txt, pmc + trace of the final library (profiles/collect_pmc.sh)}
 cd "$GRAFT_REPO_ROOT" || exit 1
-tag=${1:-r5final}; out=gpurun_out/$tag; mkdir -p $out
+tag=${1:-r6final}; out=gpurun_out/$tag; mkdir -p $out
 short=${2:-}   # "short": tests, the W5 A/B on C4 / C3, the enqueue threads, the stream, a plain bench line (about 15 minutes)
 echo "== 1. GPU suite"; timeout 900 python -m pytest tests -m gpu -q > $out/tests.txt 2>&1; echo "rc=$?"; grep -E "passed|failed|parity" $out/tests.txt | tail -3
 echo "== 2. k_render_w5 beside k_render_sm"; timeout 900 bash tools/w5_ab.sh c4 c3 $([ -z "$short" ] && echo c5) > $out/w5_ab.txt 2>&1; cat $out/w5_ab.txt | cut -c1-220
@@ -12,7 +12,7 @@ for lib in mallie_amd/ab/w5_*.so; do for c in c4 c3; do echo "$(basename $lib .s
 echo "== 3. eight ranks in one process: enqueue cost with and without a thread per member"
 for th in 0 1; do MGPU_FRAME_ENQUEUE_THREADS=$th timeout 600 bash tools/perf_multi_one_gpu.sh $tag/multi_th$th > $out/multi_threads_$th.txt 2>&1; grep "ranks 8" $out/multi_threads_$th.txt | cut -c1-260; done
 echo "== 4. the reference's stream: does it settle"; timeout 300 python tools/perf_stream.py > $out/stream.txt 2>&1; tail -6 $out/stream.txt | cut -c1-220
-if [ -n "$short" ]; then echo "== 5. bench line"; timeout 600 python bench.py > $out/bench_full.log 2>&1; grep -h "^{" $out/bench_full.log | tail -1 > $out/bench_full.json
+if [ -n "$short" ]; then echo "== 5. bench line (collects its own counter passes: profiles/pmc_current.json is of another build)"; timeout 1200 python bench.py > $out/bench_full.log 2>&1; cp -r gpurun_out/self_pmc $out/ 2>/dev/null; grep -h "^{" $out/bench_full.log | tail -1 > $out/bench_full.json
 else echo "== 5. trace, counters and the bench line of the final library"; timeout 1500 bash profiles/collect_pmc.sh $tag c2 c3 c4 c5 > $out/collect.log 2>&1; tail -3 $out/collect.log; fi
 python - $out/bench_full.json <<'PY'
 import json, sys
