@@ -190,3 +190,35 @@ def test_five_wave_kernel_on_a_deep_tree(monkeypatch):
     osc = O.OracleScene(verts, faces, None, None, None, nodes, idx)
     oimg, _, ost, _ = osc.render(frame, W, H, 6, 2, None, O.RNG_HASH, seed=3)
     assert img.tobytes() == oimg.tobytes() and ost["nodes"] == s5["nodes"] and ost["tris"] == s5["tris"]
+
+
+def test_five_wave_kernel_shares_a_render_slot_with_the_default_kernel(monkeypatch):
+    """k_render_sm and k_render_w5 share a scene's render slot and its overflow columns with DIFFERENT column pitches (depth - 8 and
+    depth - 5 entries per lane).  Round 5 remembered the buffer's capacity in lanes: a k_render_sm launch (here: a path length above
+    k_render_w5's 255 makes the call fall back) sized it, and a later k_render_w5 launch with fewer lanes but the wider pitch wrote past
+    it -- for trees 9 to 12 deep only (advisor, round 5).  A line of 4 096 triangles seen end-on (tree depth 11, every box on the way is
+    hit, the stacks fill) does it: under the emulator's ASan build the round-5 library reports a heap-buffer-overflow in
+    WStackP<5>::put here (profiles/r6_w5_slot_sharing_asan.txt), this one does not; in this plain run the frames must be k_render_sm's."""
+    monkeypatch.setenv("MGPU_RENDER_KERNEL", "sm")
+    rng = np.random.default_rng(1)
+    V, F = [], []
+    for k in range(4096):
+        z, j = -0.5 * k, rng.normal(size=3) * 0.05
+        V += [[-0.4 + j[1], -0.4, z + j[0]], [0.4, -0.3 + j[2], z], [-0.3, 0.4, z]]
+        F.append([3 * k, 3 * k + 1, 3 * k + 2])
+    verts, faces = np.array(V, np.float64), np.array(F, "u4")
+    nodes, idx, st = M.bvh_build(verts, faces, minLeaf=4)
+    assert 9 <= st["maxTreeDepth"] <= 12, st
+    W, H = 80, 8
+    frame = M.camera_frame((0.0, 0.0, 5.0), (0.0, 0.0, -10.0), width=W, height=H, fov=1.0)
+    monkeypatch.setenv("MGPU_W5", "0")
+    ref = M.Scene(verts, faces, None, None, None, nodes, idx)
+    rlong = ref.render(frame, W, H, 300, 1, None, M.RNG_HASH, seed=5)
+    rimg, rcnt, rst = ref.render(frame, W, H, 4, 4, None, M.RNG_HASH, seed=3)
+    assert rst["nodes"] > 15 * rst["real_rays"]  # the walks are deep
+    monkeypatch.setenv("MGPU_W5", "1")
+    sc = M.Scene(verts, faces, None, None, None, nodes, idx)
+    long_img, _, long_st = sc.render(frame, W, H, 300, 1, None, M.RNG_HASH, seed=5)  # falls back to k_render_sm: sizes the slot's columns
+    img, cnt, s5 = sc.render(frame, W, H, 4, 4, None, M.RNG_HASH, seed=3)            # k_render_w5: fewer lanes, wider pitch
+    assert long_img.tobytes() == rlong[0].tobytes() and long_st["nodes"] == rlong[2]["nodes"]
+    assert img.tobytes() == rimg.tobytes() and all(s5[f] == rst[f] for f in FIELDS + ("paths",)), (s5, rst)
