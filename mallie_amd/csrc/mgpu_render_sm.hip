@@ -374,6 +374,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
       const bool all_plain = __ballot(st == ST_NODE && !ray_plain) == 0ull; // wave-uniform
       const bool occ_sample = occ_sampled();
       const uint32_t occ_n0 = MGPU_OCC ? n_nodes : 0u;
+#ifdef MGPU_EMU_STATS
+      const uint32_t emu_n0 = n_nodes;
+      const bool st_was_node = st == ST_NODE;
+#endif
       if (st == ST_NODE) {
         const bool sx = (sgn & 1u) != 0u, sy = (sgn & 2u) != 0u, sz = (sgn & 4u) != 0u;
 #ifdef MGPU_UTIL
@@ -445,6 +449,22 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
       }
       if (occ_sample) occ_book(LDS_SCENE ? n_nodes - occ_n0 : (n_nodes - occ_n0) >> 1, LDS_SCENE ? MGPU_NODES_PER_STEP : MGPU_WIDE_PER_STEP,
                                0);
+#ifdef MGPU_EMU_STATS // (emulator builds only: NODE steps, the wave's trips of the repetition loop, lane-trips)
+      {
+        const uint32_t reps = (st_was_node ? (LDS_SCENE ? n_nodes - emu_n0 : (n_nodes - emu_n0 + 1u) >> 1) : 0u);
+        uint32_t mx = reps, sum = reps;
+        for (int x = 1; x < 64; x <<= 1) {
+          mx = max(mx, (uint32_t)__shfl_xor((int)mx, x));
+          sum += (uint32_t)__shfl_xor((int)sum, x);
+        }
+        if (lane == 0) {
+          atomicAdd(&emu_stats[45], 1ull);
+          atomicAdd(&emu_stats[46], (unsigned long long)mx);
+          atomicAdd(&emu_stats[47], (unsigned long long)sum);
+          atomicAdd(&emu_stats[48], (unsigned long long)cN);
+        }
+      }
+#endif
 #ifdef MGPU_UTIL
       if (cyc_dry) ++steps_n;
 #endif
@@ -615,6 +635,18 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
       // Three parts: (1) lanes in SHADE finish their ray; (2) ALL lanes of the wave run the pixel hand-out so the
       // work cursor stays wave-uniform; (3) lanes in SHADE start their next path / arm their next traversal.
       const bool shade_lane = (st == ST_SHADE);
+#ifdef MGPU_EMU_STATS // (emulator builds only: SHADE steps, their lanes, and how often each sub-body has a lane: miss tail, bounce, path start, arming)
+      {
+        const bool fin = shade_lane && have_ray;
+        const bool hit_now = fin && bt < kDblMax;
+        if (lane == 0) {
+          atomicAdd(&emu_stats[50], 1ull);
+          atomicAdd(&emu_stats[51], (unsigned long long)cS);
+          atomicAdd(&emu_stats[52], (unsigned long long)cReal);
+        }
+        (void)hit_now;
+      }
+#endif
 #if MGPU_OCC
       if (occ_sampled() && lane == 0) {
         atomicAdd(&s_occ[4], 1u);
@@ -671,6 +703,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
           // PathTrace adds to the radiance only on a miss (render.cc:409-418), and the first miss ends the path here (its
           // continuation is evaluated in closed loop): the radiance lives in this step only, not in registers between steps
           double rad0 = 0.0, rad1 = 0.0, rad2 = 0.0;
+#ifdef MGPU_EMU_STATS
+          atomicAdd(&emu_stats[53], 1ull);                                                    // rays finished
+          if (!hit) atomicAdd(&emu_stats[pathLength < 2 ? 54 : 55], 1ull);                   // primary misses / misses with a tail
+          else if (pathLength < P.maxPathLength) atomicAdd(&emu_stats[56], 1ull);            // bounces
+#endif
           if (!hit) {
             path_done = true;
             if (pathLength < 2) {
@@ -816,6 +853,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
         if (!want || exhausted || defer) break;
         if (in_item >= 64) { // current item used up: take the next one from the workgroup's cursor
           uint32_t cur_shard = 0, item_local = 0;
+#ifdef MGPU_EMU_STATS
+          if (lane == 0) atomicAdd(&emu_stats[58], 1ull); // items taken (attempts included)
+#endif
           for (;;) {
             unsigned long long c = 0;
             if (lane == 0) c = atomicAdd(&wg_cursor, 1ull);
@@ -932,6 +972,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
       if (shade_lane) {
         if (path_done && have_path) {
           have_path = false;
+#ifdef MGPU_EMU_STATS
+          atomicAdd(&emu_stats[57], 1ull); // paths started
+#endif
 #ifdef MGPU_UTIL
           if (lane == __ffsll((long long)__ballot(1)) - 1) u_start_steps++;
 #endif
