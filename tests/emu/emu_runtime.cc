@@ -7,6 +7,7 @@
 // split over different operations, a barrier some wave never reaches) aborts the process with a description: such code would hang or
 // misbehave on the GPU too, or relies on divergent cross-lane semantics the emulator does not model (see MGPU_ANY in mgpu_device.hpp).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <sys/mman.h>
 
@@ -556,6 +557,22 @@ void launch(const char *name, dim3 grid, dim3 block, size_t shmem, const std::fu
     std::lock_guard<std::mutex> lock(g_launch_mutex); // one kernel at a time: the static LDS section is the process's
     run_resident(kname.c_str(), grid, block, shmem, owned);
   });
+}
+
+} // namespace emu
+namespace isa {
+bool run(const char *mangled, dim3 grid, dim3 block, size_t shmem, const void *kernarg, size_t kernarg_bytes);
+}
+namespace emu {
+bool launch_isa(const void *fn, dim3 grid, dim3 block, size_t shmem, const void *kernarg, size_t kernarg_bytes) {
+  Dl_info info;
+  if (!dladdr(fn, &info) || !info.dli_sname) return false;
+  if (is_resident(info.dli_sname)) return false; // resident kernels run beside the host on a thread of their own: the C++ path's business
+  static const bool trace = getenv("MGPU_EMU_TRACE") != nullptr;
+  std::lock_guard<std::mutex> lock(g_launch_mutex); // one kernel at a time, like the C++ path
+  const bool ran = isa::run(info.dli_sname, grid, block, shmem, kernarg, kernarg_bytes);
+  if (trace) fprintf(stderr, "emu: %s %s grid %u block %u, dynamic LDS %zu\n", ran ? "ISA launch of" : "no ISA for", info.dli_sname, grid.x, block.x, shmem);
+  return ran;
 }
 
 void wait_resident() {

@@ -77,6 +77,33 @@ unsigned long long clock_ticks();
 void launch(const char *name, dim3 grid, dim3 block, size_t shmem, const std::function<void()> &lane_entry,
             const std::function<std::function<void()>()> &owning_copy);
 void wait_resident(); // joins resident kernels that have left or are leaving (stream / device synchronisation)
+// MGPU_EMU_ISA=<hipcc -S dump>[:...] (tests/emu/isa_interp.cc): a launch whose kernel is found in one of the dumps executes the gfx950
+// INSTRUCTION STREAM hipcc made of it instead of the host-compiled C++ -- `fn` = the kernel (its symbol is the device kernel's name),
+// `kernarg` = its arguments laid out as the kernel-argument segment.  Returns false when the kernel is not in a dump (or the switch is off).
+bool launch_isa(const void *fn, dim3 grid, dim3 block, size_t shmem, const void *kernarg, size_t kernarg_bytes);
+struct ArgPack {
+  unsigned char bytes[4096];
+  size_t size = 0;
+  template <typename T> void put(const T &v) {
+    size = (size + alignof(T) - 1) / alignof(T) * alignof(T);
+    if (size + sizeof(T) > sizeof(bytes)) abort();
+    memcpy(bytes + size, &v, sizeof(T));
+    size += sizeof(T);
+  }
+};
+// the arguments converted to the kernel's PARAMETER types, packed with their natural alignment (= the kernel-argument segment's layout)
+template <typename... P, typename... A> ArgPack pack_args(void (*)(P...), const A &...a) {
+  ArgPack p;
+  memset(p.bytes, 0, sizeof(p.bytes));
+  (p.put<P>(static_cast<P>(a)), ...);
+  return p;
+}
+template <typename... P, typename... A> bool try_isa(void (*k)(P...), dim3 grid, dim3 block, size_t shmem, const A &...a) {
+  static const bool on = getenv("MGPU_EMU_ISA") != nullptr;
+  if (!on) return false;
+  const ArgPack p = pack_args(k, a...);
+  return launch_isa(reinterpret_cast<const void *>(k), grid, block, shmem, p.bytes, p.size);
+}
 } // namespace emu
 
 #define threadIdx (emu::g_cur->thread_idx)
@@ -240,5 +267,7 @@ hipError_t hipFuncSetAttribute(const void *f, hipFuncAttribute a, int v);
 
 // the kernel's name is not allowed to contain a top-level comma (the library's launch sites bind template-ids to a variable first)
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
-  emu::launch(#kern, dim3(grid), dim3(block), (size_t)(shmem), [&]() { kern(__VA_ARGS__); }, \
-              [&]() { return std::function<void()>([=]() mutable { kern(__VA_ARGS__); }); })
+  (emu::try_isa(kern, dim3(grid), dim3(block), (size_t)(shmem), __VA_ARGS__) \
+       ? (void)0 \
+       : emu::launch(#kern, dim3(grid), dim3(block), (size_t)(shmem), [&]() { kern(__VA_ARGS__); }, \
+                     [&]() { return std::function<void()>([=]() mutable { kern(__VA_ARGS__); }); }))
