@@ -222,3 +222,28 @@ def test_five_wave_kernel_shares_a_render_slot_with_the_default_kernel(monkeypat
     img, cnt, s5 = sc.render(frame, W, H, 4, 4, None, M.RNG_HASH, seed=3)            # k_render_w5: fewer lanes, wider pitch
     assert long_img.tobytes() == rlong[0].tobytes() and long_st["nodes"] == rlong[2]["nodes"]
     assert img.tobytes() == rimg.tobytes() and all(s5[f] == rst[f] for f in FIELDS + ("paths",)), (s5, rst)
+
+
+def test_kernels_ran_from_their_gfx950_machine_code():
+    """With MGPU_EMU_ISA=<hipcc -S dumps> (tests/emu/isa_interp.cc) the launches of the cases above executed hipcc's gfx950 INSTRUCTION STREAMS,
+    not the host-compiled C++: the render kernel again, counted -- its frame is the oracle's and the interpreter's instruction counters moved by
+    what a frame of that size costs (30 .. 80 VALU wave-instructions per ray at this size; 35 on a full frame, like the hardware's counter)."""
+    import ctypes
+    if not os.environ.get("MGPU_EMU_ISA"):
+        pytest.skip("MGPU_EMU_ISA is not set: the kernels ran as host-compiled C++")
+    L = ctypes.CDLL(os.environ["MALLIE_MGPU_LIB"])
+    cnt = (ctypes.c_ulonglong * 16).in_dll(L, "isa_counters")
+    g = O.load_golden("cornell_obj")
+    sc = M.Scene(g["verts"], g["faces"], g["matIDs"], g["normals"], None)
+    osc = O.scene_from_golden("cornell_obj")
+    W, H = 96, 64
+    frame = M.camera_frame((0, 0, 20), (0, 0, 0), width=W, height=H)
+    before = [int(x) for x in cnt]
+    img, _, st = sc.render(frame, W, H, 5, 3, sc.plane(), M.RNG_HASH, seed=7)
+    after = [int(x) for x in cnt]
+    oimg, _, ost, _ = osc.render(frame, W, H, 5, 3, osc.plane(), O.RNG_HASH, seed=7)
+    assert img.tobytes() == oimg.tobytes() and (st["nodes"], st["tris"]) == (ost["nodes"], ost["tris"])
+    valu, salu, launches = after[0] - before[0], after[1] - before[1], after[8] - before[8]
+    assert launches >= 2, "the render launch did not go through the ISA interpreter"
+    assert 30.0 < valu / st["real_rays"] < 80.0 and 0.4 < salu / valu < 0.7, (valu, salu, st["real_rays"])
+    sc.close()

@@ -39,3 +39,31 @@ def test_the_product_refuses_the_emulator_build():
     for path in paths:
         txt = open(os.path.join(ROOT, path)).read()
         assert "tests/emu" not in txt and "mgpu_emu" not in txt and "ALLOW_EMULATOR" not in txt, path
+
+
+def test_kernels_run_from_hipcc_gfx950_machine_code_match_the_oracle(tmp_path):
+    """tests/emu/isa_interp.cc: the emulator executes the gfx950 instruction streams `hipcc -S` makes of the kernels (render, five-wave
+    render, batched trace, accumulate, tile order, scene layout) instead of their host-compiled C++ -- what the COMPILER made, OCML's inlined
+    division / sqrt sequences, ds_bpermute shuffles and spills included -- and every case of tests/emu/cases_emu.py still equals the oracle."""
+    if not os.path.isfile(os.path.join(ROOT, "tests", "emu", "build_emu.py")):
+        pytest.skip("tests/emu is not on this box")
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.isfile(hipcc):
+        pytest.skip("no hipcc here")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    lib = build_emu.build()
+    dumps, procs = [], []
+    for src in ("mgpu_render_sm.hip", "mgpu_kernels.hip", "mgpu_render_w5.hip", "mgpu_trace_sm.hip"):
+        out = str(tmp_path / src.replace(".hip", ".s"))
+        dumps.append(out)
+        procs.append(subprocess.Popen([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only",
+                                       os.path.join(ROOT, "mallie_amd", "csrc", src), "-o", out], stderr=subprocess.DEVNULL))
+    assert all(p.wait() == 0 for p in procs)
+    env = dict(os.environ, MALLIE_MGPU_LIB=lib, MALLIE_ALLOW_EMULATOR="1", MALLIE_NO_TORCH="1", MGPU_EMU_ISA=":".join(dumps))
+    for k in [k for k in env if k.startswith("MGPU_") and k != "MGPU_EMU_ISA"]:
+        del env[k]
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "emu", "cases_emu.py"), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "render_kernels or five_wave or batched_trace or gfx950"],
+                       env=env, capture_output=True, text=True, cwd=ROOT, timeout=1500)
+    assert r.returncode == 0 and " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], r.stdout[-4000:] + r.stderr[-2000:]
