@@ -375,7 +375,8 @@ template <int CAP, bool OVF = true> struct Stack {
 // the whole run), and |d| <= 1 + 2^-10, which holds for every ray the kernel makes when the scene's shading normals are no longer
 // than 1 + 2^-11 (checked when the scene is created; else the scene gets no hints): reach = (Q + rho_s)(1 + 2^-9).
 // tri(k) -> pointer to the 9 doubles p0, e1, e2 of the run's k-th triangle.  rec: kHintFloats floats = box A lo / hi, box B lo / hi
-// (12), cone A (nbar, thr), cone B, m as bits, 3 unused.  Returns false when the best split saves less than (1 - worth) of the
+// (12), cone A (nbar, thr), cone B, m as bits, 3 unused (the order leaf_hint_make writes; leaf_hint_pack interleaves the boxes for the
+// consultation).  Returns false when the best split saves less than (1 - worth) of the
 // expected tests (then it is not worth its two box tests).
 constexpr int kHintFloats = 24;
 #ifndef MGPU_HINT_CONE_MAX
@@ -509,23 +510,46 @@ __device__ __forceinline__ bool leaf_hint_make(TriFn tri, uint32_t n, double wor
 // slots of the double form.
 // (The cone clauses are evaluated for every consulting lane, not only behind a missed box: six float FMAs against a second,
 // dependent trip to LDS in the middle of the step.)
-__device__ __forceinline__ bool slab_hit_f32(float lx, float ly, float lz, float hx, float hy, float hz, float ox, float oy, float oz, float ix,
-                                             float iy, float iz, float bt_up) {
-  const float ax = (lx - ox) * ix, bx = (hx - ox) * ix, ay = (ly - oy) * iy, by = (hy - oy) * iy, az = (lz - oz) * iz, bz = (hz - oz) * iz;
-  const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
-  const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
-  return (tmax > 0.0f) && (tmin <= tmax) && (tmin <= bt_up);
+// Both boxes at once: the record's first twelve floats are stored INTERLEAVED -- (A.lo.x, B.lo.x), (A.lo.y, B.lo.y), (A.lo.z, B.lo.z),
+// (A.hi.x, B.hi.x), ... (leaf_hint_pack) -- so that the six subtractions and six multiplications of the two slab tests are six v_pk_add_f32 and
+// six v_pk_mul_f32 on the pairs as they were loaded (the origin and 1 / d broadcast by op_sel): the same IEEE operations on the same operands as
+// the one-box form, half the instructions (tools/isa_profile.py: -0.3 VALU wave-instructions per ray on C2).
+typedef float mgpu_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void leaf_hint_pack(const float *rec, float *out) {
+  for (int a = 0; a < 3; ++a) {
+    out[2 * a] = rec[a];              // A.lo
+    out[2 * a + 1] = rec[6 + a];      // B.lo
+    out[6 + 2 * a] = rec[3 + a];      // A.hi
+    out[6 + 2 * a + 1] = rec[9 + a];  // B.hi
+  }
+  for (int a = 0; a < 4; ++a) { // the cones likewise: (nbar_A.x, nbar_B.x), (.y, .y), (.z, .z), (thr_A, thr_B)
+    out[12 + 2 * a] = rec[12 + a];
+    out[12 + 2 * a + 1] = rec[16 + a];
+  }
+  for (int k = 20; k < kHintFloats; ++k) out[k] = rec[k];
 }
 __device__ __forceinline__ uint32_t leaf_hint_apply(float4 f0, float4 f1, float4 f2, float4 cA, float4 cB, uint32_t m, V3 org, V3 dir, double ix,
                                                     double iy, double iz, double bt, uint32_t &tri_cur, uint32_t &tri_end) {
   const float dx = (float)dir.x, dy = (float)dir.y, dz = (float)dir.z;
   const float ox = (float)org.x, oy = (float)org.y, oz = (float)org.z, jx = (float)ix, jy = (float)iy, jz = (float)iz;
   const float bt_up = __double2float_ru(bt);
+  // cA = (nbar_A.x, nbar_B.x, nbar_A.y, nbar_B.y), cB = (nbar_A.z, nbar_B.z, thr_A, thr_B): d . nbar of both halves in three packed operations
   // (NaN compares false: the half counts as grazed and stays)
-  const bool sA = fabsf(__builtin_fmaf(dx, cA.x, __builtin_fmaf(dy, cA.y, dz * cA.z))) >= cA.w;
-  const bool sB = fabsf(__builtin_fmaf(dx, cB.x, __builtin_fmaf(dy, cB.y, dz * cB.z))) >= cB.w;
-  const bool hA = !sA || slab_hit_f32(f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, ox, oy, oz, jx, jy, jz, bt_up);
-  const bool hB = !sB || slab_hit_f32(f1.z, f1.w, f2.x, f2.y, f2.z, f2.w, ox, oy, oz, jx, jy, jz, bt_up);
+  const mgpu_f2 nx = {cA.x, cA.y}, ny = {cA.z, cA.w}, nz = {cB.x, cB.y};
+  const mgpu_f2 dn = __builtin_elementwise_fma(nx, (mgpu_f2){dx, dx}, __builtin_elementwise_fma(ny, (mgpu_f2){dy, dy}, nz * dz));
+  const bool sA = fabsf(dn[0]) >= cB.z;
+  const bool sB = fabsf(dn[1]) >= cB.w;
+  // f0 = (A.lo.x, B.lo.x, A.lo.y, B.lo.y), f1 = (A.lo.z, B.lo.z, A.hi.x, B.hi.x), f2 = (A.hi.y, B.hi.y, A.hi.z, B.hi.z)
+  const mgpu_f2 lx = {f0.x, f0.y}, ly = {f0.z, f0.w}, lz = {f1.x, f1.y}, hx = {f1.z, f1.w}, hy = {f2.x, f2.y}, hz = {f2.z, f2.w};
+  const mgpu_f2 ax = (lx - ox) * jx, bx = (hx - ox) * jx, ay = (ly - oy) * jy, by = (hy - oy) * jy, az = (lz - oz) * jz, bz = (hz - oz) * jz;
+  bool hit[2];
+  for (int k = 0; k < 2; ++k) {
+    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax[k], bx[k]), __builtin_fminf(ay[k], by[k])), __builtin_fminf(az[k], bz[k]));
+    const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax[k], bx[k]), __builtin_fmaxf(ay[k], by[k])), __builtin_fmaxf(az[k], bz[k]));
+    hit[k] = (tmax > 0.0f) && (tmin <= tmax) && (tmin <= bt_up);
+  }
+  const bool hA = !sA || hit[0];
+  const bool hB = !sB || hit[1];
   const uint32_t whole = tri_end - tri_cur, mid = tri_cur + m;
   if (!hB) tri_end = mid;
   if (!hA) tri_cur = hB ? mid : tri_end;

@@ -232,8 +232,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
                            (double)MGPU_HINT_WORTH, P.hint_c, P.hint_q, rec)) {
           const uint32_t h = atomicAdd(&s_nhints, 1u);
           if (h < P.lds_hint_cap) {
-            float *dst = reinterpret_cast<float *>(lds_hints + (size_t)h * (kHintFloats * 4));
-            for (int k = 0; k < kHintFloats; ++k) dst[k] = rec[k];
+            leaf_hint_pack(rec, reinterpret_cast<float *>(lds_hints + (size_t)h * (kHintFloats * 4)));
             code = (h + 1u) << 16;
           }
         }

@@ -166,8 +166,10 @@ void worker(unsigned seed, unsigned long long n_rays, Totals &T) {
     bigpad += (rec[15] == 0.0f) + (rec[19] == 0.0f);
     uint32_t m;
     std::memcpy(&m, &rec[20], 4);
-    const float4 f0 = make_float4(rec[0], rec[1], rec[2], rec[3]), f1 = make_float4(rec[4], rec[5], rec[6], rec[7]), f2 = make_float4(rec[8], rec[9], rec[10], rec[11]),
-                 cA = make_float4(rec[12], rec[13], rec[14], rec[15]), cB = make_float4(rec[16], rec[17], rec[18], rec[19]);
+    float pk[mgpu::kHintFloats];
+    mgpu::leaf_hint_pack(rec, pk); // the layout the kernel keeps in LDS
+    const float4 f0 = make_float4(pk[0], pk[1], pk[2], pk[3]), f1 = make_float4(pk[4], pk[5], pk[6], pk[7]), f2 = make_float4(pk[8], pk[9], pk[10], pk[11]),
+                 cA = make_float4(pk[12], pk[13], pk[14], pk[15]), cB = make_float4(pk[16], pk[17], pk[18], pk[19]);
     // ---- rays at this leaf ----
     for (int r = 0; r < 256; ++r, ++rays) {
       const Tri &tt = run[g() % n];
