@@ -8,6 +8,8 @@
 // misbehave on the GPU too, or relies on divergent cross-lane semantics the emulator does not model (see MGPU_ANY in mgpu_device.hpp).
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <elf.h>
+#include <map>
 
 #include <sys/mman.h>
 
@@ -564,9 +566,47 @@ namespace isa {
 bool run(const char *mangled, dim3 grid, dim3 block, size_t shmem, const void *kernarg, size_t kernarg_bytes);
 }
 namespace emu {
+// name of a function with INTERNAL linkage (kernels in an anonymous namespace are not in the dynamic symbol table dladdr reads): from the
+// library file's own .symtab
+static const char *local_symbol_name(const Dl_info &info, const void *fn) {
+  static std::mutex mu;
+  static std::map<std::string, std::map<uintptr_t, std::string>> tables;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!info.dli_fname) return nullptr;
+  auto it = tables.find(info.dli_fname);
+  if (it == tables.end()) {
+    std::map<uintptr_t, std::string> tab;
+    FILE *f = fopen(info.dli_fname, "rb");
+    if (f) {
+      std::vector<unsigned char> img;
+      fseek(f, 0, SEEK_END);
+      const long n = ftell(f);
+      fseek(f, 0, SEEK_SET);
+      img.resize(n > 0 ? (size_t)n : 0);
+      if (n > 0 && fread(img.data(), 1, (size_t)n, f) == (size_t)n && n > (long)sizeof(Elf64_Ehdr)) {
+        const Elf64_Ehdr *eh = reinterpret_cast<const Elf64_Ehdr *>(img.data());
+        const Elf64_Shdr *sh = reinterpret_cast<const Elf64_Shdr *>(img.data() + eh->e_shoff);
+        for (int i = 0; i < eh->e_shnum; ++i)
+          if (sh[i].sh_type == SHT_SYMTAB) {
+            const Elf64_Sym *sym = reinterpret_cast<const Elf64_Sym *>(img.data() + sh[i].sh_offset);
+            const char *str = reinterpret_cast<const char *>(img.data() + sh[sh[i].sh_link].sh_offset);
+            for (size_t k = 0; k < sh[i].sh_size / sizeof(Elf64_Sym); ++k)
+              if (ELF64_ST_TYPE(sym[k].st_info) == STT_FUNC && sym[k].st_value) tab[(uintptr_t)sym[k].st_value] = str + sym[k].st_name;
+          }
+      }
+      fclose(f);
+    }
+    it = tables.emplace(info.dli_fname, std::move(tab)).first;
+  }
+  auto jt = it->second.find((uintptr_t)fn - (uintptr_t)info.dli_fbase);
+  return jt == it->second.end() ? nullptr : jt->second.c_str();
+}
+
 bool launch_isa(const void *fn, dim3 grid, dim3 block, size_t shmem, const void *kernarg, size_t kernarg_bytes) {
   Dl_info info;
-  if (!dladdr(fn, &info) || !info.dli_sname) return false;
+  if (!dladdr(fn, &info)) return false;
+  if (!info.dli_sname) info.dli_sname = local_symbol_name(info, fn);
+  if (!info.dli_sname) return false;
   if (is_resident(info.dli_sname)) return false; // resident kernels run beside the host on a thread of their own: the C++ path's business
   static const bool trace = getenv("MGPU_EMU_TRACE") != nullptr;
   std::lock_guard<std::mutex> lock(g_launch_mutex); // one kernel at a time, like the C++ path

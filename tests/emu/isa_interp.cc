@@ -208,7 +208,7 @@ static inline uint8_t *lds_ptr(Machine &M, uint32_t a, size_t bytes, const Inst 
 
 // ---------------------------------------------------------------------------------------------------------------- handlers
 // sub codes for typed families
-enum { T_F64, T_F32, T_I32, T_U32, T_U64, T_I64, T_U16 };
+enum { T_F64, T_F32, T_I32, T_U32, T_U64, T_I64, T_U16, T_I16 };
 enum { P_F, P_LT, P_EQ, P_LE, P_GT, P_LG, P_GE, P_O, P_U, P_NGE, P_NLG, P_NGT, P_NLE, P_NEQ, P_NLT, P_T, P_NE /*int*/ };
 
 template <typename T> static inline bool cmp_pred(int p, T a, T b) {
@@ -244,6 +244,7 @@ static void x_vcmp(Machine &, Wave &w, const Inst &in) {
     case T_I32: r = cmp_pred<int32_t>(p, (int32_t)src32(w, in.o[1], lane), (int32_t)src32(w, in.o[2], lane)); break;
     case T_U32: r = cmp_pred<uint32_t>(p, src32(w, in.o[1], lane), src32(w, in.o[2], lane)); break;
     case T_U16: r = cmp_pred<uint32_t>(p, src32(w, in.o[1], lane) & 0xFFFFu, src32(w, in.o[2], lane) & 0xFFFFu); break;
+    case T_I16: r = cmp_pred<int32_t>(p, (int32_t)(int16_t)src32(w, in.o[1], lane), (int32_t)(int16_t)src32(w, in.o[2], lane)); break;
     case T_U64: r = cmp_pred<uint64_t>(p, src64(w, in.o[1], lane), src64(w, in.o[2], lane)); break;
     case T_I64: r = cmp_pred<int64_t>(p, (int64_t)src64(w, in.o[1], lane), (int64_t)src64(w, in.o[2], lane)); break;
     }
@@ -715,7 +716,7 @@ static void x_readfirstlane(Machine &, Wave &w, const Inst &in) {
 enum {
   S_MOV32, S_MOV64, S_MOVK, S_ADD_I32, S_ADDK, S_SUB_I32, S_MUL_I32, S_MUL_HI_U32, S_AND32, S_AND64, S_OR32, S_OR64, S_XOR32, S_XOR64, S_ANDN2_64, S_ORN2_64, S_ANDN2_32, S_NOT64,
   S_LSHL32, S_LSHL64, S_LSHR32, S_LSHR64, S_ASHR32, S_BFM32, S_BREV32, S_BCNT1_64, S_BCNT1_32, S_MIN_U32, S_MAX_U32, S_MIN_I32, S_MAX_I32, S_CSELECT32, S_CSELECT64, S_AND_SAVEEXEC, S_OR_SAVEEXEC,
-  S_ANDN2_SAVEEXEC, S_GETREG, S_FF1_64, S_FF1_32, S_ADD_U32, S_SUB_U32, S_ADDC_U32, S_SUBB_U32, S_BFE_U32, S_ABS_I32, S_SEXT_I32_I16, S_NOT32, S_XNOR64, S_NAND64, S_NOR64, S_MUL_HI_I32, S_MEMTIME, S_BFE_I64, S_BFE_I32, S_MULK, S_BFE_U64
+  S_ANDN2_SAVEEXEC, S_GETREG, S_FF1_64, S_FF1_32, S_ADD_U32, S_SUB_U32, S_ADDC_U32, S_SUBB_U32, S_BFE_U32, S_ABS_I32, S_SEXT_I32_I16, S_NOT32, S_XNOR64, S_NAND64, S_NOR64, S_MUL_HI_I32, S_MEMTIME, S_BFE_I64, S_BFE_I32, S_MULK, S_BFE_U64, S_GETPC
 };
 static void x_salu(Machine &M, Wave &w, const Inst &in) {
   const Operand *o = in.o;
@@ -815,6 +816,7 @@ static void x_salu(Machine &M, Wave &w, const Inst &in) {
     swrite32(w, o[0], r);
     break;
   }
+  case S_GETPC: swrite64(w, o[0], 0ull); break; // (relocated symbol operands carry absolute addresses: see parse_operand)
   case S_MULK: swrite32(w, o[0], (uint32_t)((int32_t)sreg32(w, o[0]) * (int32_t)(int16_t)o[1].imm)); break;
   case S_BREV32: {
     uint32_t x = sreg32(w, o[1]), r = 0;
@@ -1243,6 +1245,7 @@ static std::unordered_map<std::string, OpDef> &optable() {
       t[std::string("v_cmp_") + e.n + "_i32" + suf] = OpDef{x_vcmp, C_VALU, (uint16_t)((T_I32 << 8) | e.p), "Uii"};
       t[std::string("v_cmp_") + e.n + "_u32" + suf] = OpDef{x_vcmp, C_VALU, (uint16_t)((T_U32 << 8) | e.p), "Uuu"};
       t[std::string("v_cmp_") + e.n + "_u16" + suf] = OpDef{x_vcmp, C_VALU, (uint16_t)((T_U16 << 8) | e.p), "Uuu"};
+      t[std::string("v_cmp_") + e.n + "_i16" + suf] = OpDef{x_vcmp, C_VALU, (uint16_t)((T_I16 << 8) | e.p), "Uii"};
       t[std::string("v_cmp_") + e.n + "_u64" + suf] = OpDef{x_vcmp, C_VALU, (uint16_t)((T_U64 << 8) | e.p), "UUU"};
       t[std::string("v_cmp_") + e.n + "_i64" + suf] = OpDef{x_vcmp, C_VALU, (uint16_t)((T_I64 << 8) | e.p), "UUU"};
     }
@@ -1286,6 +1289,7 @@ static std::unordered_map<std::string, OpDef> &optable() {
   add("s_bfe_i64", x_salu, C_SALU, S_BFE_I64, "UUu");
   add("s_bfe_u64", x_salu, C_SALU, S_BFE_U64, "UUu");
   add("s_mulk_i32", x_salu, C_SALU, S_MULK, "ii");
+  add("s_getpc_b64", x_salu, C_SALU, S_GETPC, "U");
   add("s_brev_b32", x_salu, C_SALU, S_BREV32, "bb");
   add("s_bcnt1_i32_b64", x_salu, C_SALU, S_BCNT1_64, "iU");
   add("s_bcnt1_i32_b32", x_salu, C_SALU, S_BCNT1_32, "ib");
@@ -1426,6 +1430,7 @@ static bool parse_reg(const std::string &t, char pre, uint16_t &reg, uint8_t &n)
   n = 1;
   return true;
 }
+static const std::map<std::string, std::vector<uint8_t> *> *g_data_objs = nullptr;
 static Operand parse_operand(std::string t, char ty, const std::map<std::string, int> &labels, bool &ok) {
   Operand o;
   ok = true;
@@ -1462,6 +1467,17 @@ static Operand parse_operand(std::string t, char ty, const std::map<std::string,
   }
   // a constant
   o.kind = K_IMM;
+  {
+    const size_t at = t.find("@rel32@");
+    if (at != std::string::npos) { // SYM@rel32@lo+4 / SYM@rel32@hi+12 behind an s_getpc_b64 (which gives 0 here): the halves of SYM's address
+      const std::string sym = t.substr(0, at);
+      const bool hi = t.compare(at + 7, 2, "hi") == 0;
+      if (!g_data_objs || !g_data_objs->count(sym)) { ok = false; return o; }
+      const uint64_t a = (uint64_t)(uintptr_t)g_data_objs->at(sym)->data();
+      o.imm = hi ? (a >> 32) : (a & 0xFFFFFFFFull);
+      return o;
+    }
+  }
   const char *c = t.c_str();
   char *end = nullptr;
   if (t.compare(0, 2, "0x") == 0 || t.compare(0, 3, "-0x") == 0) {
@@ -1578,6 +1594,37 @@ static void load_file(const std::string &path) {
       }
     }
   }
+  // constant data objects (.rodata tables the code reaches through s_getpc + @rel32 relocations): NAME: .long / .quad / ... .size NAME
+  static std::map<std::string, std::vector<uint8_t> *> data_objs; // (kept for the life of the process: the code holds their addresses)
+  for (size_t i = 0; i < lines.size(); ++i) {
+    const std::string t = trim(lines[i]);
+    if (t.compare(0, 6, ".type\t") != 0 && t.compare(0, 6, ".type ") != 0) continue;
+    if (t.find("@object") == std::string::npos) continue;
+    const std::string name = trim(t.substr(6, t.find(',') - 6));
+    size_t j = i + 1;
+    while (j < lines.size() && trim(lines[j]) != name + ":") {
+      if (trim(lines[j]).compare(0, 5, ".type") == 0) break;
+      ++j;
+    }
+    if (j >= lines.size() || trim(lines[j]) != name + ":") continue;
+    auto *buf = new std::vector<uint8_t>();
+    for (size_t q = j + 1; q < lines.size(); ++q) {
+      std::string u = lines[q];
+      const size_t sc = u.find(';');
+      if (sc != std::string::npos) u = u.substr(0, sc);
+      u = trim(u);
+      if (u.compare(0, 5, ".size") == 0) break;
+      auto push = [&](uint64_t v, int n) { for (int b = 0; b < n; ++b) buf->push_back((uint8_t)(v >> (8 * b))); };
+      if (u.compare(0, 5, ".long") == 0) push(strtoull(u.c_str() + 5, nullptr, 0), 4);
+      else if (u.compare(0, 5, ".quad") == 0) push(strtoull(u.c_str() + 5, nullptr, 0), 8);
+      else if (u.compare(0, 6, ".short") == 0) push(strtoull(u.c_str() + 6, nullptr, 0), 2);
+      else if (u.compare(0, 5, ".byte") == 0) push(strtoull(u.c_str() + 5, nullptr, 0), 1);
+      else if (u.compare(0, 5, ".zero") == 0) push(0, 0), buf->resize(buf->size() + strtoull(u.c_str() + 5, nullptr, 0), 0);
+    }
+    buf->resize(buf->size() + 64, 0);
+    data_objs[name] = buf;
+  }
+  g_data_objs = &data_objs;
   // metadata: the implicit ("hidden") kernel arguments and where they sit
   std::map<std::string, std::vector<std::pair<uint32_t, std::string>>> hidden;
   {
