@@ -314,7 +314,7 @@ static inline float max_f32(float a, float b) {
 static inline double quiet(double d) { return d != d ? as_f64(f64_bits(d) | (1ull << 51)) : d; }
 static inline float quietf(float d) { return d != d ? as_f32(f32_bits(d) | (1u << 22)) : d; }
 
-enum { D_ADD, D_MUL, D_FMA, D_FMAC, D_MIN, D_MAX, D_LDEXP, D_RCP, D_RSQ, D_FRACT, D_RNDNE, D_MOV64, D_TRUNC, D_FLOOR };
+enum { D_ADD, D_MUL, D_FMA, D_FMAC, D_MIN, D_MAX, D_LDEXP, D_RCP, D_RSQ, D_FRACT, D_RNDNE, D_MOV64, D_TRUNC, D_FLOOR, D_FREXP_MANT, D_CEIL, D_SQRT };
 static void x_f64(Machine &, Wave &w, const Inst &in) {
   FOR_LANES(w) {
     double r = 0.0;
@@ -343,6 +343,9 @@ static void x_f64(Machine &, Wave &w, const Inst &in) {
     }
     case D_RNDNE: r = std::nearbyint(srcd(w, in.o[1], lane)); break;
     case D_TRUNC: r = std::trunc(srcd(w, in.o[1], lane)); break;
+    case D_CEIL: r = std::ceil(srcd(w, in.o[1], lane)); break;
+    case D_SQRT: r = std::sqrt(srcd(w, in.o[1], lane)); break;
+    case D_FREXP_MANT: { const double x = srcd(w, in.o[1], lane); int e; r = (std::isinf(x) || x != x) ? x : std::frexp(x, &e); break; }
     case D_FLOOR: r = std::floor(srcd(w, in.o[1], lane)); break;
     }
     dstd(w, in.o[0], lane, r);
@@ -496,7 +499,7 @@ static void x_div_fixup_f32(Machine &, Wave &w, const Inst &in) {
 }
 
 // ---- conversions -----------------------------------------------------------------------------------------------------
-enum { CV_F32_F64, CV_F64_F32, CV_F64_I32, CV_F64_U32, CV_I32_F64, CV_U32_F64, CV_F32_I32, CV_F32_U32, CV_U32_F32, CV_I32_F32 };
+enum { CV_F32_F64, CV_F64_F32, CV_F64_I32, CV_F64_U32, CV_I32_F64, CV_U32_F64, CV_F32_I32, CV_F32_U32, CV_U32_F32, CV_I32_F32, CV_FREXP_EXP_F64 };
 static void x_cvt(Machine &, Wave &w, const Inst &in) {
   FOR_LANES(w) {
     switch (in.sub) {
@@ -513,6 +516,13 @@ static void x_cvt(Machine &, Wave &w, const Inst &in) {
     case CV_U32_F64: {
       const double x = srcd(w, in.o[1], lane);
       w.vr(in.o[0].reg, lane) = x != x || x <= 0.0 ? 0u : (x >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)x);
+      break;
+    }
+    case CV_FREXP_EXP_F64: {
+      const double x = srcd(w, in.o[1], lane);
+      int e = 0;
+      if (!(std::isinf(x) || x != x || x == 0.0)) (void)std::frexp(x, &e);
+      w.vr(in.o[0].reg, lane) = (uint32_t)e;
       break;
     }
     case CV_F32_I32: w.vr(in.o[0].reg, lane) = f32_bits((float)(int32_t)src32(w, in.o[1], lane)); break;
@@ -716,7 +726,7 @@ static void x_readfirstlane(Machine &, Wave &w, const Inst &in) {
 enum {
   S_MOV32, S_MOV64, S_MOVK, S_ADD_I32, S_ADDK, S_SUB_I32, S_MUL_I32, S_MUL_HI_U32, S_AND32, S_AND64, S_OR32, S_OR64, S_XOR32, S_XOR64, S_ANDN2_64, S_ORN2_64, S_ANDN2_32, S_NOT64,
   S_LSHL32, S_LSHL64, S_LSHR32, S_LSHR64, S_ASHR32, S_BFM32, S_BREV32, S_BCNT1_64, S_BCNT1_32, S_MIN_U32, S_MAX_U32, S_MIN_I32, S_MAX_I32, S_CSELECT32, S_CSELECT64, S_AND_SAVEEXEC, S_OR_SAVEEXEC,
-  S_ANDN2_SAVEEXEC, S_GETREG, S_FF1_64, S_FF1_32, S_ADD_U32, S_SUB_U32, S_ADDC_U32, S_SUBB_U32, S_BFE_U32, S_ABS_I32, S_SEXT_I32_I16, S_NOT32, S_XNOR64, S_NAND64, S_NOR64, S_MUL_HI_I32, S_MEMTIME, S_BFE_I64, S_BFE_I32, S_MULK, S_BFE_U64, S_GETPC
+  S_ANDN2_SAVEEXEC, S_GETREG, S_FF1_64, S_FF1_32, S_ADD_U32, S_SUB_U32, S_ADDC_U32, S_SUBB_U32, S_BFE_U32, S_ABS_I32, S_SEXT_I32_I16, S_NOT32, S_XNOR64, S_NAND64, S_NOR64, S_MUL_HI_I32, S_MEMTIME, S_BFE_I64, S_BFE_I32, S_MULK, S_BFE_U64, S_GETPC, S_FLBIT32, S_FLBIT64
 };
 static void x_salu(Machine &M, Wave &w, const Inst &in) {
   const Operand *o = in.o;
@@ -816,6 +826,8 @@ static void x_salu(Machine &M, Wave &w, const Inst &in) {
     swrite32(w, o[0], r);
     break;
   }
+  case S_FLBIT32: { const uint32_t a = sreg32(w, o[1]); swrite32(w, o[0], a ? (uint32_t)__builtin_clz(a) : 0xFFFFFFFFu); break; }
+  case S_FLBIT64: { const uint64_t a = sreg64(w, o[1]); swrite32(w, o[0], a ? (uint32_t)__builtin_clzll(a) : 0xFFFFFFFFu); break; }
   case S_GETPC: swrite64(w, o[0], 0ull); break; // (relocated symbol operands carry absolute addresses: see parse_operand)
   case S_MULK: swrite32(w, o[0], (uint32_t)((int32_t)sreg32(w, o[0]) * (int32_t)(int16_t)o[1].imm)); break;
   case S_BREV32: {
@@ -878,6 +890,8 @@ static void x_branch(Machine &, Wave &w, const Inst &in) {
   if (take) w.pc = (size_t)in.o[0].label - 1; // (the loop adds 1)
 }
 static void x_nop(Machine &, Wave &, const Inst &) {}
+// opcodes that sit on paths the kernels' inputs never take (Payne-Hanek reduction of huge sincos arguments): loading the kernel is fine, executing one aborts
+static void x_unmodelled(Machine &, Wave &, const Inst &in) { die(in, "instruction not modelled (an input took a path the interpreter does not cover)"); }
 static void x_sleep(Machine &M, Wave &, const Inst &) { M.yield = true; }
 static void x_barrier(Machine &M, Wave &w, const Inst &) { w.at_barrier = true; M.yield = true; }
 static void x_endpgm(Machine &M, Wave &w, const Inst &) { w.done = true; M.yield = true; }
@@ -1216,6 +1230,9 @@ static std::unordered_map<std::string, OpDef> &optable() {
   add("v_trunc_f32_e32 v_trunc_f32_e64", x_f32, C_VALU, F_TRUNC, "ff");
   add("v_rsq_f32_e32 v_rsq_f32_e64", x_f32, C_VALU, F_RSQ, "ff");
   add("v_trunc_f64_e32 v_trunc_f64_e64", x_f64, C_VALU, D_TRUNC, "dd");
+  add("v_ceil_f64_e32 v_ceil_f64_e64", x_f64, C_VALU, D_CEIL, "dd");
+  add("v_frexp_mant_f64_e32 v_frexp_mant_f64_e64", x_f64, C_VALU, D_FREXP_MANT, "dd");
+  add("v_frexp_exp_i32_f64_e32 v_frexp_exp_i32_f64_e64", x_cvt, C_VALU, CV_FREXP_EXP_F64, "id");
   add("v_floor_f64_e32 v_floor_f64_e64", x_f64, C_VALU, D_FLOOR, "dd");
   add("v_add_u16_e32 v_add_u16_e64", x_int, C_VALU, I_ADD_U16, "uuu");
   add("v_floor_f32_e32 v_floor_f32_e64", x_f32, C_VALU, F_FLOOR, "ff");
@@ -1319,6 +1336,9 @@ static std::unordered_map<std::string, OpDef> &optable() {
   add("s_bitcmp1_b32", x_scmp, C_SALU, (T_U32 << 8) | SC_BITCMP1, "bu");
   add("s_bitcmp0_b64", x_scmp, C_SALU, (T_U64 << 8) | SC_BITCMP0, "Uu");
   add("s_bitcmp1_b64", x_scmp, C_SALU, (T_U64 << 8) | SC_BITCMP1, "Uu");
+  add("v_trig_preop_f64", x_unmodelled, C_VALU, 0, "ddu");
+  add("s_flbit_i32_b32", x_salu, C_SALU, S_FLBIT32, "ib");
+  add("s_flbit_i32_b64", x_salu, C_SALU, S_FLBIT64, "iU");
   add("s_branch", x_branch, C_BRANCH, B_ALWAYS, "-");
   add("s_cbranch_scc0", x_branch, C_BRANCH, B_SCC0, "-");
   add("s_cbranch_scc1", x_branch, C_BRANCH, B_SCC1, "-");
