@@ -88,6 +88,8 @@ struct RenderSlot {
   size_t overflow_lanes = 0;
   void *p_woverflow = nullptr;      // the same for the wide traversal's far-child stack (16-byte entries)
   size_t woverflow_entries = 0;     // its capacity in entries (lanes x entries per lane of the launch that sized it)
+  void *p_prim = nullptr;           // HBM-resident scene: staged primary rays, 40 bytes per lane of the launch (RenderParams::prim_stage)
+  size_t prim_lanes = 0;
 };
 
 struct MgpuScene {
@@ -1018,7 +1020,7 @@ int mgpu_scene_destroy(MgpuScene *s) {
       if (p) (void)hipFree(p);
   }
   for (RenderSlot &r : s->slot) {
-    void *rp[] = {r.p_planes, r.p_tile_cost, r.p_tile_order, r.p_overflow, r.p_woverflow};
+    void *rp[] = {r.p_planes, r.p_tile_cost, r.p_tile_order, r.p_overflow, r.p_woverflow, r.p_prim};
     for (void *p : rp)
       if (p) (void)hipFree(p);
     if (r.done) (void)hipEventDestroy(r.done);
@@ -1372,6 +1374,23 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
     rc = slot_woverflow(s, R, blocks * block, dsc, w5 ? render_w5_stack_entries() : kWideStackLds);
     if (rc) return rc;
   }
+  // HBM-resident scene with the treelet kernel: the items' primary rays staged per wave in device memory (k_render_sm, PRIM; MGPU_NO_PRIM=1: off)
+  if (kern == 1 && treelet && !w5 && !getenv("MGPU_NO_PRIM")) {
+    const size_t lanes = blocks * (size_t)block;
+    if (lanes > R.prim_lanes) {
+      if (R.p_prim) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(R.p_prim));
+        s->device_bytes -= R.prim_lanes * 40;
+        R.p_prim = nullptr;
+        R.prim_lanes = 0;
+      }
+      rc = dev_alloc(s, &R.p_prim, lanes * 40);
+      if (rc) return rc;
+      R.prim_lanes = lanes;
+    }
+    prim = true;
+  }
 
   RenderParams P;
   memcpy(P.frame, frame, sizeof(P.frame));
@@ -1509,6 +1528,7 @@ static int render_frames_impl(MgpuScene *s, const double frame[12], int W, int H
     if (rc) return rc;
   }
   P.wave_log = s->p_wave_log;
+  P.prim_stage = (kern == 1 && prim) ? (unsigned char *)R.p_prim : nullptr;
   P.probe = s->probe_buf;
   P.probe_pixel = s->probe_pixel;
 

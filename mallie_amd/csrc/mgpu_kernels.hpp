@@ -63,6 +63,10 @@ struct RenderParams {
   // ... and which rays may consult them (mgpu_device.hpp, leaf_hint_make): origins with |org - hint_c|^2 <= hint_q2 = hint_q^2, which
   // bounds |org - p0| of such a ray against every triangle and sizes pads and cones (host: render_frames_impl)
   double hint_c[3], hint_q2, hint_q;
+  // k_render_sm<!LDS_SCENE, PRIM>: where the waves stage the primary rays of their current work item when LDS has no room for them
+  // (the HBM-resident scene: stacks + treelet fill it) -- 64 x 40 bytes per wave of the launch in device memory, written and read by
+  // that wave alone (its lines stay in the CU's L1 / L2)
+  unsigned char *prim_stage;
   unsigned long long *wave_log;  // device or null: 4 words per wave (diagnostic builds only)
   double *probe;                 // device or null: kProbeStride doubles per PathTrace iteration of ONE path
   uint32_t probe_pixel, probe_pass; // full-frame pixel index and pass of the probed path

@@ -203,19 +203,22 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
   // moment the item is taken and parked in LDS (40 bytes each); a lane that is handed a path copies its ray from there.  The
   // path-start body (~170 instructions: two splitmix64, two draws, a normalisation) then runs once per 64 paths with 64 lanes
   // instead of in two SHADE steps out of three with whoever asks.
-  static_assert(!PRIM || LDS_SCENE, "primary-ray staging exists for the LDS-resident scene only");
+  // HBM-resident scene (round 6): the LDS is full (stacks + treelet), so the same 40-byte slots live in device memory, 64 per wave of the
+  // launch (RenderParams::prim_stage); only the wave that wrote them reads them, a few instructions later, so they stay in the CU's L1.
+  // Measured on the ISA interpreter (tools/isa_profile.py): the path-start body ran for 38 lanes on average, now always for 64.
   struct PrimRay {
     double d[3];
     uint32_t s[4];
   };
-  PrimRay *s_prim = reinterpret_cast<PrimRay *>(const_cast<unsigned char *>(lds_tris) + (((size_t)P.lds_tris_bytes + 15) & ~(size_t)15)) + (size_t)wave * 64;
+  PrimRay *s_prim = LDS_SCENE ? reinterpret_cast<PrimRay *>(const_cast<unsigned char *>(lds_tris) + (((size_t)P.lds_tris_bytes + 15) & ~(size_t)15)) + (size_t)wave * 64
+                              : reinterpret_cast<PrimRay *>(P.prim_stage) + ((size_t)blockIdx.x * kWaves + (size_t)wave) * 64;
   // Leaf hints (mgpu_device.hpp, leaf_hint_make).  LDS-resident scene: P.lds_hint_cap records of 96 bytes behind the staging above,
   // made here from the LDS copy of the triangles; a leaf's axis field (unused by the reference's traversal) becomes (hint + 1) << 16,
   // which the NODE step adds to tri_end when it opens the leaf (slots of an LDS-resident scene stay below 2^16).  (For the
   // HBM-resident scene -- records made when the scene is created, found through packed leaf tags -- the record is one more
   // dependent fetch in front of every TRI step: built, exact, 2-4 % slower; profiles/experiments/leaf_hints_hbm.diff.txt.)
   constexpr uint32_t kHintMinTris = MGPU_HINT_MIN;
-  unsigned char *lds_hints = reinterpret_cast<unsigned char *>(s_prim - (size_t)wave * 64) + (PRIM ? (size_t)kWaves * 64 * sizeof(PrimRay) : 0);
+  unsigned char *lds_hints = const_cast<unsigned char *>(lds_tris) + (((size_t)P.lds_tris_bytes + 15) & ~(size_t)15) + (PRIM ? (size_t)kWaves * 64 * sizeof(PrimRay) : 0);
   if (LDS_SCENE && MGPU_LEAF_HINTS) {
     __shared__ uint32_t s_nhints;
     if (threadIdx.x == 0) s_nhints = 0u;
@@ -939,9 +942,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
               pr.d[0] = d.x; pr.d[1] = d.y; pr.d[2] = d.z;
               pr.s[0] = r.x; pr.s[1] = r.y; pr.s[2] = r.z; pr.s[3] = r.w;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if constexpr (LDS_SCENE) {
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            } else { // device memory: the stores must have left the wave before other lanes load the slots (workgroup scope: one CU, one L1)
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+              __builtin_amdgcn_wave_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
           }
         }
         if (want_pixel) {
@@ -1595,7 +1604,9 @@ hipError_t launch_render_sm(int stack_entry_bytes, bool lds_scene, bool prim, in
     if (stack_entry_bytes == 2) return prim ? launch_one<uint16_t, true, 1024, true>(grid, s, shmem, sc, p) : launch_one<uint16_t, true, 1024>(grid, s, shmem, sc, p);
   }
   if (!lds_scene && block == 256) return launch_one<uint32_t, false, 256>(grid, s, shmem, sc, p); // wide form: one variant
-  if (!lds_scene && block == 1024 && sc.treelet) return launch_one<uint32_t, false, 1024>(grid, s, shmem, sc, p); // ... + treelet in LDS
+  if (!lds_scene && block == 1024 && sc.treelet) // ... + treelet in LDS; prim: the items' primary rays staged in device memory (RenderParams::prim_stage)
+    return (prim && sc.grey && p.prim_stage) ? launch_grey<uint32_t, false, 1024, true, true>(grid, s, shmem, sc, p) // (a scene of coloured materials keeps the plain variant: staged, it spills 23 registers)
+                                             : launch_one<uint32_t, false, 1024>(grid, s, shmem, sc, p);
 #ifdef MGPU_EXP_768
   if (!lds_scene && block == 768 && sc.treelet) return launch_one<uint32_t, false, 768>(grid, s, shmem, sc, p); // experiment: 3 waves per SIMD, 168 VGPRs
 #endif
