@@ -9,6 +9,7 @@ echo "== 1. GPU suite"; timeout 900 python -m pytest tests -m gpu -q > $out/test
 echo "== 2. k_render_w5 beside k_render_sm"; timeout 900 bash tools/w5_ab.sh c4 c3 $([ -z "$short" ] && echo c5) > $out/w5_ab.txt 2>&1; cat $out/w5_ab.txt | cut -c1-220
 MGPU_W5_BLOCK=320 timeout 600 bash tools/w5_ab.sh c4 c3 > $out/w5_ab_320.txt 2>&1; grep "MGPU_W5=1" $out/w5_ab_320.txt | cut -c1-220
 for lib in mallie_amd/ab/w5_*.so; do for c in c4 c3; do echo "$(basename $lib .so) $c: $(MGPU_W5=1 MALLIE_MGPU_LIB=$lib timeout 300 python tools/perf_cfg.py $c 6 2>&1 | tail -1 | grep -o "median of the last [0-9]*: [0-9.]*")"; done; done > $out/w5_variants.txt 2>&1; cat $out/w5_variants.txt
+echo "== 2b. staged primary rays for HBM-resident scenes (round 6, default on): kernel ms with and without"; for c in c4 c3; do for np in 0 1; do if [ $np = 1 ]; then export MGPU_NO_PRIM=1; else unset MGPU_NO_PRIM; fi; echo "$c MGPU_NO_PRIM=$np: $(timeout 300 python tools/perf_cfg.py $c 6 2>&1 | tail -1 | cut -c1-200)"; done; done > $out/prim_hbm_ab.txt 2>&1; unset MGPU_NO_PRIM; cat $out/prim_hbm_ab.txt
 echo "== 3. eight ranks in one process: enqueue cost with and without a thread per member"
 for th in 0 1; do MGPU_FRAME_ENQUEUE_THREADS=$th timeout 600 bash tools/perf_multi_one_gpu.sh $tag/multi_th$th > $out/multi_threads_$th.txt 2>&1; grep "ranks 8" $out/multi_threads_$th.txt | cut -c1-260; done
 echo "== 4. the reference's stream: does it settle"; timeout 300 python tools/perf_stream.py > $out/stream.txt 2>&1; tail -6 $out/stream.txt | cut -c1-220
