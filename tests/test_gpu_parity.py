@@ -826,6 +826,40 @@ def test_grey_and_three_channel_kernels_agree(monkeypatch):
     assert imgs[0].tobytes() == imgs[1].tobytes() == oimg.tobytes()
 
 
+def test_staged_primary_rays_of_the_hbm_resident_kernel_change_nothing(monkeypatch):
+    """Round 6: with the scene in HBM a wave makes its work item's 64 primary rays together and parks them in device memory of its own
+    (RenderParams::prim_stage; the LDS is full there) instead of every lane making its ray where it starts a path.  Same frames byte for
+    byte, same counters word for word as with MGPU_NO_PRIM=1 -- a suzanne grid too large for LDS (several passes, one pass, a window with
+    edge tiles, primary rays only), teapot against the oracle, the reference's stream (start states from the table), two slots in flight."""
+    from mallie_amd.scenes import suzanne_grid
+    c = O.load_golden("cornell_obj")
+    verts, faces, mats, normals = suzanne_grid(c["verts"], c["faces"], 6)
+    W, H = 320, 200
+    frame = M.camera_frame((0.0, 40.0, 80.0), (0.0, 0.0, 0.0), width=W, height=H)
+    sc = M.Scene(verts, faces, mats, normals, None)
+    plane = sc.plane()
+    for (mpl, passes, win) in [(5, 4, None), (9, 1, None), (3, 2, (3, 5, 301, 187)), (1, 3, None)]:
+        monkeypatch.delenv("MGPU_NO_PRIM", raising=False)
+        img, cnt, st = sc.render(frame, W, H, mpl, passes, plane, M.RNG_HASH, seed=11, pass_base=2, window=win)
+        monkeypatch.setenv("MGPU_NO_PRIM", "1")
+        rimg, rcnt, rst = sc.render(frame, W, H, mpl, passes, plane, M.RNG_HASH, seed=11, pass_base=2, window=win)
+        assert img.tobytes() == rimg.tobytes() and np.array_equal(cnt, rcnt), (mpl, passes, win)
+        assert all(st[f] == rst[f] for f in ("real_rays", "nodes", "tris", "trace_calls", "paths")), (st, rst)
+    monkeypatch.delenv("MGPU_NO_PRIM", raising=False)
+    tp, otp = gpu_scene("teapot_obj"), O.scene_from_golden("teapot_obj")
+    W2, H2 = 120, 88
+    cam = M.camera_frame((0.0, 40.0, 250.0), (0.0, 40.0, 0.0), width=W2, height=H2)
+    img, cnt, st = tp.render(cam, W2, H2, 6, 3, tp.plane(), M.RNG_HASH, seed=5, pass_base=1)
+    oimg, ocnt, ost, _ = otp.render(cam, W2, H2, 6, 3, otp.plane(), O.RNG_HASH, seed=5, pass_base=1)
+    assert_images_match(img, oimg, "teapot with staged primary rays vs oracle")
+    assert np.array_equal(cnt, ocnt)
+    assert_same_work(st, ost)
+    # the reference's own stream: the start states come from the resolved table, staged like the hashed ones
+    simg = tp.render_stream(cam, W2, H2, 6, 1, tp.plane())[0]
+    soimg = otp.render(cam, W2, H2, 6, 1, otp.plane(), O.RNG_STREAM, stream_state=np.array(O.REFERENCE_SEED, "<u4"))[0]
+    assert_images_match(simg, soimg, "teapot in the reference's stream with staged primary rays vs oracle")
+
+
 @pytest.mark.opt_in_experiment
 @pytest.mark.parametrize("block", ["640", "320"])
 def test_hand_partitioned_five_wave_kernel_equals_the_default(block, monkeypatch):
