@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kBlock, MGPU_RENDER_MIN_WAVES) void k_render(DScene
   for (;;) {
     // ---- 1. hand pixels to idle lanes ---------------------------------------------------------------------------
     {
-      const unsigned long long need = __ballot(state == S_NEED_PIXEL);
+      const unsigned long long need = MGPU_BALLOT(state == S_NEED_PIXEL);
       if (need) {
         if (in_tile >= 64 && !exhausted) { // current tile used up: advance (refill the chunk when empty)
           if (tile_next >= tile_end) {
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kBlock, MGPU_RENDER_MIN_WAVES) void k_render(DScene
 
 #ifdef MGPU_UTIL
     u_outer += 1;
-    u_gen += (uint32_t)__popcll(__ballot(state == S_NEED_PATH));
+    u_gen += (uint32_t)__popcll(MGPU_BALLOT(state == S_NEED_PATH));
 #endif
     // ---- 2. start a new eye path (PathTrace prologue, render.cc:387-400) ----------------------------------------
     if (state == S_NEED_PATH) {
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kBlock, MGPU_RENDER_MIN_WAVES) void k_render(DScene
     h.t = kDblMax;
     h.u = h.v = 0.0;
 #ifdef MGPU_UTIL
-    u_trace += (uint32_t)__popcll(__ballot(state == S_TRACE));
+    u_trace += (uint32_t)__popcll(MGPU_BALLOT(state == S_TRACE));
 #endif
     if (state == S_TRACE) traverse<CAP, true>(sc, stk, org, dir, h, c);
 
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(1024) void k_trace_probe(const MgpuRay *__restrict_
     const double d = x * dx + y * dy + z * dz;
     const double l2 = (x * x + y * y + z * z) * (dx * dx + dy * dy + dz * dz);
     const bool near = d > 0.0 && d * d > 0.94 * l2; // cos^2 > 0.94: within ~14 degrees of the group's first direction
-    if (__ballot(!near) == 0ull) ++mine;
+    if (MGPU_BALLOT(!near) == 0ull) ++mine;
   }
   if (lane == 0 && mine) atomicAdd(&coherent, mine);
   __syncthreads();

@@ -114,17 +114,17 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
   uint32_t n_rays = 0, n_nodes = 0, n_tris = 0, trace_calls = 0, paths = 0;
 
   for (;;) {
-    const unsigned long long mN = __ballot(st == ES_NODE);
-    const unsigned long long mT = __ballot(st == ES_TRI);
-    const unsigned long long mS = __ballot(st == ES_SHADE);
+    const unsigned long long mN = MGPU_BALLOT(st == ES_NODE);
+    const unsigned long long mT = MGPU_BALLOT(st == ES_TRI);
+    const unsigned long long mS = MGPU_BALLOT(st == ES_SHADE);
     const int cN = __popcll(mN), cT = __popcll(mT), cS = __popcll(mS);
     if ((cN | cT | cS) == 0) break;
     // lanes parked between paths (deferred start, see below) do not count towards the quorum; enough of them force a step
-    const int cReal = __popcll(__ballot(st == ES_SHADE && have_ray));
+    const int cReal = __popcll(MGPU_BALLOT(st == ES_SHADE && have_ray));
     const bool run_shade = (cReal >= MGPU_ENV_SHADE_MIN) || (cN == 0 && cT == 0) || (cS - cReal >= MGPU_ENV_START_FORCE);
     if (!run_shade && cN * MGPU_ENV_NODE_WEIGHT >= cT * MGPU_ENV_TRI_WEIGHT) {
       // ================================ NODE step ================================
-      const bool all_plain = __ballot(st == ES_NODE && !ray_plain) == 0ull; // wave-uniform
+      const bool all_plain = MGPU_BALLOT(st == ES_NODE && !ray_plain) == 0ull; // wave-uniform
       if (st == ES_NODE) {
         const bool sx = (sgn & 1u) != 0u, sy = (sgn & 2u) != 0u, sz = (sgn & 4u) != 0u;
         // slab_hit<true> (min/max form) when every lane's ray qualifies, the literal form for this step otherwise
@@ -315,11 +315,11 @@ __global__ __launch_bounds__(BLOCK, 4) void k_render_env(DScene sc, EnvParams P_
       // many lanes at once.  With fewer than MGPU_ENV_START_MIN lanes between paths while others still traverse, those
       // lanes stay parked in SHADE without a ray and start together in a later step.
       const bool restart = shade_lane && !have_ray && (path_done || !have_pixel);
-      const bool defer = (cN + cT) > 0 && __popcll(__ballot(restart)) < MGPU_ENV_START_MIN;
+      const bool defer = (cN + cT) > 0 && __popcll(MGPU_BALLOT(restart)) < MGPU_ENV_START_MIN;
       // ---- pixel hand-out, executed by the whole wave (the cursor is wave-uniform) ----
       bool want = shade_lane && !have_pixel && !have_ray;
       for (;;) {
-        const unsigned long long wm = __ballot(want);
+        const unsigned long long wm = MGPU_BALLOT(want);
         if (!wm || exhausted || defer) break;
         if (in_tile >= 64) {
           uint32_t t = 0;

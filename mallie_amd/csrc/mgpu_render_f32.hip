@@ -256,12 +256,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_F32_HBM_WAVES(CAP)
   uint32_t n_rays = 0, n_nodes = 0, n_tris = 0, trace_calls = 0, paths = 0;
 
   for (;;) {
-    const unsigned long long mN = __ballot(st == F_NODE);
-    const unsigned long long mT = __ballot(st == F_TRI);
-    const unsigned long long mS = __ballot(st == F_SHADE);
+    const unsigned long long mN = MGPU_BALLOT(st == F_NODE);
+    const unsigned long long mT = MGPU_BALLOT(st == F_TRI);
+    const unsigned long long mS = MGPU_BALLOT(st == F_SHADE);
     const int cN = __popcll(mN), cT = __popcll(mT), cS = __popcll(mS);
     if ((cN | cT | cS) == 0) break;
-    const int cReal = __popcll(__ballot(st == F_SHADE && have_ray));
+    const int cReal = __popcll(MGPU_BALLOT(st == F_SHADE && have_ray));
     const bool run_shade = (cReal >= kShadeMin) || (cN == 0 && cT == 0) || (cS - cReal >= (LDS_SCENE ? 16 : 12));
     if (!run_shade && cN >= 4 * cT) {
       // ================================ NODE step ================================
@@ -476,9 +476,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : MGPU_F32_HBM_WAVES(CAP)
       }
 
       // ---- path hand-out, executed by the whole wave (the cursor variables are wave-uniform); see mgpu_render_sm.hip ----
-      const bool defer = !exhausted && (cN + cT) > 0 && __popcll(__ballot(want_pixel)) < (LDS_SCENE ? 12 : 8);
+      const bool defer = !exhausted && (cN + cT) > 0 && __popcll(MGPU_BALLOT(want_pixel)) < (LDS_SCENE ? 12 : 8);
       for (;;) {
-        const unsigned long long want = __ballot(want_pixel);
+        const unsigned long long want = MGPU_BALLOT(want_pixel);
         if (!want || exhausted || defer) break;
         if (in_item >= 64) {
           uint32_t cur_shard = 0, item_local = 0;

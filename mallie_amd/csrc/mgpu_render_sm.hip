@@ -320,7 +320,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
   auto occ_book = [&](uint32_t d, int max_d, int word) {
     uint32_t trips = 0, lanes = 0;
     for (int k = 1; k <= max_d; ++k) {
-      const unsigned long long b = __ballot(d >= (uint32_t)k);
+      const unsigned long long b = MGPU_BALLOT(d >= (uint32_t)k);
       if (b == 0ull) break;
       trips += 1u;
       lanes += (uint32_t)__popcll(b);
@@ -356,9 +356,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
   uint32_t dry_rays = 0, dry_steps = 0, dry_active = 0, dry_plen = 0, dry_inpath = 0, steps_n = 0, steps_t = 0, steps_s = 0;
 #endif
   for (;;) {
-    const unsigned long long mN = __ballot(st == ST_NODE);
-    const unsigned long long mT0 = __ballot(st == ST_TRI);
-    const unsigned long long mS = __ballot(st == ST_SHADE);
+    const unsigned long long mN = MGPU_BALLOT(st == ST_NODE);
+    const unsigned long long mT0 = MGPU_BALLOT(st == ST_TRI);
+    const unsigned long long mS = MGPU_BALLOT(st == ST_SHADE);
     const int cN = __popcll(mN), cT0 = __popcll(mT0), cS = __popcll(mS);
     if ((cN | cT0 | cS) == 0) break;
 #ifdef MGPU_UTIL
@@ -368,12 +368,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
     // Scheduling rule: SHADE is by far the most expensive body (fp64 sqrt/div/sincos), so it runs only when at least
     // MGPU_SHADE_MIN lanes have a ray to finish, or MGPU_START_FORCE lanes are parked between paths, or nothing else is
     // runnable; otherwise NODE runs unless TRI has several times more lanes waiting (MGPU_NODE_WEIGHT_*).
-    const int cReal = __popcll(__ballot(st == ST_SHADE && have_ray)); // lanes with a ray to finish (not parked between paths)
+    const int cReal = __popcll(MGPU_BALLOT(st == ST_SHADE && have_ray)); // lanes with a ray to finish (not parked between paths)
     const bool run_shade = (cReal >= MGPU_SHADE_MIN) || (cN == 0 && cT0 == 0) || (cS - cReal >= (PRIM ? MGPU_START_FORCE_PRIM : (LDS_SCENE ? MGPU_START_FORCE_LDS : MGPU_START_FORCE_HBM)));
     if (!run_shade && cN * (LDS_SCENE ? MGPU_NODE_WEIGHT_LDS : MGPU_NODE_WEIGHT_HBM) >= cT0 * (LDS_SCENE ? MGPU_TRI_WEIGHT_LDS : MGPU_TRI_WEIGHT_HBM)) {
       // ================================ NODE step ================================
       MGPU_TICK();
-      const bool all_plain = __ballot(st == ST_NODE && !ray_plain) == 0ull; // wave-uniform
+      const bool all_plain = MGPU_BALLOT(st == ST_NODE && !ray_plain) == 0ull; // wave-uniform
       const bool occ_sample = occ_sampled();
       const uint32_t occ_n0 = MGPU_OCC ? n_nodes : 0u;
 #ifdef MGPU_EMU_STATS
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
 #pragma unroll 1
           for (int rep = 0; rep < MGPU_NODES_PER_STEP; ++rep) {
 #ifdef MGPU_UTIL
-            if (lane == __ffsll((long long)__ballot(1)) - 1) u_node_it++;
+            if (lane == __ffsll((long long)MGPU_BALLOT(1)) - 1) u_node_it++;
 #endif
             const uint32_t ni = stk.get(sp);
             --sp;
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
       int cT = cT0;
       if (LDS_SCENE && MGPU_LEAF_HINTS) { // leaves opened since the last TRI step: their hints (mgpu_device.hpp, leaf_hint_make)
         const bool fresh = st == ST_TRI && (tri_end >> 16) != 0u;
-        if (__ballot(fresh) != 0ull) {
+        if (MGPU_BALLOT(fresh) != 0ull) {
           if (fresh) {
             const float *hp = reinterpret_cast<const float *>(lds_hints + (size_t)((tri_end >> 16) - 1u) * (kHintFloats * 4));
             tri_end &= 0xFFFFu;
@@ -514,9 +514,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
             if (tri_cur == tri_end) st = sp < 0 ? ST_SHADE : ST_NODE; // nothing left of the leaf
           }
 #ifdef MGPU_UTIL
-          if (lane == __ffsll((long long)__ballot(1)) - 1) u_hint_steps++;
+          if (lane == __ffsll((long long)MGPU_BALLOT(1)) - 1) u_hint_steps++;
 #endif
-          mT = __ballot(st == ST_TRI);
+          mT = MGPU_BALLOT(st == ST_TRI);
           cT = __popcll(mT);
         }
       }
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
 #pragma unroll 1
           for (int rep = 0; rep < MGPU_TRIS_PER_STEP; ++rep) {
 #ifdef MGPU_UTIL
-            if (lane == __ffsll((long long)__ballot(1)) - 1) u_tri_it++;
+            if (lane == __ffsll((long long)MGPU_BALLOT(1)) - 1) u_tri_it++;
 #endif
             const unsigned char *tp = lds_tris + (size_t)tri_cur * 80;
             const double2 a0 = *reinterpret_cast<const double2 *>(tp);
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
 #pragma unroll 1
           for (int rep = 0; rep < MGPU_TRIS_PER_STEP; ++rep) {
 #ifdef MGPU_UTIL
-            if (lane == __ffsll((long long)__ballot(1)) - 1) u_tri_it++;
+            if (lane == __ffsll((long long)MGPU_BALLOT(1)) - 1) u_tri_it++;
 #endif
             const DTri *tp = sc.tris + tri_cur;
             const double2 a0 = reinterpret_cast<const double2 *>(tp)[0], a1 = reinterpret_cast<const double2 *>(tp)[1],
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
               trace_calls += (uint32_t)P.maxPathLength;
 #ifdef MGPU_UTIL
               const unsigned long long cyc_tail0 = clock64();
-              const bool tail_first = lane == __ffsll((long long)__ballot(1)) - 1;
+              const bool tail_first = lane == __ffsll((long long)MGPU_BALLOT(1)) - 1;
 #endif
               double d0 = 0.5, d1 = 0.5, d2 = 0.5; // Material().diffuse default (material.h:12-15)
               const bool mul = last_mat != kNoMaterial;
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
           } else {
 #ifdef MGPU_UTIL
             const unsigned long long cyc_b0 = clock64();
-            const bool bounce_first = lane == __ffsll((long long)__ballot(1)) - 1;
+            const bool bounce_first = lane == __ffsll((long long)MGPU_BALLOT(1)) - 1;
 #endif
             const V3 hitP = org + scale(dir, t);
             (void)rng_next(rng); // `double r = randomreal();` drawn and never used (render.cc:430)
@@ -849,9 +849,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
       // ---- (2) path hand-out, executed by the whole wave (cursor variables are wave-uniform) ----
       // deferred start: with few lanes asking for a new path while others still traverse, the lanes stay parked (state
       // SHADE, no ray) and the path-start body runs later for more of them at once
-      const bool defer = !exhausted && (cN + cT0) > 0 && __popcll(__ballot(want_pixel)) < (PRIM ? MGPU_START_MIN_PRIM : (LDS_SCENE ? MGPU_START_MIN_LDS : MGPU_START_MIN_HBM));
+      const bool defer = !exhausted && (cN + cT0) > 0 && __popcll(MGPU_BALLOT(want_pixel)) < (PRIM ? MGPU_START_MIN_PRIM : (LDS_SCENE ? MGPU_START_MIN_LDS : MGPU_START_MIN_HBM));
       for (;;) {
-        const unsigned long long want = __ballot(want_pixel);
+        const unsigned long long want = MGPU_BALLOT(want_pixel);
         if (!want || exhausted || defer) break;
         if (in_item >= 64) { // current item used up: take the next one from the workgroup's cursor
           uint32_t cur_shard = 0, item_local = 0;
@@ -984,7 +984,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
           atomicAdd(&emu_stats[57], 1ull); // paths started
 #endif
 #ifdef MGPU_UTIL
-          if (lane == __ffsll((long long)__ballot(1)) - 1) u_start_steps++;
+          if (lane == __ffsll((long long)MGPU_BALLOT(1)) - 1) u_start_steps++;
 #endif
           // start a new eye path (PathTrace prologue, render.cc:387-400)
           if constexpr (PRIM) {
@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
               ++n_nodes;
               sp = -1;
               st = ST_SHADE; // a miss: the ray is finished
-              const bool rhit = (__ballot(!ray_plain) == 0ull) ? slab_hit<true>(rb0, rb1, rb2, org, ix, iy, iz, sx, sy, sz, bt)
+              const bool rhit = (MGPU_BALLOT(!ray_plain) == 0ull) ? slab_hit<true>(rb0, rb1, rb2, org, ix, iy, iz, sx, sy, sz, bt)
                                                               : slab_hit<false>(rb0, rb1, rb2, org, ix, iy, iz, sx, sy, sz, bt);
               if (rhit) {
                 if (rmeta.x == 0) {

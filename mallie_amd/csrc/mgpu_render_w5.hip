@@ -131,17 +131,17 @@ __global__ __launch_bounds__(BLOCK, MGPU_W5_WAVES) void k_render_w5(DScene sc, R
   uint32_t n_nodes = 0, n_tris = 0;
 
   for (;;) {
-    const unsigned long long mN = __ballot(st == W_NODE);
-    const unsigned long long mT = __ballot(st == W_TRI);
-    const unsigned long long mR = __ballot(st == W_SHADE);
-    const unsigned long long mP = __ballot(st == W_PARK);
+    const unsigned long long mN = MGPU_BALLOT(st == W_NODE);
+    const unsigned long long mT = MGPU_BALLOT(st == W_TRI);
+    const unsigned long long mR = MGPU_BALLOT(st == W_SHADE);
+    const unsigned long long mP = MGPU_BALLOT(st == W_PARK);
     const int cN = __popcll(mN), cT = __popcll(mT), cReal = __popcll(mR), cPark = __popcll(mP);
     if ((cN | cT | cReal | cPark) == 0) break;
     // the rule of k_render_sm: SHADE with a quorum of rays to finish, or of lanes between paths, or when nothing else can run
     const bool run_shade = (cReal >= MGPU_W5_SHADE_MIN) || (cN == 0 && cT == 0) || (cPark >= MGPU_W5_START_FORCE);
     if (!run_shade && cN >= cT * MGPU_W5_TRI_WEIGHT) {
       // ================================ NODE step ================================
-      const bool all_plain = __ballot(st == W_NODE && (flags & kFlagPlain) == 0u) == 0ull;
+      const bool all_plain = MGPU_BALLOT(st == W_NODE && (flags & kFlagPlain) == 0u) == 0ull;
       if (st == W_NODE) {
         const bool sx = (flags & 1u) != 0u, sy = (flags & 2u) != 0u, sz = (flags & 4u) != 0u;
         int r;
@@ -318,9 +318,9 @@ __global__ __launch_bounds__(BLOCK, MGPU_W5_WAVES) void k_render_w5(DScene sc, R
       }
 
       // ---- (2) path hand-out, executed by the whole wave (cursor variables are wave-uniform): k_render_sm's, item for item ----
-      const bool defer = !exhausted && (cN + cT) > 0 && __popcll(__ballot(want_pixel)) < MGPU_W5_START_MIN;
+      const bool defer = !exhausted && (cN + cT) > 0 && __popcll(MGPU_BALLOT(want_pixel)) < MGPU_W5_START_MIN;
       for (;;) {
-        const unsigned long long want = __ballot(want_pixel);
+        const unsigned long long want = MGPU_BALLOT(want_pixel);
         if (!want || exhausted || defer) break;
         if (in_item >= 64) {
           uint32_t cur_shard = 0, item_local = 0;
@@ -450,8 +450,8 @@ __global__ __launch_bounds__(BLOCK, MGPU_W5_WAVES) void k_render_w5(DScene sc, R
       }
       // the wave's counters: rays armed, paths started, Trace() calls of what ended (0, 1 or maxPathLength per lane)
       {
-        const uint32_t a = (uint32_t)__popcll(__ballot(armed)), s = (uint32_t)__popcll(__ballot(started));
-        const uint32_t t1 = (uint32_t)__popcll(__ballot(tc_add == 1u)), tm = (uint32_t)__popcll(__ballot(tc_add > 1u));
+        const uint32_t a = (uint32_t)__popcll(MGPU_BALLOT(armed)), s = (uint32_t)__popcll(MGPU_BALLOT(started));
+        const uint32_t t1 = (uint32_t)__popcll(MGPU_BALLOT(tc_add == 1u)), tm = (uint32_t)__popcll(MGPU_BALLOT(tc_add > 1u));
         if (lane == 0) {
           s_wcnt[wave][0] += a;
           s_wcnt[wave][1] += t1 + tm * (uint32_t)P.maxPathLength;

@@ -42,7 +42,7 @@ __device__ __forceinline__ void traverse_coop(const DScene &sc, const Stack<CAP,
   const uint32_t sgn = (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u);
   double ix, iy, iz;
   const bool inv_ok = inverse_dir_w(dir, ix, iy, iz);
-  const bool all_plain = __ballot(!(sc.boxes_ordered && inv_ok && origin_is_finite(org))) == 0ull;
+  const bool all_plain = MGPU_BALLOT(!(sc.boxes_ordered && inv_ok && origin_is_finite(org))) == 0ull;
   h.t = kDblMax; h.u = 0.0; h.v = 0.0; h.slot = kNoHit;
   int sp = -1;
   if (active) {
@@ -77,7 +77,7 @@ __device__ __forceinline__ void traverse_coop(const DScene &sc, const Stack<CAP,
         }
       }
     }
-    unsigned long long open = __ballot(leaf_cnt != 0);
+    unsigned long long open = MGPU_BALLOT(leaf_cnt != 0);
     if (!open) break; // every lane has run dry
     while (open) {    // one open leaf at a time, its triangles across the lanes
       const int L = __ffsll((long long)open) - 1;
@@ -111,7 +111,7 @@ __device__ __forceinline__ void traverse_coop(const DScene &sc, const Stack<CAP,
             cand = !(u < 0.0 || u > 1.0) && !(v < 0.0 || u + v > 1.0) && !(t < 0.0);
           }
         }
-        unsigned long long pm = __ballot(cand);
+        unsigned long long pm = MGPU_BALLOT(cand);
         while (pm) { // the reference's loop over the leaf, for the triangles that got as far as `t > tBest`
           const int j = __ffsll((long long)pm) - 1;
           pm &= pm - 1;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64) void k_trace_server(DScene sc, TraceMailbox *mb
     const bool work = owner && r != served;
     const bool stop = __shfl(r, kSrvSlotsPerWave) != 0u;
     const unsigned long long now = wall_clock64();
-    if (__ballot(work)) {
+    if (MGPU_BALLOT(work)) {
       V3 org = v3(0.0, 0.0, 0.0), dir = v3(1.0, 1.0, 1.0); // lanes without a request carry a harmless ray and never start it
       if (work) {
         // the ray: three 16-byte loads in flight together (ONE PCIe round trip; the request number's acquire orders them behind

@@ -77,15 +77,15 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
   uint32_t n_rays = 0, n_nodes = 0, n_tris = 0;
 
   for (;;) {
-    const unsigned long long mN = __ballot(st == TS_NODE);
-    const unsigned long long mT = __ballot(st == TS_TRI);
-    const unsigned long long mE = __ballot(st == TS_EMIT);
+    const unsigned long long mN = MGPU_BALLOT(st == TS_NODE);
+    const unsigned long long mT = MGPU_BALLOT(st == TS_TRI);
+    const unsigned long long mE = MGPU_BALLOT(st == TS_EMIT);
     const int cN = __popcll(mN), cT = __popcll(mT), cE = __popcll(mE);
     if ((cN | cT | cE) == 0) break;
     const bool run_emit = (cE >= MGPU_EMIT_MIN) || (cN == 0 && cT == 0);
     if (!run_emit && cN * MGPU_TRACE_NODE_WEIGHT >= cT) {
       // ================================ NODE step ================================
-      const bool all_plain = __ballot(st == TS_NODE && !ray_plain) == 0ull; // wave-uniform
+      const bool all_plain = MGPU_BALLOT(st == TS_NODE && !ray_plain) == 0ull; // wave-uniform
       if (st == TS_NODE) {
         const bool sx = (sgn & 1u) != 0u, sy = (sgn & 2u) != 0u, sz = (sgn & 4u) != 0u;
         // slab test in min/max form when every lane's ray qualifies, the literal form for this step otherwise
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
       // the whole wave stores them as 8-byte pieces, neighbouring lanes writing neighbouring pieces of one record -- a
       // lane storing its own record would issue 23 store instructions of one isolated 8-byte write per lane each.
       {
-        const unsigned long long em = __ballot(emitting);
+        const unsigned long long em = MGPU_BALLOT(emitting);
         const int total = __popcll(em);
         const int my_rank = (int)__popcll(em & ((1ull << lane) - 1ull));
         unsigned long long *stage = s_stage + (size_t)wave * (16 * 23 + 16);
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kTraceBlock, 4) void k_trace_sm(DScene sc, const Mg
       // ---- hand-out of ray indices, executed by the whole wave (the cursor is wave-uniform) ----
       bool want = emit_lane;
       for (;;) {
-        const unsigned long long wm = __ballot(want);
+        const unsigned long long wm = MGPU_BALLOT(want);
         if (!wm || exhausted) break;
         if (cur_next >= cur_end) {
           uint32_t base = 0;
