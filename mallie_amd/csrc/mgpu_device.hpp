@@ -660,13 +660,24 @@ __device__ __forceinline__ int wide_node_step(const WNode *__restrict__ wn, cons
                                               double iy, double iz, bool sx, bool sy, bool sz, uint32_t sgn /* sx | sy << 1 | sz << 2 */,
                                               double bt, uint32_t &cur,
                                               int &sp, uint32_t &tri_cur, uint32_t &tri_end, uint32_t &n_nodes,
-                                              const unsigned char *tl = nullptr) {
+                                              const unsigned char *tl = nullptr, const bool plain_rt = kPlain) {
   int res = WT_NODE;
 #pragma unroll 1
   for (int rep = 0; rep < REPS; ++rep) {
     if (cur == kWNone) {
       // next far child whose tmin still is <= the best t (bvh_accel.cc:586: `tmin <= maxT`, the only clause that can
       // have changed since it was pushed)
+#ifdef MGPU_EXP_POP1 // (experiment: one pop per repetition, a culled entry costs the repetition)
+      if (sp == 0) {
+        res = WT_DONE;
+        break;
+      }
+      uint32_t ref, tag;
+      double tmin;
+      --sp;
+      stk.get(sp, ref, tag, tmin);
+      if (!(tmin <= bt)) continue;
+#else
       uint32_t ref = 0, tag = 0;
       bool got = false;
       while (sp > 0) {
@@ -682,6 +693,7 @@ __device__ __forceinline__ int wide_node_step(const WNode *__restrict__ wn, cons
         res = WT_DONE;
         break;
       }
+#endif
       if (tag != kWInterior) {
         tri_cur = ref;
         tri_end = ref + tag;
@@ -717,8 +729,19 @@ __device__ __forceinline__ int wide_node_step(const WNode *__restrict__ wn, cons
     MGPU_KEEP4(m.x, m.y, m.z, m.w);
     n_nodes += 2;
     double t0, t1;
+#ifdef MGPU_EXP_ONE_LOOP // (experiment: one record loop for both slab forms, the form picked per repetition by a wave-uniform branch)
+    bool h0, h1;
+    if (plain_rt) {
+      h0 = slab_t<true>(a0, a1, a2, org, ix, iy, iz, sx, sy, sz, bt, t0);
+      h1 = slab_t<true>(a3, a4, a5, org, ix, iy, iz, sx, sy, sz, bt, t1);
+    } else {
+      h0 = slab_t<false>(a0, a1, a2, org, ix, iy, iz, sx, sy, sz, bt, t0);
+      h1 = slab_t<false>(a3, a4, a5, org, ix, iy, iz, sx, sy, sz, bt, t1);
+    }
+#else
     const bool h0 = slab_t<kPlain>(a0, a1, a2, org, ix, iy, iz, sx, sy, sz, bt, t0);
     const bool h1 = slab_t<kPlain>(a3, a4, a5, org, ix, iy, iz, sx, sy, sz, bt, t1);
+#endif
     const uint32_t axis = m.y >> 30, tag0 = m.y & kWInterior, tag1 = m.w;
     const bool nearIsSecond = ((sgn >> axis) & 1u) != 0u; // dirSign[node.axis], bvh_accel.cc:818-824
     const bool hn = nearIsSecond ? h1 : h0, hf = nearIsSecond ? h0 : h1;

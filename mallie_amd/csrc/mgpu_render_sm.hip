@@ -439,6 +439,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
           if (st == ST_NODE && sp < 0) st = ST_SHADE;
         } else {
           int r;
+#ifdef MGPU_EXP_ONE_LOOP
+          if (true)
+            r = wide_node_step<true, MGPU_WIDE_PER_STEP, kWideStackLds, TL>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, sgn, bt, cur, sp,
+                                                                           tri_cur, tri_end, n_nodes, lds_treelet, all_plain);
+          else
+#endif
           if (all_plain)
             r = wide_node_step<true, MGPU_WIDE_PER_STEP, kWideStackLds, TL>(sc.wnodes, wstk, org, ix, iy, iz, sx, sy, sz, sgn, bt, cur, sp,
                                                                            tri_cur, tri_end, n_nodes, lds_treelet);
