@@ -184,11 +184,15 @@ hipError_t launch_stream_states(int cap, hipStream_t s, const DScene &sc, const 
 //                               stay uncertain for later calls (the classification is cached per camera with the scene).
 //   The table equals the serial kernel's word for word (tests), 1080p pass: see DESIGN.md 4.7.
 // =====================================================================================================================
+#ifndef MGPU_STREAM_FINISH_RUN
+#define MGPU_STREAM_FINISH_RUN 4
+#endif
 namespace {
 constexpr int kRoundL = 128;                           // uncertain pixels per round
 constexpr int kRoundCand = kRoundL * (kRoundL + 1) / 2; // candidates (i, s), 0 <= s <= i < L
 constexpr int kSBlock = 256;                           // threads per workgroup of the kernels below
 constexpr int kClassifyRandom = 11;                    // random probes per pixel beside the five fixed ones
+constexpr uint32_t kFinishRun = MGPU_STREAM_FINISH_RUN; // fewest consecutive pixels a thread of k_stream_finish walks from one jump
 constexpr int kPromoteDx = 8, kPromoteDy = 1;          // a pixel that fails its verification takes this neighbourhood with it
 
 // v <- T^n v with the columns of T^(2^j) in LDS (`jm`: [levels][128])
@@ -468,30 +472,52 @@ __global__ __launch_bounds__(kSBlock) void k_stream_finish(DScene sc, StreamPara
   const uint4 s0 = *reinterpret_cast<const uint4 *>(P.state);
   uint4 *table = reinterpret_cast<uint4 *>(P.table) + (size_t)pass * npix;
   Counters c{};
-  for (uint32_t pix = blockIdx.x * kSBlock + threadIdx.x; pix < npix; pix += gridDim.x * kSBlock) {
-    unsigned char k = cls[pix];
-    if (k >= 4) k -= 4; // promoted by an earlier pass of this attempt: this attempt's C / J still count it as certain
-    const uint32_t j = J[pix];
-    const uint32_t h = R.C[pix] + R.USx[j];
-    const uint4 st = stream_jump(s0, 2ull * pix + (unsigned long long)R.E * h, jm);
-    table[pix] = st;
-    const bool assumed = k == 1 || (k == 2 && R.uflag[j] != 0);
-    const bool truth = primary_hits_state<CAP>(sc, stk, P, pix, st, c);
-    if (truth != assumed) {
-      if (k == 2) atomicAdd(&bad[1], 1u); // cannot happen: the chain traced exactly this ray
+  // A thread takes a RUN of consecutive pixels: it jumps from s0 to the first pixel's state once (a GF(2) matrix product per set bit
+  // of the offset: ~7 000 instructions) and walks on from there -- the next pixel starts 2 or 2 + E draws later, i.e. 16 or 16 + 8 E
+  // instructions of the generator itself.  (Round 6, counted on the ISA interpreter: the per-pixel jumps were 92 % of this kernel's and 60 % of a
+  // settled 1080p resolution's vector instructions.)  The offsets are still taken from C / USx pixel by pixel: a step that is neither of the two
+  // (it cannot be) jumps.
+  // Run length: the grid's threads share the frame evenly, one run each (a 1080p pass on 256 CUs: 8 pixels), at least kFinishRun -- this
+  // kernel is short enough that the longest thread decides its time.
+  const uint32_t nthreads = gridDim.x * kSBlock;
+  const uint32_t run_len = max(kFinishRun, (npix + nthreads - 1) / nthreads);
+  const uint32_t nruns = (npix + run_len - 1) / run_len;
+  for (uint32_t run = blockIdx.x * kSBlock + threadIdx.x; run < nruns; run += gridDim.x * kSBlock) {
+    const uint32_t p0 = run * run_len, p1 = min(npix, p0 + run_len);
+    unsigned long long n_cur = 0;
+    uint4 st = make_uint4(0, 0, 0, 0);
+    for (uint32_t pix = p0; pix < p1; ++pix) {
+      unsigned char k = cls[pix];
+      if (k >= 4) k -= 4; // promoted by an earlier pass of this attempt: this attempt's C / J still count it as certain
+      const uint32_t j = J[pix];
+      const uint32_t h = R.C[pix] + R.USx[j];
+      const unsigned long long n = 2ull * pix + (unsigned long long)R.E * h;
+      if (pix == p0 || n < n_cur || n - n_cur > 2ull + R.E) st = stream_jump(s0, n, jm);
       else {
-        // the probes missed something smaller than a pixel: uncertain from the next attempt on (and for later calls) -- together with
-        // its certain neighbours: such features come in runs (an edge seen edge-on), and every attempt costs a whole resolution
-        const int gx = (int)(pix % (uint32_t)P.W), gy = (int)(pix / (uint32_t)P.W);
-        for (int dy = -kPromoteDy; dy <= kPromoteDy; ++dy)
-          for (int dx = -kPromoteDx; dx <= kPromoteDx; ++dx) {
-            const int x = gx + dx, y = gy + dy;
-            if (x < 0 || y < 0 || x >= P.W || y >= P.H) continue;
-            const uint32_t q = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
-            const unsigned char cq = cls[q];
-            if (cq < 2) cls[q] = 4 + cq; // (idempotent: whoever else promotes it writes the same value)
-          }
-        atomicAdd(&bad[0], 1u);
+        uint32_t w[4] = {st.x, st.y, st.z, st.w};
+        for (uint32_t d = (uint32_t)(n - n_cur); d; --d) rng_step(w);
+        st = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+      n_cur = n;
+      table[pix] = st;
+      const bool assumed = k == 1 || (k == 2 && R.uflag[j] != 0);
+      const bool truth = primary_hits_state<CAP>(sc, stk, P, pix, st, c);
+      if (truth != assumed) {
+        if (k == 2) atomicAdd(&bad[1], 1u); // cannot happen: the chain traced exactly this ray
+        else {
+          // the probes missed something smaller than a pixel: uncertain from the next attempt on (and for later calls) -- together with
+          // its certain neighbours: such features come in runs (an edge seen edge-on), and every attempt costs a whole resolution
+          const int gx = (int)(pix % (uint32_t)P.W), gy = (int)(pix / (uint32_t)P.W);
+          for (int dy = -kPromoteDy; dy <= kPromoteDy; ++dy)
+            for (int dx = -kPromoteDx; dx <= kPromoteDx; ++dx) {
+              const int x = gx + dx, y = gy + dy;
+              if (x < 0 || y < 0 || x >= P.W || y >= P.H) continue;
+              const uint32_t q = (uint32_t)y * (uint32_t)P.W + (uint32_t)x;
+              const unsigned char cq = cls[q];
+              if (cq < 2) cls[q] = 4 + cq; // (idempotent: whoever else promotes it writes the same value)
+            }
+          atomicAdd(&bad[0], 1u);
+        }
       }
     }
   }
