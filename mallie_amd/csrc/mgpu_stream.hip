@@ -178,7 +178,8 @@ hipError_t launch_stream_states(int cap, hipStream_t s, const DScene &sc, const 
 //                               s += F[i][s] through it: L table reads instead of L ray casts on the critical path.  The walk of
 //                               round r is done by every workgroup of round r + 1's launch (which needs its S0).
 //     finish                    h_k = C[k] + (uncertain hits before k) for EVERY pixel, its start state into the table -- a thread jumps
-//                               from s0 to the first pixel of its run and steps the generator from pixel to pixel (round 6) -- and the VERIFICATION: every pixel's primary ray is traced with its final jitter and
+//                               from s0 to the first pixel of its run and steps the generator from pixel to pixel (round 6) -- and the
+//                               VERIFICATION: every pixel's primary ray is traced with its final jitter and
 //                               compared with the flag the chain assumed.  A "certain" pixel that disagrees (a feature smaller than
 //                               a pixel that the five probes missed) becomes uncertain and everything is resolved again; pixels
 //                               stay uncertain for later calls (the classification is cached per camera with the scene).
