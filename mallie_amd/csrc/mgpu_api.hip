@@ -1015,7 +1015,7 @@ int mgpu_scene_destroy(MgpuScene *s) {
   if (s->ahead_stream) (void)hipStreamDestroy(s->ahead_stream);
   {
     StreamScratch &X = s->stream;
-    void *sp[] = {X.cls, X.C, X.J, X.U, X.base, X.block_sum, X.F, X.uflag, X.Sarr, X.USx, X.totals, X.bad};
+    void *sp[] = {X.cls, X.C, X.J, X.U, X.base, X.block_sum, X.F, X.uflag, X.Sarr, X.USx, X.totals, X.bad, X.table, X.state, X.jump};
     for (void *p : sp)
       if (p) (void)hipFree(p);
   }
@@ -1941,11 +1941,7 @@ int mgpu_render_stream(MgpuScene *s, const double origin[3], const double corner
   const double t0 = now_ms();
   uint32_t *d_table = nullptr, *d_state = nullptr;
   uint4 *d_jump = nullptr;
-  auto cleanup = [&]() {
-    if (d_table) (void)hipFree(d_table);
-    if (d_state) (void)hipFree(d_state);
-    if (d_jump) (void)hipFree(d_jump);
-  };
+  auto cleanup = [&]() {}; // (the three buffers live in the scene's stream scratch since round 6 and go with the scene)
 #define TRY_S(expr)                                                             \
   do {                                                                          \
     hipError_t e_ = (expr);                                                     \
@@ -1973,11 +1969,31 @@ int mgpu_render_stream(MgpuScene *s, const double origin[3], const double corner
         stream_jump_matrices(jump.data());
       }
     }
-    TRY_S(hipMalloc((void **)&d_table, table_bytes));
-    TRY_S(hipMalloc((void **)&d_state, 16));
-    TRY_S(hipMalloc((void **)&d_jump, jump.size() * 4));
+    StreamScratch &X = s->stream;
+    if (table_bytes > X.table_bytes) {
+      if (X.table) {
+        TRY_S(hipDeviceSynchronize());
+        TRY_S(hipFree(X.table));
+        X.table = nullptr;
+        X.table_bytes = 0;
+      }
+      TRY_S(hipMalloc((void **)&X.table, table_bytes));
+      X.table_bytes = table_bytes;
+    }
+    if (!X.state) TRY_S(hipMalloc((void **)&X.state, 16));
+    if (!X.jump) {
+      TRY_S(hipMalloc((void **)&X.jump, jump.size() * 4));
+      hipError_t ej = hipMemcpy(X.jump, jump.data(), jump.size() * 4, hipMemcpyHostToDevice);
+      if (ej != hipSuccess) {
+        (void)hipFree(X.jump);
+        X.jump = nullptr;
+        return fail(MGPU_ERR_HIP, "upload of the jump matrices failed: %s", hipGetErrorString(ej));
+      }
+    }
+    d_table = X.table;
+    d_state = X.state;
+    d_jump = X.jump;
     TRY_S(hipMemcpy(d_state, stream_state, 16, hipMemcpyHostToDevice));
-    TRY_S(hipMemcpy(d_jump, jump.data(), jump.size() * 4, hipMemcpyHostToDevice));
     rc = ensure_overflow(s, 256);
     if (rc) {
       cleanup();

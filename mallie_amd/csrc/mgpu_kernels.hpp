@@ -175,6 +175,12 @@ struct StreamScratch {
   unsigned char *F = nullptr, *uflag = nullptr;
   uint32_t *Sarr = nullptr, *USx = nullptr, *totals = nullptr, *bad = nullptr;
   size_t npix_cap = 0, sarr_cap = 0;
+  // kept from call to call (round 6; a 1080p pass's table is 33 MB: allocating and freeing it, the 90 KB of jump matrices and the state word
+  // on every Render() call cost three hipMalloc / hipFree pairs, each hipFree a device synchronisation)
+  uint32_t *table = nullptr;           // start states, 16 bytes per pixel and pass
+  size_t table_bytes = 0;
+  uint32_t *state = nullptr;           // the stream state the kernels advance
+  uint4 *jump = nullptr;               // T^(2^j), uploaded once
   // what the cached classification belongs to
   double key_frame[12];
   float key_plane[4];
