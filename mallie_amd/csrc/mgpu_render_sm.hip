@@ -211,7 +211,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : (BLOCK == 768 ? 3 : MGP
     uint32_t s[4];
   };
   PrimRay *s_prim = LDS_SCENE ? reinterpret_cast<PrimRay *>(const_cast<unsigned char *>(lds_tris) + (((size_t)P.lds_tris_bytes + 15) & ~(size_t)15)) + (size_t)wave * 64
-                              : reinterpret_cast<PrimRay *>(P.prim_stage) + ((size_t)blockIdx.x * kWaves + (size_t)wave) * 64;
+                              : (PRIM ? reinterpret_cast<PrimRay *>(P.prim_stage) + ((size_t)blockIdx.x * kWaves + (size_t)wave) * 64 : nullptr);
   // Leaf hints (mgpu_device.hpp, leaf_hint_make).  LDS-resident scene: P.lds_hint_cap records of 96 bytes behind the staging above,
   // made here from the LDS copy of the triangles; a leaf's axis field (unused by the reference's traversal) becomes (hint + 1) << 16,
   // which the NODE step adds to tri_end when it opens the leaf (slots of an LDS-resident scene stay below 2^16).  (For the
