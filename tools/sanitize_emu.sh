@@ -12,7 +12,8 @@ case $mode in
 asan) read lib rt < <(python tests/emu/build_emu.py asan)
   LD_PRELOAD=$rt ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:detect_stack_use_after_return=0 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 MALLIE_MGPU_LIB=$lib \
     python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 3000 -k "$EXCL" --tb=line -p no:cacheprovider -rA > scratch/emu/asan_suite.txt 2>&1
-  echo "sanitizer reports: $(grep -c 'AddressSanitizer\|runtime error:' scratch/emu/asan_suite.txt)"; grep -E "passed|failed" scratch/emu/asan_suite.txt | tail -1 ;;
+  echo "sanitizer reports: $(grep -c 'AddressSanitizer\|runtime error:' scratch/emu/asan_suite.txt)"; grep -E "passed|failed" scratch/emu/asan_suite.txt | tail -1
+  grep -qE "[0-9]+ passed" scratch/emu/asan_suite.txt || echo "NO SUMMARY LINE: the run died (a sanitizer abort takes pytest's buffered output with it) -- rerun the last test printed with -x -s" ;;
 tsan) read lib rt < <(python tests/emu/build_emu.py tsan)
   LD_PRELOAD=$rt TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0:history_size=4" MALLIE_NO_TORCH=1 MALLIE_MGPU_LIB=$lib \
     python -m pytest tests/emu/cases_emu.py -q -s -p no:cacheprovider --tb=short -k "resident_server or several_ranks" > scratch/emu/tsan_suite.txt 2>&1
