@@ -1873,7 +1873,13 @@ bool run(const char *mangled, dim3 grid, dim3 block, size_t shmem, const void *k
     else if (h.second == "hidden_grid_dims") put16(1);
   }
   const unsigned nw = nthreads / 64;
-  constexpr size_t kQuantum = 4096;
+  // how long a wave runs before the next one of its workgroup gets its turn: 4096 instructions, or -- MGPU_EMU_ISA_QUANTUM=random[:seed] -- a
+  // random 1 .. 512 per turn, which moves the waves against each other between every pair of barriers (a missing barrier or a racy LDS protocol
+  // between waves then shows as a wrong frame sooner or later)
+  static const char *qenv = getenv("MGPU_EMU_ISA_QUANTUM");
+  static const bool qrandom = qenv && strncmp(qenv, "random", 6) == 0;
+  static uint64_t qstate = qrandom && qenv[6] == ':' ? strtoull(qenv + 7, nullptr, 0) * 2654435761ull + 1 : 88172645463325252ull;
+  size_t kQuantum = qenv && !qrandom && atol(qenv) > 0 ? (size_t)atol(qenv) : 4096;
   Machine M;
   M.k = &K;
   isa_counters[8] += 1;
@@ -1915,6 +1921,10 @@ bool run(const char *mangled, dim3 grid, dim3 block, size_t shmem, const void *k
         if (w.at_barrier) { ++waiting; continue; }
         progressed = true;
         M.yield = false;
+        if (qrandom) {
+          qstate ^= qstate << 13; qstate ^= qstate >> 7; qstate ^= qstate << 17;
+          kQuantum = 1 + (size_t)(qstate % 512);
+        }
         for (size_t n = 0; n < kQuantum && !M.yield; ++n) {
           const Inst &in = K.code[w.pc];
           K.hits[w.pc] += 1;
