@@ -57,7 +57,10 @@ def main():
             if p.wait() != 0:
                 raise SystemExit("hipcc -S failed")
         prof = keep or os.path.join(tmp, "profile.tsv")
+        sys.path.insert(0, os.path.join(R, "tests", "emu"))
+        import build_emu
         env = dict(os.environ, MGPU_EMU_ISA=":".join(dumps))
+        env.setdefault("MALLIE_MGPU_LIB", build_emu.build())  # (the emulator library: built when missing or stale)
         if defs:
             sys.stderr.write("note: -D flags change the ISA only; the emulator library (host side, launch parameters) is the default build\n")
         r = subprocess.run([sys.executable, os.path.join(R, "tools", "isa_run.py"), key, str(W), str(H), str(spp), prof], env=env, capture_output=True, text=True)
